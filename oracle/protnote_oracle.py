@@ -1,0 +1,271 @@
+"""CPU oracle for the ProtNote forward/training hot path.   *** TEST INFRASTRUCTURE, NOT PRODUCT ***
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product
+(protnote_amd/) never calls it and fails loudly when the HIP library is missing.
+
+A functional, float32, torch-CPU restatement of the reference algorithm operating directly on a
+reference-style ``state_dict`` (dict name -> tensor).  It deliberately keeps the reference's *naive*
+formulation (materialised [B*N_L, 2d] joint tensor, explicit padding masks) so that it is an
+independent check of the factorised HIP implementation.  All line numbers cite /root/reference.
+
+Parity pin: checked against golden vectors produced by running the reference itself on CPU
+(tests/golden/make_golden.py -> tests/golden/*.npz; tests/test_oracle_golden.py).  The reference has
+no golden vectors / KATs of its own for this path.  torchvision.ops.MLP (third-party,
+torchvision==0.15.2 per the reference's setup.py:17, absent here) is restated as its published layer
+order Linear,[norm],ReLU,Dropout ... Linear,Dropout; that ordering is pinned by the state-dict key
+names W_p.{0,1,4,5,8,9,12} only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder  (protnote/models/protein_encoders.py, protnote/data/datasets.py:535-569)
+# ------------------------------------------------------------------------------------------------
+def set_padding_to_sentinel(x: Tensor, lens: Tensor, sentinel: float) -> Tensor:
+    """datasets.py:535-569 - x[b, :, t] = sentinel for t >= lens[b]; x is [B, C, L]."""
+    b, _, l = x.shape
+    pad = torch.arange(l).expand(b, l) >= lens.unsqueeze(1)
+    return torch.where(pad.unsqueeze(1).expand_as(x), torch.tensor(sentinel, dtype=x.dtype), x)
+
+
+def masked_conv1d(x: Tensor, lens: Tensor, w: Tensor, b: Tensor, dilation: int) -> Tensor:
+    """protein_encoders.py:8-17 - mask, Conv1d(padding='same', stride 1), mask."""
+    x = set_padding_to_sentinel(x, lens, 0.0)
+    x = F.conv1d(x, w, b, stride=1, padding="same", dilation=dilation)
+    return set_padding_to_sentinel(x, lens, 0.0)
+
+
+def _bn(x: Tensor, sd: SD, prefix: str, training: bool, eps: float, momentum: float) -> Tensor:
+    """torch.nn.BatchNorm1d semantics incl. in-place running-stat update when training."""
+    rm, rv = sd[prefix + "running_mean"], sd[prefix + "running_var"]
+    y = F.batch_norm(x, rm, rv, sd[prefix + "weight"], sd[prefix + "bias"], training, momentum, eps)
+    if training and (prefix + "num_batches_tracked") in sd:
+        sd[prefix + "num_batches_tracked"] += 1
+    return y
+
+
+def residual_block(x: Tensor, lens: Tensor, sd: SD, p: str, dilation: int, training: bool) -> Tensor:
+    """protein_encoders.py:61-67 with BN eps=1e-3, momentum=0.01 (:36,:48)."""
+    out = F.relu(_bn(x, sd, p + "bn_activation_1.0.", training, 1e-3, 0.01))
+    out = masked_conv1d(out, lens, sd[p + "masked_conv1.weight"], sd[p + "masked_conv1.bias"], dilation)
+    out = F.relu(_bn(out, sd, p + "bn_activation_2.0.", training, 1e-3, 0.01))
+    out = masked_conv1d(out, lens, sd[p + "masked_conv2.weight"], sd[p + "masked_conv2.bias"], 1)
+    return out + x
+
+
+def num_resnet_blocks(sd: SD, prefix: str = "") -> int:
+    n = 0
+    while f"{prefix}resnet_blocks.{n}.masked_conv1.weight" in sd:
+        n += 1
+    return n
+
+
+def proteinfer_get_embeddings(sd: SD, x: Tensor, lens: Tensor, training: bool = False,
+                              dilation_base: int = 3, prefix: str = "",
+                              taps: Optional[dict] = None) -> Tensor:
+    """protein_encoders.py:109-118.  `sd` buffers are updated in place when training."""
+    feats = masked_conv1d(x, lens, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], 1)
+    if taps is not None:
+        taps["conv1"] = feats
+    for i in range(num_resnet_blocks(sd, prefix)):
+        feats = residual_block(feats, lens, sd, f"{prefix}resnet_blocks.{i}.", dilation_base ** i, training)
+        if taps is not None:
+            taps[f"block{i}"] = feats
+    feats = set_padding_to_sentinel(feats, lens, 0.0)
+    return feats.sum(dim=-1) / lens.unsqueeze(-1)
+
+
+def proteinfer_forward(sd: SD, x: Tensor, lens: Tensor, training: bool = False, dilation_base: int = 3,
+                       prefix: str = "") -> Tensor:
+    """protein_encoders.py:120-123."""
+    e = proteinfer_get_embeddings(sd, x, lens, training, dilation_base, prefix)
+    return F.linear(e, sd[prefix + "output_layer.weight"], sd[prefix + "output_layer.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
+# heads  (protnote/models/ProtNote.py)
+# ------------------------------------------------------------------------------------------------
+def _linear_indices(sd: SD, prefix: str):
+    idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix)
+                  and k.endswith(".weight") and sd[k].dim() == 2})
+    return idx
+
+
+def mlp_rows(sd: SD, prefix: str, x: Tensor, training: bool) -> Tensor:
+    """torchvision.ops.MLP as built at ProtNote.py:63-81: (Linear no-bias, BN(eps 1e-5, mom 0.1), ReLU,
+    Dropout(0)) x (n-1), Linear no-bias, Dropout(0)."""
+    lin = _linear_indices(sd, prefix)
+    for n, i in enumerate(lin):
+        x = F.linear(x, sd[f"{prefix}{i}.weight"], sd.get(f"{prefix}{i}.bias"))
+        if n < len(lin) - 1:
+            x = F.relu(_bn(x, sd, f"{prefix}{i + 1}.", training, 1e-5, 0.1))
+    return x
+
+
+def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool) -> Tensor:
+    """get_mlp ProtNote.py:337-378 with batch_norm=True: (Linear no-bias, BN, ReLU[, Dropout]) x n, Linear(h,1)."""
+    lin = _linear_indices(sd, prefix)
+    for n, i in enumerate(lin):
+        x = F.linear(x, sd[f"{prefix}{i}.weight"], sd.get(f"{prefix}{i}.bias"))
+        if n < len(lin) - 1:
+            if f"{prefix}{i + 1}.running_mean" in sd:
+                x = _bn(x, sd, f"{prefix}{i + 1}.", training, 1e-5, 0.1)
+            x = F.relu(x)
+    return x
+
+
+def joint_embeddings(P_e: Tensor, L_e: Tensor, fusion: str) -> Tensor:
+    """ProtNote.py:112-152 - row index = i * N_L + j (protein-major)."""
+    b, n = P_e.shape[0], L_e.shape[0]
+    j = torch.cat([P_e[:, None, :].expand(b, n, -1), L_e[None, :, :].expand(b, n, -1)], dim=2)
+    j = j.reshape(b * n, -1)
+    d = P_e.shape[1]
+    if fusion == "concatenation_diff":
+        j = torch.cat([j, j[:, :d] - j[:, d:]], dim=-1)
+    if fusion == "concatenation_prod":
+        j = torch.cat([j, j[:, :d] * j[:, d:]], dim=-1)
+    return j
+
+
+def noised_label_embeddings(L_f: Tensor, alpha: float, u: Tensor) -> Tensor:
+    """ProtNote.py:219-240 with the uniform sample `u` in [0,1) supplied by the caller."""
+    return L_f + (2 * u - 1) * (alpha / math.sqrt(L_f.shape[1]))
+
+
+def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], label_embeddings: Tensor,
+                     *, fusion: str = "concatenation", training: bool = False, temperature: float = 0.07,
+                     descriptions_per_label: int = 1, noise_alpha: float = 0.0,
+                     noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
+                     dilation_base: int = 3, sequence_embeddings: Optional[Tensor] = None,
+                     aux: Optional[dict] = None) -> Tensor:
+    """ProtNote.forward (ProtNote.py:168-334), cached-label-embedding path; encoder frozen (no_grad)."""
+    L_f = label_embeddings
+    if training and label_token_counts is not None and noise_alpha > 0:
+        L_f = noised_label_embeddings(L_f, noise_alpha, noise_u)
+    if sequence_embeddings is not None:
+        P_f = sequence_embeddings
+    else:
+        with torch.no_grad():
+            P_f = proteinfer_get_embeddings(sd, onehots, lens, training, dilation_base, "sequence_encoder.")
+    P_e = mlp_rows(sd, "W_p.", P_f, training)
+    L_e = mlp_rows(sd, "W_l.", L_f, training)
+    if aux is not None:
+        aux.update(P_f=P_f, P_e=P_e, L_e=L_e)
+    b, n = P_e.shape[0], L_e.shape[0]
+    if fusion == "similarity":
+        logits = torch.mm(F.normalize(P_e, dim=-1, p=2), F.normalize(L_e, dim=-1, p=2).t()) / temperature
+    elif fusion.startswith("concatenation"):
+        logits = output_mlp(sd, "output_layer.", joint_embeddings(P_e, L_e, fusion), training)
+    else:
+        raise ValueError("feature fusion method not implemented")
+    if training or descriptions_per_label == 1:
+        return logits.reshape(b, n)
+    p = torch.sigmoid(logits).reshape(b, n // descriptions_per_label, descriptions_per_label).mean(-1)
+    return torch.special.logit(p, eps=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / metrics / optimiser step
+# ------------------------------------------------------------------------------------------------
+def bce_loss(logits: Tensor, target: Tensor, pos_weight: float = 1.0) -> Tensor:
+    """losses.py:275-276."""
+    return F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor(pos_weight))
+
+
+def focal_loss(logits: Tensor, target: Tensor, gamma: float = 2.0, alpha: float = -1.0,
+               label_smoothing: float = 0.0) -> Tensor:
+    """losses.py:190-213 (reduction='mean')."""
+    if label_smoothing > 0:
+        target = target * (1.0 - label_smoothing) + (1 - target) * label_smoothing
+    bce = F.binary_cross_entropy_with_logits(logits, target, reduction="none")
+    pt = torch.exp(-bce)
+    loss = ((1 - pt) ** gamma) * bce
+    if alpha >= 0:
+        loss = (alpha * target + (1 - alpha) * (1 - target)) * loss
+    return loss.mean()
+
+
+def tp_fn_fp(probs: Tensor, labels: Tensor, threshold: float = 0.5):
+    """ProtNoteTrainer.py:61-83."""
+    preds = (probs >= threshold).float()
+    return (preds * labels).sum(0), ((1 - preds) * labels).sum(0), (preds * (1 - labels)).sum(0)
+
+
+def f1_per_label(tp, fn, fp):
+    """ProtNoteTrainer.py:54-58."""
+    pr = tp / (tp + fp + 1e-8)
+    rc = tp / (tp + fn + 1e-8)
+    return 2 * (pr * rc) / (pr + rc + 1e-8)
+
+
+def f1_micro(tp, fn, fp):
+    """ProtNoteTrainer.py:42-51."""
+    return f1_per_label(tp.sum(), fn.sum(), fp.sum())
+
+
+def trainable_names(sd: SD):
+    """ProtNoteTrainer.py:199-226 with the default config: encoder frozen, heads trainable."""
+    skip = ("running_mean", "running_var", "num_batches_tracked")
+    return [k for k in sd if not k.startswith("sequence_encoder.") and not k.startswith("label_encoder.")
+            and not k.endswith(skip)]
+
+
+def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, multihots: Tensor, *,
+               loss: str = "BCE", fusion: str = "concatenation", noise_alpha: float = 0.0,
+               noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
+               clip: Optional[float] = 1.0, lr: float = 3e-4, dilation_base: int = 3,
+               adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
+               **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+    """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU).
+
+    Updates `sd` in place (params by Adam, BN buffers by the train-mode forward).
+    Returns (logits, loss, grads, total_grad_norm)."""
+    names = trainable_names(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    logits = protnote_forward(work, onehots, lens, label_embeddings, fusion=fusion, training=True,
+                              noise_alpha=noise_alpha, noise_u=noise_u, temperature=temperature,
+                              label_token_counts=label_token_counts, dilation_base=dilation_base)
+    y = multihots.float()
+    l = bce_loss(logits, y, **loss_kw) if loss == "BCE" else focal_loss(logits, y, **loss_kw)
+    grads_t = torch.autograd.grad(l, [leaves[k] for k in names], allow_unused=True)
+    grads = {k: g for k, g in zip(names, grads_t) if g is not None}
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    if apply_update:
+        coef = 1.0
+        if clip is not None:  # torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm/(norm+1e-6), max=1)
+            coef = min(float(clip) / (float(total) + 1e-6), 1.0)
+        st = adam_state if adam_state is not None else {}
+        st["step"] = st.get("step", 0) + 1
+        t = st["step"]
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for k, g in grads.items():
+            g = g * coef
+            m = st.setdefault("m/" + k, torch.zeros_like(g))
+            v = st.setdefault("v/" + k, torch.zeros_like(g))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+            sd[k] = sd[k] - (lr / (1 - b1 ** t)) * (m / denom)
+    return logits.detach(), l.detach(), grads, total
+
+
+def as_torch_sd(npz, prefix: str) -> SD:
+    """Load 'prefix/<state-dict key>' arrays of a golden .npz as a torch state dict (copies)."""
+    import numpy as np
+
+    out = {}
+    for k in npz.files:
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(np.array(npz[k]))
+    return out

@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REFERENCE implementation on CPU.
+
+Runs ONLY in the authoring container (needs /root/reference).  The reference's Python never
+travels to the GPU box; only the .npz files written here do.  Re-run:
+
+    python tests/golden/make_golden.py
+
+What is executed (all f32, CPU, torch.manual_seed fixed):
+  * protnote/models/protein_encoders.py  ProteInfer.get_embeddings / forward   (eval + train-mode BN)
+  * protnote/models/ProtNote.py          ProtNote.forward for the 4 FEATURE_FUSION modes,
+                                         eval (with and without description ensembling) and train
+  * protnote/utils/losses.py             BCE / FocalLoss through get_loss
+  * protnote/models/ProtNoteTrainer.py   calculate_tp_fn_fp / calculate_f1 / calculate_f1_micro and the
+                                         body of the train step (:728-755): loss -> backward ->
+                                         clip_grad_norm_(1.0) -> Adam(lr=3e-4).step()
+  * protnote/data/collators.py           collate_variable_sequence_length
+
+Absent third-party modules that are NOT on the arithmetic path are stubbed in sys.modules.
+torchvision.ops.MLP (pinned torchvision==0.15.2 in the reference's setup.py:17) is absent from this
+image; its constructor is restated below (a pure nn.Sequential builder; the arithmetic is torch.nn).
+"""
+import os
+import sys
+import types
+import importlib.machinery
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PROTNOTE_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, k):
+        return _Anything()
+
+
+def install_stubs():
+    import transformers  # noqa: F401  (must be imported before a fake torchvision exists)
+
+    class MLP(torch.nn.Sequential):
+        """torchvision.ops.MLP (v0.15.2) constructor, restated."""
+
+        def __init__(self, in_channels, hidden_channels, norm_layer=None,
+                     activation_layer=torch.nn.ReLU, inplace=None, bias=True, dropout=0.0):
+            params = {} if inplace is None else {"inplace": inplace}
+            layers = []
+            in_dim = in_channels
+            for hidden_dim in hidden_channels[:-1]:
+                layers.append(torch.nn.Linear(in_dim, hidden_dim, bias=bias))
+                if norm_layer is not None:
+                    layers.append(norm_layer(hidden_dim))
+                layers.append(activation_layer(**params))
+                layers.append(torch.nn.Dropout(dropout, **params))
+                in_dim = hidden_dim
+            layers.append(torch.nn.Linear(in_dim, hidden_channels[-1], bias=bias))
+            layers.append(torch.nn.Dropout(dropout, **params))
+            super().__init__(*layers)
+
+    tv = _stub("torchvision")
+    tv.ops = _stub("torchvision.ops", MLP=MLP)
+    bio = _stub("Bio")
+    bio.SeqIO = _stub("Bio.SeqIO")
+    bio.ExPASy = _stub("Bio.ExPASy", Enzyme=_Anything())
+    _stub("Bio.Seq", Seq=_Anything)
+    _stub("Bio.SeqRecord", SeqRecord=_Anything)
+    _stub("blosum", BLOSUM=lambda n: {})
+    _stub("wget")
+    _stub("pynvml", nvmlInit=_Anything(), nvmlDeviceGetHandleByIndex=_Anything(),
+          nvmlDeviceGetMemoryInfo=_Anything())
+    _stub("loralib", Linear=_Anything)
+    _stub("wandb")
+    tm = _stub("torchmetrics", MetricCollection=_Anything, Metric=object)
+    tm.classification = _stub("torchmetrics.classification", Precision=_Anything, Recall=_Anything,
+                              BinaryPrecision=_Anything, BinaryRecall=_Anything, F1Score=_Anything,
+                              AveragePrecision=_Anything)
+    te = _stub("torcheval")
+    te.metrics = _stub("torcheval.metrics", MultilabelAUPRC=_Anything, BinaryAUPRC=_Anything,
+                       BinaryBinnedAUPRC=_Anything, MultilabelBinnedAUPRC=_Anything, Mean=_Anything,
+                       BinaryF1Score=_Anything)
+    te.metrics.toolkit = _stub("torcheval.metrics.toolkit", sync_and_compute=_Anything())
+    sys.path.insert(0, REF)
+
+
+def randomize_(module, g):
+    """Randomise BN affine/running stats and rescale weights so activations/logits are O(1)
+    (default init gives logits ~ -0.0105 +- 5e-4, which would make a 1e-3 tolerance vacuous)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.3)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.5)
+        elif isinstance(m, (torch.nn.Linear, torch.nn.Conv1d)):
+            with torch.no_grad():
+                fan_in = m.weight[0].numel()
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.6 / fan_in ** 0.5))
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def onehots(g, lens, lmax, pad_garbage=False):
+    b = len(lens)
+    x = torch.zeros(b, 20, lmax)
+    ids = torch.randint(0, 20, (b, lmax), generator=g)
+    x.scatter_(1, ids[:, None, :], 1.0)
+    for i, n in enumerate(lens):
+        x[i, :, n:] = 7.0 if pad_garbage else 0.0
+    return x, ids
+
+
+# --------------------------------------------------------------------------------------------
+def golden_encoder():
+    from protnote.models.protein_encoders import ProteInfer
+
+    g = torch.Generator().manual_seed(1234)
+    cfg = dict(num_labels=13, input_channels=20, output_channels=52, kernel_size=9,
+               dilation_base=3, num_resnet_blocks=5, bottleneck_factor=0.5)
+    torch.manual_seed(0)
+    model = ProteInfer(activation=torch.nn.ReLU, **cfg)
+    randomize_(model, g)
+    out = {"cfg_" + k: np.array(v) for k, v in cfg.items()}
+    out.update(sd_np(model, "sd/"))
+
+    lens = [200, 1, 37, 150, 199, 9]
+    lmax = 200
+    x, ids = onehots(g, lens, lmax, pad_garbage=True)
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    out["x"] = x.numpy()
+    out["lens"] = lens_t.numpy()
+
+    model.eval()
+    with torch.no_grad():
+        feats = model.conv1(x, lens_t)
+        out["eval/conv1"] = feats.numpy().copy()
+        for i, blk in enumerate(model.resnet_blocks):
+            feats = blk(feats, lens_t)
+            if i in (0, 4):
+                out[f"eval/block{i}"] = feats.numpy().copy()
+        out["eval/embeddings"] = model.get_embeddings(x, lens_t).numpy()
+        out["eval/logits"] = model(x, lens_t).numpy()
+        # pad-length invariance: same sequences padded to 260 with zeros
+        x2 = torch.zeros(len(lens), 20, 260)
+        x2[:, :, :lmax] = x
+        for i, n in enumerate(lens):
+            x2[i, :, n:] = 0.0
+        out["eval/embeddings_pad260"] = model.get_embeddings(x2, lens_t).numpy()
+
+    # train-mode BN: frozen encoder still uses batch stats and updates buffers
+    model.train()
+    with torch.no_grad():
+        out["train/embeddings"] = model.get_embeddings(x, lens_t).numpy()
+    out.update(sd_np(model, "sd_after_train/"))
+    np.savez_compressed(os.path.join(OUT, "encoder_small.npz"), **out)
+    print("encoder_small.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd")})
+
+
+# --------------------------------------------------------------------------------------------
+def _train_step(model, loss_fn, inputs, targets, clip=1.0, lr=3e-4):
+    """Body of ProtNoteTrainer.train_one_epoch :728-755 on CPU (autocast/GradScaler are no-ops)."""
+    from torch.nn.utils import clip_grad_norm_
+
+    params = [p for n, p in model.named_parameters()
+              if p.requires_grad and not n.startswith("sequence_encoder")]
+    opt = torch.optim.Adam(params, lr=lr)
+    logits, _ = model(**inputs)
+    loss = loss_fn(logits, targets.float())
+    loss.backward()
+    grads = {n: p.grad.detach().numpy().copy() for n, p in model.named_parameters()
+             if p.grad is not None}
+    total_norm = clip_grad_norm_(model.parameters(), max_norm=clip)
+    opt.step()
+    opt.zero_grad()
+    return logits.detach().numpy().copy(), float(loss.detach()), grads, float(total_norm)
+
+
+def golden_protnote():
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.losses import get_loss
+    import protnote.models.ProtNote as PN
+
+    enc_cfg = dict(num_labels=7, input_channels=20, output_channels=28, kernel_size=9,
+                   dilation_base=3, num_resnet_blocks=2, bottleneck_factor=0.5)
+    head_cfg = dict(protein_embedding_dim=28, label_embedding_dim=24, latent_dim=16,
+                    output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                    outout_mlp_add_batchnorm=True, projection_head_num_layers=4,
+                    projection_head_hidden_dim_scale_factor=3, dropout=0.0,
+                    label_embedding_noising_alpha=20.0, temperature=0.07)
+    lens = [50, 3, 21, 50, 17, 44]
+    lmax = 50
+    n_labels = 10
+    for fusion in ("concatenation", "concatenation_diff", "concatenation_prod", "similarity"):
+        g = torch.Generator().manual_seed(99)
+        torch.manual_seed(1)
+        enc = ProteInfer(activation=torch.nn.ReLU, **enc_cfg)
+        model = ProtNote(sequence_encoder=enc, label_encoder=None, feature_fusion=fusion,
+                         inference_descriptions_per_label=2, **head_cfg)
+        randomize_(model, g)
+        for n, p in model.named_parameters():
+            if n.startswith("sequence_encoder"):
+                p.requires_grad = False
+        out = {"fusion": np.array(fusion)}
+        out.update({"enc_cfg_" + k: np.array(v) for k, v in enc_cfg.items()})
+        out.update({"head_cfg_" + k: np.array(v) for k, v in head_cfg.items()})
+        out.update(sd_np(model, "sd/"))
+        x, _ = onehots(g, lens, lmax)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        # 2 descriptions per label, consecutive rows belong to one label (datasets.py:327-343)
+        lab = torch.randn(n_labels * 2, 24, generator=g)
+        counts = torch.randint(3, 30, (n_labels * 2,), generator=g)
+        y = (torch.rand(len(lens), n_labels, generator=g) < 0.3).to(torch.int64)
+        out.update(x=x.numpy(), lens=lens_t.numpy(), label_embeddings=lab.numpy(),
+                   label_token_counts=counts.numpy(), multihots=y.numpy())
+
+        model.eval()
+        with torch.no_grad():
+            lg, _ = model(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab)
+            out["eval/logits_ens2"] = lg.numpy()          # [B, n_labels] (ensembled, ProtNote.py:313-322)
+            model.inference_descriptions_per_label = 1
+            lg1, _ = model(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab)
+            out["eval/logits_raw"] = lg1.numpy()          # [B, 2*n_labels]
+            model.inference_descriptions_per_label = 2
+            out["eval/P_f"] = model.sequence_encoder.get_embeddings(x, lens_t).numpy()
+            out["eval/P_e"] = model.W_p(torch.from_numpy(out["eval/P_f"])).numpy()
+            out["eval/L_e"] = model.W_l(lab).numpy()
+
+        # ---- train step on the first description of each label, fixed noise tensor ----
+        lab1 = lab[0::2].contiguous()
+        cnt1 = counts[0::2].contiguous()
+        u = torch.rand(lab1.shape, generator=g)
+        out["train/noise_u"] = u.numpy()
+        real_rand_like = torch.rand_like
+        PN.torch.rand_like = lambda t, *a, **k: u.clone()
+        try:
+            for loss_name in ("BCE", "FocalLoss"):
+                m2 = type(model)(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg),
+                                 label_encoder=None, feature_fusion=fusion,
+                                 inference_descriptions_per_label=2, **head_cfg)
+                m2.load_state_dict(model.state_dict())
+                for n, p in m2.named_parameters():
+                    if n.startswith("sequence_encoder"):
+                        p.requires_grad = False
+                m2.train()
+                cfg = {"params": {"LOSS_FN": loss_name, "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1,
+                                  "LABEL_SMOOTHING": 0.0}}
+                loss_fn = get_loss(cfg, bce_pos_weight=torch.tensor(1.0))
+                inputs = dict(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab1,
+                              label_token_counts=cnt1)
+                logits, loss, grads, gnorm = _train_step(m2, loss_fn, inputs, y)
+                p = f"train_{loss_name}/"
+                out[p + "logits"] = logits
+                out[p + "loss"] = np.array(loss, dtype=np.float32)
+                out[p + "grad_norm"] = np.array(gnorm, dtype=np.float32)
+                for k, v in grads.items():
+                    out[p + "grad/" + k] = v
+                out.update(sd_np(m2, p + "sd_after/"))
+        finally:
+            PN.torch.rand_like = real_rand_like
+        fn = os.path.join(OUT, f"protnote_small_{fusion}.npz")
+        np.savez_compressed(fn, **out)
+        print(os.path.basename(fn), os.path.getsize(fn) // 1024, "KiB")
+
+
+# --------------------------------------------------------------------------------------------
+def golden_losses_metrics():
+    from protnote.utils.losses import get_loss, FocalLoss
+    from protnote.models.ProtNoteTrainer import calculate_tp_fn_fp, calculate_f1, calculate_f1_micro
+
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(33, 57, generator=g) * 3
+    logits[0, 0] = 0.0          # sigmoid == 0.5 == threshold edge (>=)
+    logits[1, 1] = 40.0
+    logits[2, 2] = -40.0
+    y = (torch.rand(33, 57, generator=g) < 0.2).to(torch.int64)
+    out = {"logits": logits.numpy(), "multihots": y.numpy()}
+    for name, pw in (("BCE", 1.0), ("BCE_pw", 3.5)):
+        fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(pw))
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg, y.float())
+        l.backward()
+        out[f"{name}/loss"] = l.detach().numpy()
+        out[f"{name}/dlogits"] = lg.grad.numpy()
+        out[f"{name}/pos_weight"] = np.array(pw, dtype=np.float32)
+    for name, gamma, alpha, ls in (("Focal", 2, -1, 0.0), ("Focal_a", 2, 0.25, 0.0),
+                                   ("Focal_ls", 1.5, -1, 0.1)):
+        fn = FocalLoss(alpha=alpha, gamma=gamma, label_smoothing=ls)
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg, y.float())
+        l.backward()
+        out[f"{name}/loss"] = l.detach().numpy()
+        out[f"{name}/dlogits"] = lg.grad.numpy()
+        out[f"{name}/params"] = np.array([gamma, alpha, ls], dtype=np.float32)
+    for th in (0.5, 0.3):
+        tp, fn_, fp = calculate_tp_fn_fp(torch.sigmoid(logits), y, threshold=th)
+        out[f"th{th}/tp"], out[f"th{th}/fn"], out[f"th{th}/fp"] = tp.numpy(), fn_.numpy(), fp.numpy()
+        out[f"th{th}/f1"] = calculate_f1(tp, fn_, fp).numpy()
+        out[f"th{th}/f1_micro"] = calculate_f1_micro(tp, fn_, fp).numpy()
+    np.savez_compressed(os.path.join(OUT, "losses_metrics.npz"), **out)
+    print("losses_metrics.npz")
+
+
+# --------------------------------------------------------------------------------------------
+def golden_collator():
+    from protnote.data.collators import collate_variable_sequence_length
+
+    g = torch.Generator().manual_seed(5)
+    lens = [7, 3, 11, 5]
+    n_lab, d = 6, 8
+    lab = torch.randn(n_lab, d, generator=g)
+    cnt = torch.randint(1, 9, (n_lab,), generator=g)
+    batch = []
+    out = {}
+    for i, n in enumerate(lens):
+        ids = torch.randint(0, 20, (n,), generator=g)
+        oh = torch.nn.functional.one_hot(ids, 20).T.float()       # [20, n] (datasets.py process_example)
+        mh = (torch.rand(n_lab, generator=g) < 0.4).to(torch.int64)
+        batch.append({"sequence_onehots": oh, "sequence_id": f"P{i}", "sequence_length": torch.tensor(n),
+                      "label_multihots": mh, "label_embeddings": lab, "label_token_counts": cnt})
+        out[f"in/ids{i}"] = ids.numpy()
+        out[f"in/multihots{i}"] = mh.numpy()
+    out["in/label_embeddings"] = lab.numpy()
+    out["in/label_token_counts"] = cnt.numpy()
+    res = collate_variable_sequence_length(batch, label_sample_size=None, distribute_labels=False,
+                                           shuffle_labels=False, in_batch_sampling=False,
+                                           grid_sampler=False, world_size=1, rank=0)
+    for k, v in res.items():
+        if torch.is_tensor(v):
+            out["out/" + k] = v.numpy()
+            out["out_dtype/" + k] = np.array(str(v.dtype))
+        else:
+            out["out/" + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "collator.npz"), **out)
+    print("collator.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    install_stubs()
+    torch.set_num_threads(8)
+    golden_encoder()
+    golden_protnote()
+    golden_losses_metrics()
+    golden_collator()

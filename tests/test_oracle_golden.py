@@ -1,0 +1,116 @@
+"""Pin the CPU oracle (oracle/protnote_oracle.py) to vectors produced by the reference itself
+(tests/golden/make_golden.py).  Tolerances: 2e-5 abs on O(1) activations/logits (f32 reassociation only),
+exact for integer-valued counts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+
+FUSIONS = ("concatenation", "concatenation_diff", "concatenation_prod", "similarity")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_encoder_eval_and_train(golden_dir):
+    g = _load(golden_dir, "encoder_small.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    taps = {}
+    emb = O.proteinfer_get_embeddings(sd, x, lens, training=False, taps=taps)
+    for k in ("conv1", "block0", "block4"):
+        np.testing.assert_allclose(taps[k].numpy(), g["eval/" + k], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(emb.numpy(), g["eval/embeddings"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(O.proteinfer_forward(sd, x, lens).numpy(), g["eval/logits"], atol=5e-5, rtol=1e-5)
+    # train-mode BN: batch statistics + running-stat drift of the "frozen" encoder
+    emb_t = O.proteinfer_get_embeddings(sd, x, lens, training=True)
+    np.testing.assert_allclose(emb_t.numpy(), g["train/embeddings"], atol=5e-5, rtol=1e-5)
+    after = O.as_torch_sd(g, "sd_after_train/")
+    for k, v in after.items():
+        np.testing.assert_allclose(sd[k].numpy(), v.numpy(), atol=1e-5, rtol=1e-5, err_msg=k)
+
+
+def test_encoder_pad_invariance(golden_dir):
+    g = _load(golden_dir, "encoder_small.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    x2 = torch.zeros(x.shape[0], 20, 260)
+    x2[:, :, : x.shape[2]] = x
+    emb = O.proteinfer_get_embeddings(sd, x2, lens)
+    np.testing.assert_allclose(emb.numpy(), g["eval/embeddings_pad260"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(emb.numpy(), g["eval/embeddings"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+def test_protnote_eval(golden_dir, fusion):
+    g = _load(golden_dir, f"protnote_small_{fusion}.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])
+    T = float(g["head_cfg_temperature"])
+    aux = {}
+    raw = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=T, aux=aux)
+    np.testing.assert_allclose(aux["P_f"].numpy(), g["eval/P_f"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(aux["P_e"].numpy(), g["eval/P_e"], atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(aux["L_e"].numpy(), g["eval/L_e"], atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(raw.numpy(), g["eval/logits_raw"], atol=1e-4, rtol=1e-5)
+    ens = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=T, descriptions_per_label=2)
+    np.testing.assert_allclose(ens.numpy(), g["eval/logits_ens2"], atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+@pytest.mark.parametrize("loss", ("BCE", "FocalLoss"))
+def test_protnote_train_step(golden_dir, fusion, loss):
+    g = _load(golden_dir, f"protnote_small_{fusion}.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous()
+    y = torch.from_numpy(g["multihots"])
+    u = torch.from_numpy(g["train/noise_u"])
+    logits, l, grads, gn = O.train_step(
+        sd, x, lens, lab, y, loss=loss, fusion=fusion, noise_alpha=float(g["head_cfg_label_embedding_noising_alpha"]),
+        noise_u=u, label_token_counts=cnt, temperature=float(g["head_cfg_temperature"]))
+    p = f"train_{loss}/"
+    np.testing.assert_allclose(logits.numpy(), g[p + "logits"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(float(l), float(g[p + "loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(gn), float(g[p + "grad_norm"]), rtol=1e-4)
+    for k in g.files:
+        if k.startswith(p + "grad/"):
+            name = k[len(p + "grad/"):]
+            ref = g[k]
+            np.testing.assert_allclose(grads[name].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=name)
+    for k in g.files:
+        if k.startswith(p + "sd_after/"):
+            name = k[len(p + "sd_after/"):]
+            np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
+
+
+def test_losses_and_metrics(golden_dir):
+    g = _load(golden_dir, "losses_metrics.npz")
+    logits = torch.from_numpy(g["logits"])
+    y = torch.from_numpy(g["multihots"])
+    for name in ("BCE", "BCE_pw"):
+        lg = logits.clone().requires_grad_(True)
+        l = O.bce_loss(lg, y.float(), pos_weight=float(g[name + "/pos_weight"]))
+        l.backward()
+        np.testing.assert_allclose(float(l), float(g[name + "/loss"]), rtol=1e-6)
+        np.testing.assert_allclose(lg.grad.numpy(), g[name + "/dlogits"], atol=1e-9, rtol=1e-5)
+    for name in ("Focal", "Focal_a", "Focal_ls"):
+        gamma, alpha, ls = (float(v) for v in g[name + "/params"])
+        lg = logits.clone().requires_grad_(True)
+        l = O.focal_loss(lg, y.float(), gamma=gamma, alpha=alpha, label_smoothing=ls)
+        l.backward()
+        np.testing.assert_allclose(float(l), float(g[name + "/loss"]), rtol=1e-6)
+        np.testing.assert_allclose(lg.grad.numpy(), g[name + "/dlogits"], atol=1e-9, rtol=1e-5)
+    for th in (0.5, 0.3):
+        tp, fn, fp = O.tp_fn_fp(torch.sigmoid(logits), y, threshold=th)
+        assert np.array_equal(tp.numpy(), g[f"th{th}/tp"])          # integer-valued counts: bit-exact
+        assert np.array_equal(fn.numpy(), g[f"th{th}/fn"])
+        assert np.array_equal(fp.numpy(), g[f"th{th}/fp"])
+        np.testing.assert_array_equal(O.f1_per_label(tp, fn, fp).numpy(), g[f"th{th}/f1"])
+        np.testing.assert_array_equal(O.f1_micro(tp, fn, fp).numpy(), g[f"th{th}/f1_micro"])
