@@ -1,0 +1,135 @@
+/* protnote_hip.h - C ABI of libprotnote_hip.so, the MI355X (gfx950) implementation of ProtNote's
+ * forward/training hot path.
+ *
+ * The reference (microsoft/protnote) is 100 % Python and has no FFI of its own; the boundary its callers
+ * use is the nn.Module API (bin/main.py:383-452, protnote/models/ProtNoteTrainer.py:288,729).  Every
+ * entry point below therefore names the reference *function* it replaces (file:line under
+ * /root/reference); the ctypes binding a maintainer would add is protnote_amd/_lib.py (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; pn_last_error() returns the message of
+ *    the calling thread's last failure.
+ *  - all pointers are DEVICE pointers (HBM) unless the name ends in _host; f32 unless typed otherwise.
+ *  - no hidden allocation, no ownership transfer: scratch comes from the caller (`ws`, size from the
+ *    matching *_ws_bytes query); launches go to `stream` (a hipStream_t passed as void*), nothing
+ *    synchronises the device.
+ *  - internal activations are channels-last [B*L, ld4(C)] with ld4(C) = C rounded up to a multiple of 4
+ *    and zero pad lanes; conv weights must be packed by pn_pack_conv_weight first.
+ */
+#ifndef PROTNOTE_HIP_H
+#define PROTNOTE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_MAX_BLOCKS 16
+#define PN_MAX_LAYERS 8
+
+const char* pn_last_error(void);
+int pn_version(void);
+
+/* torch.nn.BatchNorm1d state: weight, bias, running_mean, running_var (each [C]) */
+typedef struct pn_bn {
+  const float* weight;
+  const float* bias;
+  float* running_mean;
+  float* running_var;
+} pn_bn;
+
+/* ---- ProteInfer encoder: protnote/models/protein_encoders.py:70-153 ---- */
+typedef struct pn_res_block { /* Residual, protein_encoders.py:23-67 */
+  pn_bn bn1;
+  const float* conv_a_w; /* packed [Cb][ksize][ld4(C)]  (masked_conv1) */
+  const float* conv_a_b; /* [Cb] */
+  pn_bn bn2;
+  const float* conv_b_w; /* packed [C][1][ld4(Cb)]      (masked_conv2) */
+  const float* conv_b_b; /* [C] */
+} pn_res_block;
+
+typedef struct pn_encoder {
+  int Cin, C, Cb, ksize, nblocks, dil_base;
+  const float* conv1_w; /* packed [C][ksize][ld4(Cin)] */
+  const float* conv1_b; /* [C] */
+  pn_res_block blk[PN_MAX_BLOCKS];
+} pn_encoder;
+
+/* torch Conv1d weight [Cout][Cin][k] -> packed [Cout][k][ld4(Cin)] (zero pad lanes). */
+int pn_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k, void* stream);
+
+size_t pn_encoder_ws_bytes(const pn_encoder* enc, int B, int L);
+
+/* ProteInfer.get_embeddings (protein_encoders.py:109-118): onehots [B][Cin][L] f32, lens [B] i64 ->
+ * emb [B][ld_emb] (first C columns).  training != 0 reproduces train-mode BatchNorm (batch statistics
+ * over all B*L positions incl. zeroed pads, running-stat update, momentum 0.01, eps 1e-3) exactly as the
+ * "frozen" encoder behaves under model.train() (ProtNoteTrainer.py:844). */
+int pn_encoder_fwd(const pn_encoder* enc, const float* onehots, const int64_t* lens, int B, int L,
+                   float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- row MLPs W_p / W_l: torchvision.ops.MLP built at protnote/models/ProtNote.py:63-81 ---- */
+typedef struct pn_mlp {
+  int nlayers;              /* number of Linear layers */
+  int dims[PN_MAX_LAYERS + 1]; /* dims[0]=in, dims[i+1]=out of layer i */
+  const float* w[PN_MAX_LAYERS];    /* [dims[i+1]][dims[i]] */
+  const float* bias[PN_MAX_LAYERS]; /* or NULL */
+  pn_bn bn[PN_MAX_LAYERS];          /* BN after layer i for i < nlayers-1 (weight==NULL: no BN) */
+  float bn_eps, bn_momentum;
+} pn_mlp;
+
+size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows);
+
+/* y[rows][dims[n]] = MLP(x[rows][ldx]); eval-mode BN only in this entry point.
+ * Replaces self.W_p(P_f) / self.W_l(L_f), ProtNote.py:270-271. */
+int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* ---- pair head: _get_joint_embeddings + output_layer, ProtNote.py:112-152,286-293,337-378 ---- */
+typedef struct pn_pairhead {
+  int d;        /* latent dim: P_e [B][d], L_e [NL][d] */
+  int in_dim;   /* 2d (concatenation) or 3d (concatenation_diff) */
+  int fusion;   /* 0 concatenation, 1 concatenation_diff */
+  int nlayers;  /* hidden layers (>= 2) */
+  int h;        /* hidden width */
+  const float* w[PN_MAX_LAYERS];    /* w[0]: [h][in_dim]; w[i>0]: [h][h] */
+  const float* bias[PN_MAX_LAYERS]; /* hidden-layer bias when there is no BN, else NULL */
+  pn_bn bn[PN_MAX_LAYERS];
+  const float* w_out; /* [h] */
+  const float* b_out; /* [1] */
+  float bn_eps, bn_momentum;
+} pn_pairhead;
+
+size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);
+
+/* logits_pairs[j*B + i] (label-major pair grid) for all B x NL pairs, eval-mode BN.
+ * The [B*NL, 2d] joint tensor of the reference is never materialised: layer 1 is separable,
+ * z1[i,j] = P_e[i] W1a^T + L_e[j] W1b^T. */
+int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                         float* logits_pairs, int label_chunk, void* ws, size_t ws_bytes, void* stream);
+
+/* ProtNote.py:308-322: pair logits for NL = n_out*ndesc description rows (consecutive rows = one label)
+ * -> out[B][n_out];  ndesc == 1: plain re-layout;  else logit(mean_d sigmoid(x), eps=1e-7).
+ * protein_major = 0: input is the label-major pair grid x[j*B + i]; 1: input is x[i*NL + j]. */
+int pn_ensemble_logit(const float* logits_pairs, int B, int NL, int ndesc, int protein_major, float* out,
+                      void* stream);
+
+/* ProtNote.py:219-240: out = L_f + (2u - 1) * scale, scale = alpha / sqrt(d); u ~ U[0,1) from the caller. */
+int pn_label_noise(const float* L_f, const float* u, float scale, float* out, long n, void* stream);
+
+/* ---- similarity head, ProtNote.py:281-284 ---- */
+size_t pn_similarity_ws_bytes(int B, int NL);
+int pn_similarity_fwd(const float* P_e, const float* L_e, int B, int NL, int d, float temperature,
+                      float* logits /* [B][NL] */, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- generic f32-MFMA GEMM (unit tests / building block): C[M][N] = relu?(A*s+t)[M][K] W[N][K]^T + bias */
+int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K,
+               const float* bias, const float* a_scale, const float* a_shift, double* col_sum,
+               double* col_sumsq, int tile_variant, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+"""protnote_amd - MI355X-native implementation of ProtNote's forward/training hot path.
+
+Module layout mirrors the reference package so `protnote.models.ProtNote.ProtNote`,
+`protnote.models.protein_encoders.ProteInfer` and `protnote.utils.losses.get_loss` have drop-in twins
+under `protnote_amd.`.  All arithmetic runs in hand-written HIP kernels reached
+through the C ABI in include/protnote_hip.h; PyTorch only owns device memory, streams and
+torch.distributed."""
+__version__ = "0.1.0"

@@ -1,0 +1,127 @@
+"""ctypes binding of libprotnote_hip.so (the C ABI in include/protnote_hip.h).
+
+The library is mandatory: importing a kernel entry point without the built .so raises - there is no
+CPU or eager fallback anywhere in protnote_amd."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprotnote_hip.so")
+
+PN_MAX_BLOCKS = 16
+PN_MAX_LAYERS = 8
+fp = C.POINTER(C.c_float)
+
+
+class pn_bn(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p)]
+
+
+class pn_res_block(C.Structure):
+    _fields_ = [("bn1", pn_bn), ("conv_a_w", C.c_void_p), ("conv_a_b", C.c_void_p), ("bn2", pn_bn),
+                ("conv_b_w", C.c_void_p), ("conv_b_b", C.c_void_p)]
+
+
+class pn_encoder(C.Structure):
+    _fields_ = [("Cin", C.c_int), ("C", C.c_int), ("Cb", C.c_int), ("ksize", C.c_int), ("nblocks", C.c_int),
+                ("dil_base", C.c_int), ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p),
+                ("blk", pn_res_block * PN_MAX_BLOCKS)]
+
+
+class pn_mlp(C.Structure):
+    _fields_ = [("nlayers", C.c_int), ("dims", C.c_int * (PN_MAX_LAYERS + 1)),
+                ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
+                ("bn", pn_bn * PN_MAX_LAYERS), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+
+
+class pn_pairhead(C.Structure):
+    _fields_ = [("d", C.c_int), ("in_dim", C.c_int), ("fusion", C.c_int), ("nlayers", C.c_int), ("h", C.c_int),
+                ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
+                ("bn", pn_bn * PN_MAX_LAYERS), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+
+
+_lib = None
+
+_SIGS = {
+    "pn_last_error": (C.c_char_p, []),
+    "pn_version": (C.c_int, []),
+    "pn_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pn_encoder_ws_bytes": (C.c_size_t, [C.POINTER(pn_encoder), C.c_int, C.c_int]),
+    "pn_encoder_fwd": (C.c_int, [C.POINTER(pn_encoder), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_mlp_rows_ws_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
+    "pn_mlp_rows_fwd_eval": (C.c_int, [C.POINTER(pn_mlp), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    "pn_pairhead_eval_ws_bytes": (C.c_size_t, [C.POINTER(pn_pairhead), C.c_int, C.c_int, C.c_int]),
+    "pn_pairhead_fwd_eval": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_ensemble_logit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pn_label_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
+    "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pn_similarity_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_gemm_nt": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int,
+                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m protnote_amd.build` "
+                "(protnote_amd has no CPU/eager fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("libprotnote_hip: " + lib().pn_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("protnote_amd runs on an MI355X HIP device only: got a CPU tensor "
+                               "(there is no CPU fallback; move the model and inputs to cuda)")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    """Grow-only per-device scratch buffer (uint8), reused across calls on the same stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws_cache.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,361 @@
+// f32-MFMA "NT" GEMM engine for gfx950 (CDNA4):  C[M,N] = opA(A)[M,K] * W[N,K]^T  with fused operand
+// generators and epilogues.  One workgroup = WAVES_M x WAVES_N wave64s, each owning WM x WN tiles of
+// v_mfma_f32_32x32x2_f32 (exact f32: bitwise a k-ordered fmaf chain).  Operand tiles are staged
+// global -> registers (transform applied here: BN affine / ReLU / padding mask / pair broadcast-sum)
+// -> LDS [row][BK+4] -> ds_read_b128 fragments.  The LDS row stride BK+4 floats keeps every 16-lane
+// ds_read_b128 group on 16 distinct 16-byte slots (conflict-free) and every ds_write_b128 aligned.
+//
+// K is "segmented": K = nseg segments of Kseg floats (Kseg % 4 == 0).  A plain GEMM has nseg = 1.
+// The dilated conv (reference protein_encoders.py:8-17,39-46) is the implicit GEMM with one segment per
+// tap: segment s reads activation row p + (s - nseg/2)*dil, zero outside [0, len[b]).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3 };
+enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3 };
+
+struct GemmParams {
+  int M, N;          // output rows / true output columns
+  int Nstore;        // columns written (>= N; columns in [N, Nstore) are written as 0 - padded layouts)
+  int nseg, Kseg;    // segmented K
+  // ---- A operand ----
+  const float* A;
+  long lda;
+  const float* a_scale;  // per-k affine (A_AFFINE_RELU, optional for A_CONV): relu(x*scale+shift)
+  const float* a_shift;
+  const float* A2;       // A_PAIRSUM_RELU: relu(A[r % pairB] + A2[r / pairB])
+  long lda2;
+  int pairB;
+  const int* lens;       // A_CONV / E_CONV: int32 sequence lengths [M / L]
+  int L;
+  int dil;
+  // ---- B operand (weights, [N][ldw], K-contiguous) ----
+  const float* W;
+  long ldw;
+  // ---- epilogue ----
+  float* C;
+  long ldc;
+  const float* bias;     // [N] or null
+  const float* resid;    // E_CONV: residual added on valid rows, or null
+  long ldr;
+  double* col_sum;       // optional per-column sum / sum of squares of the stored values (train-mode BN)
+  double* col_sumsq;
+  const float* e_scale;  // E_ROWDOT: sum_n relu(acc*e_scale[n]+e_shift[n]) * e_w[n]
+  const float* e_shift;
+  const float* e_w;
+  float* rowdot_out;     // [n_col_tiles * WAVES_N][M] deterministic partials
+  const float* row_scale;  // E_SCALE_RC: acc * row_scale[m] * col_scale[n] * alpha
+  const float* col_scale;
+  float alpha;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const GemmParams p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * WM * 32;
+  constexpr int BN = WAVES_N * WN * 32;
+  constexpr int LDK = BK + 4;
+  constexpr int KV = BK / 4;    // float4 granules per tile row
+  constexpr int RPP = NT / KV;  // tile rows covered per pass of the workgroup
+  constexpr int NQA = BM / RPP;
+  constexpr int NQB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/thread mismatch");
+  constexpr int STAGE = (BM + BN) * LDK;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  const int ntn = (p.Nstore + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn;
+  const int tile_m = blockIdx.x / ntn;
+  const int row0 = tile_m * BM;
+  const int col0 = tile_n * BN;
+
+  const int kv = tid % KV;
+  const int r_in = tid / KV;
+
+  // ---------------- per-thread operand row state ----------------
+  const float* arow[NQA];
+  const float* arow2[NQA];
+  int a_t[NQA], a_len[NQA];
+#pragma unroll
+  for (int q = 0; q < NQA; ++q) {
+    int r = row0 + r_in + q * RPP;
+    if (r > p.M - 1) r = p.M - 1;  // clamp: duplicates are discarded by the epilogue
+    if constexpr (AK == A_PAIRSUM_RELU) {
+      const int j = r / p.pairB;
+      const int i = r - j * p.pairB;
+      arow[q] = p.A + (long)i * p.lda;
+      arow2[q] = p.A2 + (long)j * p.lda2;
+    } else {
+      arow[q] = p.A + (long)r * p.lda;
+      arow2[q] = nullptr;
+    }
+    if constexpr (AK == A_CONV) {
+      const int b = r / p.L;
+      a_t[q] = r - b * p.L;
+      a_len[q] = p.lens[b];
+    } else {
+      a_t[q] = 0;
+      a_len[q] = 0;
+    }
+  }
+  const float* brow[NQB];
+  bool bvalid[NQB];
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) {
+    const int n = col0 + r_in + q * RPP;
+    bvalid[q] = n < p.N;
+    brow[q] = p.W + (long)(bvalid[q] ? n : 0) * p.ldw;
+  }
+
+  const int spt = (p.Kseg + BK - 1) / BK;  // slabs per segment
+  const int nslab = p.nseg * spt;
+  const bool conv_affine = (AK == A_CONV) && (p.a_scale != nullptr);
+
+  float4 ra[NQA], ra2[NQA], rb[NQB];
+  float4 rsc = make_float4(0, 0, 0, 0), rsh = make_float4(0, 0, 0, 0);
+  unsigned avalid = 0;
+
+  auto fetch = [&](int s) {
+    const int seg = s / spt;
+    const int c = (s - seg * spt) * BK + 4 * kv;
+    const bool kok = c < p.Kseg;
+    avalid = 0;
+    if constexpr (AK == A_CONV) {
+      const int sh = (seg - p.nseg / 2) * p.dil;
+#pragma unroll
+      for (int q = 0; q < NQA; ++q) {
+        const int tt = a_t[q] + sh;
+        const bool ok = kok && (a_t[q] < a_len[q]) && (tt >= 0) && (tt < a_len[q]);
+        ra[q] = ok ? ld4(arow[q] + (long)sh * p.lda + c) : make_float4(0, 0, 0, 0);
+        avalid |= (ok ? 1u : 0u) << q;
+      }
+      if (conv_affine && kok) {
+        rsc = ld4(p.a_scale + c);
+        rsh = ld4(p.a_shift + c);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQA; ++q) {
+        ra[q] = kok ? ld4(arow[q] + c) : make_float4(0, 0, 0, 0);
+        if constexpr (AK == A_PAIRSUM_RELU) ra2[q] = kok ? ld4(arow2[q] + c) : make_float4(0, 0, 0, 0);
+      }
+      avalid = kok ? 0xffffffffu : 0u;
+      if constexpr (AK == A_AFFINE_RELU) {
+        if (kok) {
+          rsc = ld4(p.a_scale + c);
+          rsh = ld4(p.a_shift + c);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      rb[q] = (kok && bvalid[q]) ? ld4(brow[q] + (long)seg * p.Kseg + c) : make_float4(0, 0, 0, 0);
+    }
+  };
+
+  auto commit = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LDK;
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) {
+      float4 v = ra[q];
+      const bool ok = (avalid >> q) & 1u;
+      if constexpr (AK == A_AFFINE_RELU) {
+        if (ok) {
+          v.x = relu(fmaf(v.x, rsc.x, rsh.x));
+          v.y = relu(fmaf(v.y, rsc.y, rsh.y));
+          v.z = relu(fmaf(v.z, rsc.z, rsh.z));
+          v.w = relu(fmaf(v.w, rsc.w, rsh.w));
+        }
+      } else if constexpr (AK == A_PAIRSUM_RELU) {
+        v.x = relu(v.x + ra2[q].x);
+        v.y = relu(v.y + ra2[q].y);
+        v.z = relu(v.z + ra2[q].z);
+        v.w = relu(v.w + ra2[q].w);
+      } else if constexpr (AK == A_CONV) {
+        if (conv_affine && ok) {
+          v.x = relu(fmaf(v.x, rsc.x, rsh.x));
+          v.y = relu(fmaf(v.y, rsc.y, rsh.y));
+          v.z = relu(fmaf(v.z, rsc.z, rsh.z));
+          v.w = relu(fmaf(v.w, rsc.w, rsh.w));
+        }
+      }
+      *reinterpret_cast<float4*>(As + (r_in + q * RPP) * LDK + 4 * kv) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      *reinterpret_cast<float4*>(Bs + (r_in + q * RPP) * LDK + 4 * kv) = rb[q];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * STAGE + (wm * WM * 32 + frag_row) * LDK + frag_k;
+    const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---------------- main loop: register-prefetch double buffering, one barrier per slab ----------------
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nslab) fetch(s + 1);
+    compute(cur);
+    if (s + 1 < nslab) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int hl = lane >> 5;  // which 4-row group of each 8
+  const int cl = lane & 31;
+  const bool want_stats = (EK == E_STORE || EK == E_CONV) && (p.col_sum != nullptr);
+  float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
+  if (want_stats) {
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = col0 + (wn * WN + j) * 32 + cl;
+    const bool cok = col < p.N;
+    float s1 = 0.f, s2 = 0.f;
+    float bj = 0.f, es = 0.f, et = 0.f, ew = 0.f, cs = 0.f;
+    if constexpr (EK == E_STORE || EK == E_CONV) {
+      bj = (cok && p.bias) ? p.bias[col] : 0.f;
+    }
+    if constexpr (EK == E_ROWDOT) {
+      if (cok) {
+        es = p.e_scale[col];
+        et = p.e_shift[col];
+        ew = p.e_w[col];
+      }
+    }
+    if constexpr (EK == E_SCALE_RC) cs = cok ? p.col_scale[col] * p.alpha : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const bool rok = row < p.M;
+        float v = acc[i][j][e];
+        if constexpr (EK == E_STORE) {
+          v = cok ? v + bj : 0.f;
+          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
+          if (rok) {
+            s1 += v;
+            s2 += v * v;
+          }
+        } else if constexpr (EK == E_CONV) {
+          bool live = false;
+          if (rok) {
+            const int b = row / p.L;
+            live = (row - b * p.L) < p.lens[b];
+          }
+          if (live && cok) {
+            v += bj;
+            if (p.resid) v += p.resid[(long)row * p.ldr + col];
+          } else {
+            v = 0.f;
+          }
+          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
+          s1 += v;
+          s2 += v * v;
+        } else if constexpr (EK == E_SCALE_RC) {
+          if (rok && cok) p.C[(long)row * p.ldc + col] = v * p.row_scale[row] * cs;
+        } else if constexpr (EK == E_ROWDOT) {
+          acc[i][j][e] = cok ? relu(fmaf(v, es, et)) * ew : 0.f;
+        }
+      }
+    }
+    if (want_stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (hl == 0) {
+        atomicAdd(&red[(wn * WN + j) * 32 + cl], s1);
+        atomicAdd(&red[BN + (wn * WN + j) * 32 + cl], s2);
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int i = tid; i < BN; i += NT) {
+      const int col = col0 + i;
+      if (col < p.N) {
+        atomicAdd(&p.col_sum[col], (double)red[i]);
+        atomicAdd(&p.col_sumsq[col], (double)red[BN + i]);
+      }
+    }
+  }
+  if constexpr (EK == E_ROWDOT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) v += acc[i][j][e];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        if (cl == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK>
+struct GemmCfg {
+  static constexpr int BM = WAVES_M * WM * 32;
+  static constexpr int BN = WAVES_N * WN * 32;
+  static constexpr int NT = WAVES_M * WAVES_N * 64;
+  static constexpr int LDS_BYTES = 2 * (BM + BN) * (BK + 4) * (int)sizeof(float);
+};
+
+}  // namespace pn

@@ -1,0 +1,653 @@
+// libprotnote_hip.so - MI355X (gfx950) kernels + C ABI for the ProtNote hot path.  See include/protnote_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/protnote_hip.h"
+#include "gemm_engine.hpp"
+
+using namespace pn;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+#define HIP_OK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                   \
+  } while (0)
+#define PN_OK(expr)         \
+  do {                      \
+    int _r = (expr);        \
+    if (_r != 0) return _r; \
+  } while (0)
+
+extern "C" const char* pn_last_error(void) { return g_err; }
+extern "C" int pn_version(void) { return 1; }
+
+static inline int ld4(int c) { return (c + 3) & ~3; }
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Bump {
+  char* base;
+  size_t off, cap;
+  bool ok;
+  Bump(void* p, size_t cap_) : base((char*)p), off(0), cap(cap_), ok(true) {}
+  template <class T>
+  T* take(size_t n) {
+    size_t b = al256(n * sizeof(T));
+    if (off + b > cap) {
+      ok = false;
+      return nullptr;
+    }
+    T* r = (T*)(base + off);
+    off += b;
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GEMM launch
+// ------------------------------------------------------------------------------------------------
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
+static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
+  using Cfg = GemmCfg<WAVES_M, WAVES_N, WM, WN, BK>;
+  auto kern = gemm_nt_kernel<AK, EK, WAVES_M, WAVES_N, WM, WN, BK>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Cfg::LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  if (p.Kseg % 4 != 0) return fail("gemm: K segment %d not a multiple of 4", p.Kseg);
+  const long tm = (p.M + Cfg::BM - 1) / Cfg::BM;
+  const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
+  if (tm * tn > 0x7fffffffL) return fail("gemm: grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64)
+template <int AK, int EK>
+static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
+  if (variant == 1) return launch_gemm_cfg<AK, EK, 4, 1, 1, 2, 32>(p, st);
+  return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, 32>(p, st);
+}
+
+static int pick_variant(int n) {
+  const int n128 = (n + 127) / 128 * 128, n64 = (n + 63) / 64 * 64;
+  return (n128 * 100 > n64 * 108) ? 1 : 0;
+}
+
+static GemmParams gp_zero() {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.nseg = 1;
+  p.alpha = 1.f;
+  p.pairB = 1;
+  p.L = 1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lens32(const int64_t* lens, int* out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = (int)lens[i];
+}
+
+// [B][Cin][L] f32 -> channels-last [B*L][ld], padding (t >= len) and pad lanes zeroed
+// (first half of MaskedConv1D.forward, protein_encoders.py:14)
+__global__ void k_ncl_to_nlc(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ out,
+                             int B, int Cin, int L, int ld) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)B * L) return;
+  const int b = (int)(p / L), t = (int)(p - (long)b * L);
+  const bool live = t < lens[b];
+  const float* src = x + (long)b * Cin * L + t;
+  float* dst = out + p * ld;
+  for (int c = 0; c < ld; ++c) dst[c] = (live && c < Cin) ? src[(long)c * L] : 0.f;
+}
+
+__global__ void k_pack_conv(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int k,
+                            int ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)Cout * k * ld;
+  if (i >= total) return;
+  const int c = (int)(i % ld);
+  const int tap = (int)((i / ld) % k);
+  const int co = (int)(i / ((long)ld * k));
+  packed[i] = (c < Cin) ? w[((long)co * Cin + c) * k + tap] : 0.f;
+}
+
+// eval-mode BatchNorm folded to y = x*s + t; pad lanes (c >= C) get s = t = 0
+__global__ void k_bn_fold_eval(pn_bn bn, const float* lin_bias, float eps, int C, int ld, float* s, float* t) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) {
+    if (bn.weight != nullptr) {
+      sc = bn.weight[c] / sqrtf(bn.running_var[c] + eps);
+      sh = bn.bias[c] - bn.running_mean[c] * sc;
+    } else {  // no BatchNorm: identity scale, optional Linear bias
+      sc = 1.f;
+      sh = lin_bias ? lin_bias[c] : 0.f;
+    }
+  }
+  s[c] = sc;
+  t[c] = sh;
+}
+
+// train-mode BatchNorm from accumulated column sums: batch mean / biased variance for normalisation,
+// running stats updated with momentum and the unbiased variance (torch.nn.BatchNorm1d semantics).
+__global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq, double count, float eps,
+                                float momentum, int C, int ld, float* s, float* t, float* mean_out,
+                                float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) {
+    const double mean = sum[c] / count;
+    double var = sumsq[c] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    sc = bn.weight[c] * invstd;
+    sh = bn.bias[c] - (float)mean * sc;
+    const double unb = count > 1 ? var * (count / (count - 1.0)) : var;
+    bn.running_mean[c] = (1.f - momentum) * bn.running_mean[c] + momentum * (float)mean;
+    bn.running_var[c] = (1.f - momentum) * bn.running_var[c] + momentum * (float)unb;
+    if (mean_out) mean_out[c] = (float)mean;
+    if (invstd_out) invstd_out[c] = invstd;
+  }
+  s[c] = sc;
+  t[c] = sh;
+}
+
+// masked mean over positions (protein_encoders.py:114-117); x is channels-last and already zero at pads
+__global__ void k_pool(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ emb, int L,
+                       int C, int ldx, int ld_emb) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int len = lens[b];
+  const float* src = x + (long)b * L * ldx + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int t = 0;
+  for (; t + 3 < len; t += 4) {
+    a0 += src[(long)t * ldx];
+    a1 += src[(long)(t + 1) * ldx];
+    a2 += src[(long)(t + 2) * ldx];
+    a3 += src[(long)(t + 3) * ldx];
+  }
+  for (; t < len; ++t) a0 += src[(long)t * ldx];
+  emb[(long)b * ld_emb + c] = ((a0 + a1) + (a2 + a3)) / (float)len;
+}
+
+// out[r][c] = in[r][c]*s[c] + (t ? t[c] : 0)
+__global__ void k_affine_rows(const float* __restrict__ in, long ldi, float* __restrict__ out, long ldo, long rows,
+                              int cols, const float* __restrict__ s, const float* __restrict__ t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  out[r * ldo + c] = fmaf(in[r * ldi + c], s[c], t ? t[c] : 0.f);
+}
+
+// concatenation_diff: W1 = [W1a | W1b | W1c] acting on [P, L, P-L]  ->  effective [W1a+W1c | W1b-W1c]
+__global__ void k_diff_weight(const float* __restrict__ w, float* __restrict__ out, int h, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)h * 2 * d) return;
+  const int n = (int)(i / (2 * d));
+  const int k = (int)(i - (long)n * 2 * d);
+  const float* row = w + (long)n * 3 * d;
+  out[i] = (k < d) ? row[k] + row[2 * d + k] : row[k] - row[2 * d + (k - d)];
+}
+
+__global__ void k_rowdot_reduce(const float* __restrict__ partials, int nparts, long M, const float* __restrict__ b,
+                                float* __restrict__ out) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  float a = 0.f;
+  for (int q = 0; q < nparts; ++q) a += partials[(long)q * M + r];
+  out[r] = a + (b ? b[0] : 0.f);
+}
+
+// pair logits (label-major: r = j*B + i) -> out[i][n_out]
+__global__ void k_ensemble(const float* __restrict__ pairs, int B, int NL, int ndesc, int pmajor,
+                           float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nout = NL / ndesc;
+  if (idx >= (long)B * nout) return;
+  const int i = (int)(idx % B);
+  const int jo = (int)(idx / B);
+  float v;
+  if (ndesc == 1) {
+    v = pmajor ? pairs[(long)i * NL + jo] : pairs[(long)jo * B + i];
+  } else {
+    float acc = 0.f;
+    for (int d = 0; d < ndesc; ++d) {
+      const long j = (long)jo * ndesc + d;
+      const float x = pmajor ? pairs[(long)i * NL + j] : pairs[j * B + i];
+      acc += 1.f / (1.f + expf(-x));
+    }
+    float pm = acc / (float)ndesc;
+    const float eps = 1e-7f;  // torch.special.logit(eps=1e-7) clamps to [eps, 1-eps]
+    pm = fminf(fmaxf(pm, eps), 1.f - eps);
+    v = logf(pm / (1.f - pm));
+  }
+  out[(long)i * nout + jo] = v;
+}
+
+// 1 / max(||x_r||_2, 1e-12)  (F.normalize, ProtNote.py:282-283); one wave per row
+__global__ void k_rownorm_inv(const float* __restrict__ x, long ld, int rows, int d, float* __restrict__ out) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float a = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = x[(long)r * ld + c];
+    a = fmaf(v, v, a);
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[r] = 1.f / fmaxf(sqrtf(a), 1e-12f);
+}
+
+static inline unsigned nblk(long n, int t) { return (unsigned)((n + t - 1) / t); }
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+extern "C" int pn_pack_conv_weight(const float* w, float* packed, int Cout, int Cin, int k, void* stream) {
+  const int ld = ld4(Cin);
+  const long total = (long)Cout * k * ld;
+  hipLaunchKernelGGL(k_pack_conv, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cout,
+                     Cin, k, ld);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+struct EncWs {
+  int* lens32;
+  float *x0, *xa, *xb, *z, *s1, *t1, *s2, *t2;
+  double *sum_x, *sq_x, *sum_z, *sq_z;
+};
+
+static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
+  const long P = (long)B * L;
+  const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
+  w.lens32 = bp.take<int>(B);
+  w.x0 = bp.take<float>(P * ldi);
+  w.xa = bp.take<float>(P * ldc);
+  w.xb = bp.take<float>(P * ldc);
+  w.z = bp.take<float>(P * ldb);
+  w.s1 = bp.take<float>(ldc);
+  w.t1 = bp.take<float>(ldc);
+  w.s2 = bp.take<float>(ldb);
+  w.t2 = bp.take<float>(ldb);
+  w.sum_x = bp.take<double>(2 * (size_t)ldc);
+  w.sq_x = w.sum_x ? w.sum_x + ldc : nullptr;
+  w.sum_z = bp.take<double>(2 * (size_t)ldb);
+  w.sq_z = w.sum_z ? w.sum_z + ldb : nullptr;
+  return bp.ok;
+}
+
+extern "C" size_t pn_encoder_ws_bytes(const pn_encoder* enc, int B, int L) {
+  Bump bp(nullptr, (size_t)-1);
+  EncWs w;
+  enc_carve(enc, B, L, bp, w);
+  return bp.off;
+}
+
+extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
+                              float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
+  if (B <= 0 || L <= 0) return fail("encoder: empty batch");
+  Bump bp(ws, ws_bytes);
+  EncWs w;
+  if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
+  const long P = (long)B * L;
+  if (P > 0x7fffffffL) return fail("encoder: B*L too large");
+  const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
+  const float bn_eps = 1e-3f, bn_mom = 0.01f;  // protein_encoders.py:36,48
+
+  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, w.lens32, B);
+  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, w.lens32, w.x0, B, e->Cin, L,
+                     ldi);
+  HIP_OK(hipGetLastError());
+
+  auto conv = [&](const float* in, int ld_in, int Cin_, const float* wpk, const float* bias, int Cout, int ld_out,
+                  float* out, int ntap, int dil, const float* s, const float* t, const float* resid,
+                  double* csum, double* csq) -> int {
+    GemmParams p = gp_zero();
+    p.M = (int)P;
+    p.N = Cout;
+    p.Nstore = ld_out;
+    p.nseg = ntap;
+    p.Kseg = ld_in;
+    p.A = in;
+    p.lda = ld_in;
+    p.a_scale = s;
+    p.a_shift = t;
+    p.lens = w.lens32;
+    p.L = L;
+    p.dil = dil;
+    p.W = wpk;
+    p.ldw = (long)ntap * ld_in;
+    p.C = out;
+    p.ldc = ld_out;
+    p.bias = bias;
+    p.resid = resid;
+    p.ldr = ld_out;
+    p.col_sum = csum;
+    p.col_sumsq = csq;
+    (void)Cin_;
+    return launch_gemm<A_CONV, E_CONV>(p, pick_variant(ld_out), st);
+  };
+
+  // conv1: MaskedConv1D(Cin -> C, k, dil 1), no BN/ReLU in front (protein_encoders.py:84-91,110)
+  float* x = w.xa;
+  float* xn = w.xb;
+  if (training) HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
+  PN_OK(conv(w.x0, ldi, e->Cin, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
+             training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+
+  int dil = 1;
+  for (int i = 0; i < e->nblocks; ++i) {
+    const pn_res_block& bk = e->blk[i];
+    // bn_activation_1 folded into conv_a's operand load
+    if (training) {
+      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, w.sum_x, w.sq_x,
+                         (double)P, bn_eps, bn_mom, e->C, ldc, w.s1, w.t1, (float*)nullptr, (float*)nullptr);
+      HIP_OK(hipMemsetAsync(w.sum_z, 0, 2 * (size_t)ldb * sizeof(double), st));
+    } else {
+      hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const float*)nullptr,
+                         bn_eps, e->C, ldc, w.s1, w.t1);
+    }
+    PN_OK(conv(x, ldc, e->C, bk.conv_a_w, bk.conv_a_b, e->Cb, ldb, w.z, e->ksize, dil, w.s1, w.t1, nullptr,
+               training ? w.sum_z : nullptr, training ? w.sq_z : nullptr));
+    if (training) {
+      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, w.sum_z, w.sq_z,
+                         (double)P, bn_eps, bn_mom, e->Cb, ldb, w.s2, w.t2, (float*)nullptr, (float*)nullptr);
+      HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
+    } else {
+      hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const float*)nullptr,
+                         bn_eps, e->Cb, ldb, w.s2, w.t2);
+    }
+    const bool need_stats = training && (i + 1 < e->nblocks);
+    PN_OK(conv(w.z, ldb, e->Cb, bk.conv_b_w, bk.conv_b_b, e->C, ldc, xn, 1, 1, w.s2, w.t2, x,
+               need_stats ? w.sum_x : nullptr, need_stats ? w.sq_x : nullptr));
+    float* tmp = x;
+    x = xn;
+    xn = tmp;
+    dil *= e->dil_base;
+  }
+  hipLaunchKernelGGL(k_pool, dim3(nblk(e->C, 256), B), dim3(256), 0, st, x, w.lens32, emb, L, e->C, ldc, ld_emb);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row MLP (W_p / W_l), eval
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows) {
+  size_t b = 0;
+  int hmax = 0;
+  for (int i = 0; i + 1 < m->nlayers; ++i) hmax = m->dims[i + 1] > hmax ? m->dims[i + 1] : hmax;
+  b += 2 * al256((size_t)rows * hmax * sizeof(float));  // ping-pong hidden activations
+  b += 2 * al256((size_t)hmax * sizeof(float));         // s, t
+  return b;
+}
+
+extern "C" int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (m->nlayers < 1 || m->nlayers > PN_MAX_LAYERS) return fail("mlp: bad layer count %d", m->nlayers);
+  for (int i = 0; i <= m->nlayers; ++i)
+    if (i < m->nlayers && m->dims[i] % 4 != 0) return fail("mlp: dims[%d]=%d not a multiple of 4", i, m->dims[i]);
+  if (ldx % 4 != 0) return fail("mlp: ldx %% 4 != 0");
+  int hmax = 0;
+  for (int i = 0; i + 1 < m->nlayers; ++i) hmax = m->dims[i + 1] > hmax ? m->dims[i + 1] : hmax;
+  Bump bp(ws, ws_bytes);
+  float* buf[2];
+  buf[0] = bp.take<float>((size_t)rows * hmax);
+  buf[1] = bp.take<float>((size_t)rows * hmax);
+  float* s = bp.take<float>(hmax);
+  float* t = bp.take<float>(hmax);
+  if (!bp.ok) return fail("mlp: workspace too small");
+  const float* in = x;
+  long ldin = ldx;
+  for (int i = 0; i < m->nlayers; ++i) {
+    const bool last = (i + 1 == m->nlayers);
+    GemmParams p = gp_zero();
+    p.M = rows;
+    p.N = m->dims[i + 1];
+    p.Nstore = p.N;
+    p.Kseg = m->dims[i];
+    p.A = in;
+    p.lda = ldin;
+    p.W = m->w[i];
+    p.ldw = m->dims[i];
+    float* out = last ? y : buf[i & 1];
+    p.C = out;
+    p.ldc = p.N;
+    // Linear bias: with a BN behind it the bias is applied by the fold; for the last layer add directly
+    p.bias = last ? m->bias[i] : nullptr;
+    if (i == 0) {
+      PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(p.N), st)));
+    } else {
+      p.a_scale = s;
+      p.a_shift = t;
+      PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, pick_variant(p.N), st)));
+    }
+    if (!last) {
+      // fold BN_i (or identity + bias) for the next layer's operand load
+      if (m->bn[i].weight != nullptr && m->bias[i] != nullptr)
+        return fail("mlp: Linear bias together with BatchNorm is not supported");
+      hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(p.N, 256)), dim3(256), 0, st, m->bn[i], m->bias[i], m->bn_eps,
+                         p.N, p.N, s, t);
+      HIP_OK(hipGetLastError());
+    }
+    in = out;
+    ldin = p.N;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair head, eval
+// ------------------------------------------------------------------------------------------------
+struct PairWs {
+  float *A1, *B1, *weff, *z[2], *partials, *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS];
+  int nparts;
+};
+
+static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp, PairWs& w) {
+  const int h = hd->h;
+  const long crow = (long)chunk * B;
+  w.A1 = bp.take<float>((size_t)B * h);
+  w.B1 = bp.take<float>((size_t)NL * h);
+  w.weff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * hd->d) : nullptr;
+  const int nz = hd->nlayers >= 4 ? 2 : (hd->nlayers == 3 ? 1 : 0);
+  w.z[0] = nz >= 1 ? bp.take<float>((size_t)crow * h) : nullptr;
+  w.z[1] = nz >= 2 ? bp.take<float>((size_t)crow * h) : nullptr;
+  w.nparts = ((h + 127) / 128) * 2;  // variant 0: BN=128, WAVES_N=2
+  w.partials = bp.take<float>((size_t)w.nparts * crow);
+  for (int i = 0; i < hd->nlayers; ++i) {
+    w.s[i] = bp.take<float>(h);
+    w.t[i] = bp.take<float>(h);
+  }
+  return bp.ok;
+}
+
+static int clamp_chunk(int chunk, int NL) {
+  if (chunk <= 0 || chunk > NL) chunk = NL;
+  return chunk;
+}
+
+extern "C" size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk) {
+  Bump bp(nullptr, (size_t)-1);
+  PairWs w;
+  pair_carve(hd, B, NL, clamp_chunk(label_chunk, NL), bp, w);
+  return bp.off;
+}
+
+extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                                    float* logits_pairs, int label_chunk, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int h = hd->h, d = hd->d;
+  if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 2..%d)", hd->nlayers, PN_MAX_LAYERS);
+  if (hd->fusion != 0 && hd->fusion != 1) return fail("pairhead: fusion %d not implemented", hd->fusion);
+  if (d % 4 || h % 4) return fail("pairhead: d and h must be multiples of 4");
+  const int chunk = clamp_chunk(label_chunk, NL);
+  if ((long)chunk * B > 0x7fffffffL) return fail("pairhead: chunk too large");
+  Bump bp(ws, ws_bytes);
+  PairWs w;
+  if (!pair_carve(hd, B, NL, chunk, bp, w)) return fail("pairhead: workspace too small");
+
+  // layer 1, separable: A1 = P_e W1a^T, B1 = L_e W1b^T
+  const float* w1 = hd->w[0];
+  long ldw1 = hd->in_dim;
+  if (hd->fusion == 1) {
+    hipLaunchKernelGGL(k_diff_weight, dim3(nblk((long)h * 2 * d, 256)), dim3(256), 0, st, hd->w[0], w.weff, h, d);
+    HIP_OK(hipGetLastError());
+    w1 = w.weff;
+    ldw1 = 2 * d;
+  }
+  {
+    GemmParams p = gp_zero();
+    p.M = B; p.N = h; p.Nstore = h; p.Kseg = d;
+    p.A = P_e; p.lda = d; p.W = w1; p.ldw = ldw1; p.C = w.A1; p.ldc = h;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+    p.M = NL; p.A = L_e; p.W = w1 + d; p.C = w.B1;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+  }
+  for (int i = 0; i < hd->nlayers; ++i) {
+    if (hd->bn[i].weight != nullptr && hd->bias[i] != nullptr)
+      return fail("pairhead: Linear bias together with BatchNorm is not supported");
+    hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[i], hd->bias[i], hd->bn_eps, h,
+                       h, w.s[i], w.t[i]);
+  }
+  // A' = s1*A1 + t1, B' = s1*B1  =>  h1[i,j] = relu(A'[i] + B'[j])
+  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, w.A1, (long)h, w.A1, (long)h,
+                     (long)B, h, w.s[0], w.t[0]);
+  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.B1, (long)h, w.B1, (long)h,
+                     (long)NL, h, w.s[0], (const float*)nullptr);
+  HIP_OK(hipGetLastError());
+
+  for (int j0 = 0; j0 < NL; j0 += chunk) {
+    const int nj = (NL - j0 < chunk) ? NL - j0 : chunk;
+    const long rows = (long)nj * B;
+    const float* in = nullptr;
+    for (int li = 1; li < hd->nlayers; ++li) {
+      const bool last = (li + 1 == hd->nlayers);
+      GemmParams p = gp_zero();
+      p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
+      p.W = hd->w[li]; p.ldw = h;
+      if (li == 1) {
+        p.A = w.A1; p.lda = h; p.A2 = w.B1 + (long)j0 * h; p.lda2 = h; p.pairB = B;
+      } else {
+        p.A = in; p.lda = h; p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
+      }
+      if (last) {
+        p.e_scale = w.s[li]; p.e_shift = w.t[li]; p.e_w = hd->w_out; p.rowdot_out = w.partials;
+        if (li == 1) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_ROWDOT>(p, 0, st)));
+        else PN_OK((launch_gemm<A_AFFINE_RELU, E_ROWDOT>(p, 0, st)));
+      } else {
+        float* out = w.z[(li - 1) & 1];
+        p.C = out; p.ldc = h;
+        if (li == 1) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+        else PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+        in = out;
+      }
+    }
+    hipLaunchKernelGGL(k_rowdot_reduce, dim3(nblk(rows, 256)), dim3(256), 0, st, w.partials, w.nparts, rows,
+                       hd->b_out, logits_pairs + (long)j0 * B);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+__global__ void k_label_noise(const float* __restrict__ x, const float* __restrict__ u, float scale,
+                              float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] + (2.f * u[i] - 1.f) * scale;
+}
+
+extern "C" int pn_label_noise(const float* L_f, const float* u, float scale, float* out, long n, void* stream) {
+  hipLaunchKernelGGL(k_label_noise, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, L_f, u, scale, out, n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_ensemble_logit(const float* logits_pairs, int B, int NL, int ndesc, int protein_major, float* out,
+                                 void* stream) {
+  if (ndesc < 1 || NL % ndesc != 0) return fail("ensemble: NL=%d not divisible by ndesc=%d", NL, ndesc);
+  const long n = (long)B * (NL / ndesc);
+  hipLaunchKernelGGL(k_ensemble, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, logits_pairs, B, NL, ndesc,
+                     protein_major, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// similarity head
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t pn_similarity_ws_bytes(int B, int NL) {
+  return al256((size_t)B * sizeof(float)) + al256((size_t)NL * sizeof(float));
+}
+
+extern "C" int pn_similarity_fwd(const float* P_e, const float* L_e, int B, int NL, int d, float temperature,
+                                 float* logits, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (d % 4) return fail("similarity: d %% 4 != 0");
+  Bump bp(ws, ws_bytes);
+  float* rs = bp.take<float>(B);
+  float* cs = bp.take<float>(NL);
+  if (!bp.ok) return fail("similarity: workspace too small");
+  hipLaunchKernelGGL(k_rownorm_inv, dim3(nblk(B, 4)), dim3(256), 0, st, P_e, (long)d, B, d, rs);
+  hipLaunchKernelGGL(k_rownorm_inv, dim3(nblk(NL, 4)), dim3(256), 0, st, L_e, (long)d, NL, d, cs);
+  HIP_OK(hipGetLastError());
+  GemmParams p = gp_zero();
+  p.M = B; p.N = NL; p.Nstore = NL; p.Kseg = d;
+  p.A = P_e; p.lda = d; p.W = L_e; p.ldw = d; p.C = logits; p.ldc = NL;
+  p.row_scale = rs; p.col_scale = cs; p.alpha = 1.f / temperature;
+  return launch_gemm<A_PLAIN, E_SCALE_RC>(p, 0, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic GEMM entry (tests / building block)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
+                          int K, const float* bias, const float* a_scale, const float* a_shift, double* col_sum,
+                          double* col_sumsq, int tile_variant, void* stream) {
+  if (K % 4 || lda % 4 || ldw % 4) return fail("gemm_nt: K, lda, ldw must be multiples of 4");
+  GemmParams p = gp_zero();
+  p.M = M; p.N = N; p.Nstore = N; p.Kseg = K;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias;
+  p.col_sum = col_sum; p.col_sumsq = col_sumsq;
+  const int v = tile_variant < 0 ? pick_variant(N) : tile_variant;
+  if (a_scale) {
+    p.a_scale = a_scale; p.a_shift = a_shift;
+    return launch_gemm<A_AFFINE_RELU, E_STORE>(p, v, (hipStream_t)stream);
+  }
+  return launch_gemm<A_PLAIN, E_STORE>(p, v, (hipStream_t)stream);
+}

@@ -1,0 +1,285 @@
+"""ProtNote two-tower fusion model on MI355X - drop-in twin of protnote/models/ProtNote.py (reference :9-378).
+
+Same constructor kwargs (including the reference's misspelt `outout_mlp_add_batchnorm`), same
+`forward(...) -> (logits, embeddings_dict)` contract, same state_dict keys (W_p.{0,1,4,5,...},
+W_l.*, output_layer.*, sequence_encoder.*).  torch.nn modules are parameter containers only; the
+arithmetic runs in libprotnote_hip.so:
+
+  * W_p / W_l row MLPs                -> pn_mlp_rows_fwd_eval / train path (f32-MFMA GEMMs, BN folded
+                                         into the next layer's operand load)
+  * _get_joint_embeddings + output_layer (reference :112-152, :286-293) -> pn_pairhead_*: the
+    [B*N_L, 2d] joint tensor is never built; layer 1 is separable (z1[i,j] = A[i] + Bm[j]) and the
+    remaining layers are tiled GEMMs over the pair grid with ReLU/BN fused into operand generation.
+  * similarity head (reference :281-284) -> pn_similarity_fwd
+  * inference-time description ensembling (reference :308-322) -> pn_ensemble_logit
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+_FUSION_ID = {"concatenation": 0, "concatenation_diff": 1}
+
+
+def _row_mlp(in_channels, hidden_channels, bias, dropout):
+    """Layer order of torchvision.ops.MLP(norm_layer=BatchNorm1d) as built at reference ProtNote.py:63-81:
+    (Linear, BatchNorm1d, ReLU, Dropout) per hidden width, then Linear, Dropout - this fixes the
+    checkpoint keys W_*.{0,1,4,5,8,9,12}."""
+    layers = []
+    d = in_channels
+    for h in hidden_channels[:-1]:
+        layers += [nn.Linear(d, h, bias=bias), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(dropout)]
+        d = h
+    layers += [nn.Linear(d, hidden_channels[-1], bias=bias), nn.Dropout(dropout)]
+    return nn.Sequential(*layers)
+
+
+def get_mlp(input_dim, hidden_dim, num_layers, input_dropout=0.0, dropout=0.0, batch_norm=False,
+            output_neuron_bias=None):
+    """Container with the layer order of reference get_mlp (ProtNote.py:337-378)."""
+    layers = []
+    if input_dropout > 0:
+        layers.append(nn.Dropout(input_dropout))
+    for idx in range(num_layers):
+        layers.append(nn.Linear(input_dim if idx == 0 else hidden_dim, hidden_dim, bias=not batch_norm))
+        if batch_norm:
+            layers.append(nn.BatchNorm1d(hidden_dim))
+        layers.append(nn.ReLU())
+        if idx < num_layers - 1:
+            layers.append(nn.Dropout(dropout))
+    out = nn.Linear(hidden_dim, 1)
+    if output_neuron_bias is not None:
+        out.bias.data.fill_(output_neuron_bias)
+    layers.append(out)
+    return nn.Sequential(*layers)
+
+
+def _bn_struct(bn):
+    if bn is None:
+        return L.pn_bn(None, None, None, None)
+    return L.pn_bn(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr())
+
+
+def _split_layers(seq):
+    """[(Linear, BatchNorm1d|None), ...] from a Sequential container (Dropout/ReLU skipped)."""
+    flat = []
+
+    def walk(m):
+        if isinstance(m, nn.Sequential):
+            for c in m:
+                walk(c)
+        else:
+            flat.append(m)
+
+    walk(seq)
+    out = []
+    for m in flat:
+        if isinstance(m, nn.Linear):
+            out.append([m, None])
+        elif isinstance(m, nn.BatchNorm1d):
+            out[-1][1] = m
+        elif isinstance(m, nn.Dropout) and m.p > 0 and m.training:
+            raise NotImplementedError("dropout > 0 in train mode is not implemented in protnote_amd")
+    return out
+
+
+class ProtNote(nn.Module):
+    def __init__(self, protein_embedding_dim=1100, label_embedding_dim=1024, label_embedding_pooling_method="mean",
+                 inference_descriptions_per_label=1, latent_dim=1024, label_encoder=None, sequence_encoder=None,
+                 label_encoder_num_trainable_layers=False, train_sequence_encoder=False,
+                 output_mlp_hidden_dim_scale_factor=1024, output_mlp_num_layers=2, output_neuron_bias=None,
+                 outout_mlp_add_batchnorm=True, residual_connection=False, dropout=0.0,
+                 sequence_embedding_dropout=0.0, label_embedding_dropout=0.0, label_embedding_noising_alpha=0.0,
+                 projection_head_num_layers=1, projection_head_hidden_dim_scale_factor=1,
+                 label_batch_size_limit=float("inf"), sequence_batch_size_limit=float("inf"),
+                 feature_fusion="concatenation", temperature=0.07):
+        super().__init__()
+        self.label_encoder_num_trainable_layers = label_encoder_num_trainable_layers
+        self.train_sequence_encoder = train_sequence_encoder
+        self.label_encoder, self.sequence_encoder = label_encoder, sequence_encoder
+        self.inference_descriptions_per_label = inference_descriptions_per_label
+        self.label_batch_size_limit, self.sequence_batch_size_limit = label_batch_size_limit, sequence_batch_size_limit
+        self.feature_fusion = feature_fusion
+        self.temperature = temperature
+        self.label_embedding_pooling_method = label_embedding_pooling_method
+        self.latent_dim = latent_dim
+        self.label_embedding_noising_alpha = label_embedding_noising_alpha
+        self.residual_connection = residual_connection
+
+        hidden = [latent_dim * projection_head_hidden_dim_scale_factor] * (projection_head_num_layers - 1) + [latent_dim]
+        self.W_p = _row_mlp(protein_embedding_dim, hidden, bias=False, dropout=dropout)
+        self.W_l = _row_mlp(label_embedding_dim, hidden, bias=False, dropout=dropout)
+        # reference :83-86 - wrapping renames the checkpoint keys, kept for compatibility
+        if sequence_embedding_dropout > 0:
+            self.W_p = nn.Sequential(nn.Dropout(sequence_embedding_dropout), self.W_p)
+        if label_embedding_dropout > 0:
+            self.W_l = nn.Sequential(nn.Dropout(label_embedding_dropout), self.W_l)
+        if self.label_embedding_pooling_method == "all":
+            self.raw_attn_scorer = nn.Linear(label_embedding_dim, 1, bias=True)
+        if self.feature_fusion.startswith("concatenation"):
+            self.output_layer = get_mlp(
+                input_dim=self._get_concatenated_features_dim(),
+                hidden_dim=int(round(output_mlp_hidden_dim_scale_factor * latent_dim)),
+                num_layers=output_mlp_num_layers, output_neuron_bias=output_neuron_bias,
+                batch_norm=outout_mlp_add_batchnorm, dropout=dropout)
+        # label-chunk size of the eval pair head (rows = chunk * B); None = auto (~512k pair rows)
+        self.pair_label_chunk = None
+
+    def _get_concatenated_features_dim(self):
+        dim = {"concatenation_diff": self.latent_dim * 3, "concatenation_prod": self.latent_dim * 3,
+               "concatenation": self.latent_dim * 2}
+        return dim[self.feature_fusion]
+
+    # ------------------------------------------------------------------ descriptors
+    def _mlp_desc(self, seq):
+        layers = _split_layers(seq)
+        if len(layers) > L.PN_MAX_LAYERS:
+            raise ValueError("too many projection layers")
+        m = L.pn_mlp()
+        m.nlayers = len(layers)
+        m.dims[0] = layers[0][0].in_features
+        eps, mom = 1e-5, 0.1
+        for i, (lin, bn) in enumerate(layers):
+            m.dims[i + 1] = lin.out_features
+            m.w[i] = lin.weight.data_ptr()
+            m.bias[i] = lin.bias.data_ptr() if lin.bias is not None else None
+            m.bn[i] = _bn_struct(bn)
+            if bn is not None:
+                eps, mom = bn.eps, bn.momentum
+        m.bn_eps, m.bn_momentum = eps, mom
+        return m, layers
+
+    def _pair_desc(self):
+        layers = _split_layers(self.output_layer)
+        hidden, out = layers[:-1], layers[-1][0]
+        hd = L.pn_pairhead()
+        hd.d = self.latent_dim
+        hd.in_dim = hidden[0][0].in_features
+        if self.feature_fusion not in _FUSION_ID:
+            raise NotImplementedError(f"feature_fusion={self.feature_fusion!r} is not implemented in protnote_amd yet")
+        hd.fusion = _FUSION_ID[self.feature_fusion]
+        hd.nlayers = len(hidden)
+        hd.h = hidden[0][0].out_features
+        eps, mom = 1e-5, 0.1
+        for i, (lin, bn) in enumerate(hidden):
+            hd.w[i] = lin.weight.data_ptr()
+            hd.bias[i] = lin.bias.data_ptr() if lin.bias is not None else None
+            hd.bn[i] = _bn_struct(bn)
+            if bn is not None:
+                eps, mom = bn.eps, bn.momentum
+        hd.w_out = out.weight.data_ptr()
+        hd.b_out = out.bias.data_ptr()
+        hd.bn_eps, hd.bn_momentum = eps, mom
+        return hd, layers
+
+    # ------------------------------------------------------------------ HIP stages (eval)
+    def _project_eval(self, seq, x):
+        m, keep = self._mlp_desc(seq)
+        rows = x.shape[0]
+        lib = L.lib()
+        ws = L.workspace(lib.pn_mlp_rows_ws_bytes(C.byref(m), rows), x.device, "mlp")
+        y = torch.empty(rows, m.dims[m.nlayers], dtype=torch.float32, device=x.device)
+        L.check(lib.pn_mlp_rows_fwd_eval(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(y), L.ptr(ws), ws.numel(),
+                                         L.stream_ptr()))
+        del keep
+        return y
+
+    def _auto_chunk(self, B, NL):
+        if self.pair_label_chunk:
+            return int(self.pair_label_chunk)
+        return max(1, min(NL, (512 * 1024) // max(B, 1)))
+
+    def _pairhead_eval(self, P_e, L_e):
+        hd, keep = self._pair_desc()
+        B, NL = P_e.shape[0], L_e.shape[0]
+        chunk = self._auto_chunk(B, NL)
+        lib = L.lib()
+        ws = L.workspace(lib.pn_pairhead_eval_ws_bytes(C.byref(hd), B, NL, chunk), P_e.device, "pair")
+        pairs = torch.empty(NL * B, dtype=torch.float32, device=P_e.device)
+        L.check(lib.pn_pairhead_fwd_eval(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
+                                         L.ptr(ws), ws.numel(), L.stream_ptr()))
+        del keep
+        return pairs  # label-major pair grid: pairs[j*B + i]
+
+    def _similarity(self, P_e, L_e):
+        B, NL, d = P_e.shape[0], L_e.shape[0], P_e.shape[1]
+        lib = L.lib()
+        ws = L.workspace(lib.pn_similarity_ws_bytes(B, NL), P_e.device, "sim")
+        logits = torch.empty(B, NL, dtype=torch.float32, device=P_e.device)
+        L.check(lib.pn_similarity_fwd(L.ptr(P_e), L.ptr(L_e), B, NL, d, float(self.temperature), L.ptr(logits),
+                                      L.ptr(ws), ws.numel(), L.stream_ptr()))
+        return logits
+
+    @staticmethod
+    def _ensemble(pairs, B, NL, ndesc, protein_major=False):
+        out = torch.empty(B, NL // ndesc, dtype=torch.float32, device=pairs.device)
+        L.check(L.lib().pn_ensemble_logit(L.ptr(pairs), B, NL, ndesc, 1 if protein_major else 0, L.ptr(out),
+                                          L.stream_ptr()))
+        return out
+
+    def _noised(self, L_f, u):
+        """Reference :219-240: L_f + (2u - 1) * alpha / sqrt(d), u ~ U[0,1) supplied by torch's Philox stream."""
+        out = torch.empty_like(L_f)
+        scale = float(self.label_embedding_noising_alpha) / math.sqrt(L_f.shape[1])
+        L.check(L.lib().pn_label_noise(L.ptr(L_f), L.ptr(u.contiguous()), scale, L.ptr(out), L_f.numel(),
+                                       L.stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sequence_onehots=None, sequence_embeddings=None, sequence_lengths=None, tokenized_labels=None,
+                label_embeddings=None, label_token_counts=None, save_embeddings=False):
+        """Reference ProtNote.forward (ProtNote.py:168-334).  Returns (logits [B, N_L], embeddings dict)."""
+        # ---- label branch (:192-217): cached-embedding path only ----
+        if label_embeddings is not None and (self.label_encoder_num_trainable_layers == 0 or not self.training):
+            L_f = label_embeddings
+        elif tokenized_labels is not None and self.training:
+            raise NotImplementedError("on-the-fly label encoding (tokenized_labels) is outside the MI355X hot path; "
+                                      "pass cached label_embeddings")
+        else:
+            raise ValueError("Incompatible label parameters passed to forward method.")
+        L.require_hip(L_f)
+        if self.label_embedding_pooling_method == "all":
+            raise NotImplementedError("LABEL_EMBEDDING_POOLING_METHOD='all' (additive attention) is not implemented")
+        if save_embeddings:
+            raise NotImplementedError("save_embeddings=True would materialise the [B*N_L, 2d] joint tensor, "
+                                      "which protnote_amd never builds")
+
+        with torch.autocast(device_type="cuda", enabled=False):  # kernels are f32; ignore AMP (ProtNoteTrainer.py:728)
+            if self.training and torch.is_grad_enabled():
+                from .train_path import forward_train
+
+                logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
+                                       label_token_counts)
+                return logits, {"output_layer_embeddings": [], "joint_embeddings": []}
+
+            with torch.no_grad():
+                L_f = L_f.detach().float().contiguous()
+                if self.training and label_token_counts is not None and self.label_embedding_noising_alpha > 0:
+                    # reference :219-240
+                    L_f = self._noised(L_f, torch.rand_like(L_f))
+                # ---- sequence branch (:243-264) ----
+                if sequence_embeddings is not None and (not self.train_sequence_encoder or not self.training):
+                    P_f = sequence_embeddings.detach().float().contiguous()
+                elif sequence_onehots is not None and sequence_lengths is not None:
+                    P_f = self.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
+                else:
+                    raise ValueError("Incompatible sequence parameters passed to forward method.")
+                if self.training:
+                    raise NotImplementedError("train-mode forward under no_grad is not implemented")
+                P_e = self._project_eval(self.W_p, P_f)
+                L_e = self._project_eval(self.W_l, L_f)
+                B, NL = P_e.shape[0], L_e.shape[0]
+                ndesc = 1 if self.training else int(self.inference_descriptions_per_label)
+                if self.feature_fusion == "similarity":
+                    logits = self._similarity(P_e, L_e)
+                    if ndesc != 1:
+                        logits = self._ensemble(logits, B, NL, ndesc, protein_major=True)
+                elif self.feature_fusion.startswith("concatenation"):
+                    pairs = self._pairhead_eval(P_e, L_e)
+                    logits = self._ensemble(pairs, B, NL, ndesc)
+                else:
+                    raise ValueError("feature fusion method not implemented")
+        return logits, {"output_layer_embeddings": [], "joint_embeddings": []}

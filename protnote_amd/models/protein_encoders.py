@@ -1,0 +1,157 @@
+"""ProteInfer encoder on MI355X - drop-in twin of protnote/models/protein_encoders.py (reference :8-153).
+
+Same constructor, methods, and state_dict keys as the reference classes; torch.nn modules are used only as
+parameter containers (device memory + checkpoint key layout).  All arithmetic - masked dilated
+convolutions as f32-MFMA implicit GEMMs with the BatchNorm/ReLU/padding-mask fused into operand load and
+epilogue, and the masked mean-pool - runs in libprotnote_hip.so (pn_encoder_fwd)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+class MaskedConv1D(torch.nn.Conv1d):
+    """Parameter container for reference MaskedConv1D (protein_encoders.py:8-17)."""
+
+    def forward(self, x, sequence_lengths):  # pragma: no cover - never called piecewise
+        raise RuntimeError("MaskedConv1D runs fused inside pn_encoder_fwd; call ProteInfer.get_embeddings")
+
+
+class Residual(torch.nn.Module):
+    """Parameter container for reference Residual (protein_encoders.py:23-67)."""
+
+    def __init__(self, input_channels: int, kernel_size: int, dilation: int, bottleneck_factor: float,
+                 activation=torch.nn.ReLU):
+        super().__init__()
+        bottleneck = int(np.floor(input_channels * bottleneck_factor))
+        self.bn_activation_1 = torch.nn.Sequential(
+            torch.nn.BatchNorm1d(input_channels, eps=0.001, momentum=0.01), activation())
+        self.masked_conv1 = MaskedConv1D(input_channels, bottleneck, kernel_size=kernel_size, stride=1,
+                                         padding="same", dilation=dilation)
+        self.bn_activation_2 = torch.nn.Sequential(
+            torch.nn.BatchNorm1d(bottleneck, eps=0.001, momentum=0.01), activation())
+        self.masked_conv2 = MaskedConv1D(bottleneck, input_channels, kernel_size=1, stride=1, padding="same",
+                                         dilation=1)
+
+    def forward(self, x, sequence_lengths):  # pragma: no cover
+        raise RuntimeError("Residual runs fused inside pn_encoder_fwd; call ProteInfer.get_embeddings")
+
+
+def _ld4(c):
+    return (c + 3) & ~3
+
+
+class ProteInfer(torch.nn.Module):
+    def __init__(self, num_labels: int, input_channels: int, output_channels: int, kernel_size: int, activation,
+                 dilation_base: int, num_resnet_blocks: int, bottleneck_factor: float):
+        super().__init__()
+        if activation is not torch.nn.ReLU:
+            raise ValueError("protnote_amd ProteInfer implements the ReLU activation only")
+        if num_resnet_blocks > L.PN_MAX_BLOCKS:
+            raise ValueError(f"at most {L.PN_MAX_BLOCKS} residual blocks are supported")
+        if kernel_size % 2 != 1:
+            raise ValueError("kernel_size must be odd (padding='same')")
+        self.conv1 = MaskedConv1D(input_channels, output_channels, kernel_size=kernel_size, stride=1,
+                                  padding="same", dilation=1)
+        self.resnet_blocks = torch.nn.ModuleList(
+            Residual(output_channels, kernel_size, dilation_base ** i, bottleneck_factor, activation)
+            for i in range(num_resnet_blocks))
+        self.output_layer = torch.nn.Linear(output_channels, num_labels)
+        self._dims = dict(Cin=input_channels, C=output_channels,
+                          Cb=int(np.floor(output_channels * bottleneck_factor)), ksize=kernel_size,
+                          nblocks=num_resnet_blocks, dil_base=dilation_base)
+        self._packed = {}  # name -> (version, data_ptr, packed tensor)
+
+    # ---- weight packing: torch [Cout][Cin][k] -> [Cout][k][ld4(Cin)] (pn_pack_conv_weight) ----
+    def _pack(self, name: str, conv: torch.nn.Conv1d) -> torch.Tensor:
+        w = conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        hit = self._packed.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        cout, cin, k = w.shape
+        packed = torch.empty(cout, k, _ld4(cin), dtype=torch.float32, device=w.device)
+        L.check(L.lib().pn_pack_conv_weight(L.ptr(w.detach().contiguous()), L.ptr(packed), cout, cin, k,
+                                            L.stream_ptr()))
+        self._packed[name] = (key, packed)
+        return packed
+
+    @staticmethod
+    def _bn_struct(bn: torch.nn.BatchNorm1d) -> L.pn_bn:
+        return L.pn_bn(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                       bn.running_var.data_ptr())
+
+    def _descriptor(self):
+        d = self._dims
+        enc = L.pn_encoder()
+        enc.Cin, enc.C, enc.Cb = d["Cin"], d["C"], d["Cb"]
+        enc.ksize, enc.nblocks, enc.dil_base = d["ksize"], d["nblocks"], d["dil_base"]
+        keep = [self._pack("conv1", self.conv1)]
+        enc.conv1_w = keep[-1].data_ptr()
+        enc.conv1_b = self.conv1.bias.data_ptr()
+        for i, blk in enumerate(self.resnet_blocks):
+            b = enc.blk[i]
+            b.bn1 = self._bn_struct(blk.bn_activation_1[0])
+            keep.append(self._pack(f"a{i}", blk.masked_conv1))
+            b.conv_a_w = keep[-1].data_ptr()
+            b.conv_a_b = blk.masked_conv1.bias.data_ptr()
+            b.bn2 = self._bn_struct(blk.bn_activation_2[0])
+            keep.append(self._pack(f"b{i}", blk.masked_conv2))
+            b.conv_b_w = keep[-1].data_ptr()
+            b.conv_b_b = blk.masked_conv2.bias.data_ptr()
+        return enc, keep
+
+    def get_embeddings(self, x, sequence_lengths):
+        """[B, Cin, L] f32 one-hots + [B] lengths -> [B, C] masked mean-pooled features
+        (reference protein_encoders.py:109-118).  In train mode BatchNorm uses batch statistics and
+        updates its running buffers exactly like the reference's "frozen" encoder does."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "TRAIN_SEQUENCE_ENCODER=True (encoder backward) is not implemented; freeze the encoder "
+                "(reference default, base_config.yaml:71) or call under torch.no_grad()")
+        L.require_hip(x, sequence_lengths)
+        if x.dim() != 3 or x.shape[1] != self._dims["Cin"]:
+            raise ValueError(f"expected [B, {self._dims['Cin']}, L] input, got {tuple(x.shape)}")
+        x = x.detach().contiguous().float()
+        lens = sequence_lengths.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        B, _, Lmax = x.shape
+        enc, keep = self._descriptor()
+        lib = L.lib()
+        nbytes = lib.pn_encoder_ws_bytes(C.byref(enc), B, Lmax)
+        ws = L.workspace(nbytes, x.device, "enc")
+        emb = torch.empty(B, self._dims["C"], dtype=torch.float32, device=x.device)
+        training = 1 if self.training else 0
+        L.check(lib.pn_encoder_fwd(C.byref(enc), L.ptr(x), L.ptr(lens), B, Lmax, L.ptr(emb), emb.shape[1],
+                                   training, L.ptr(ws), ws.numel(), L.stream_ptr()))
+        if training:
+            for blk in self.resnet_blocks:
+                blk.bn_activation_1[0].num_batches_tracked += 1
+                blk.bn_activation_2[0].num_batches_tracked += 1
+        del keep
+        return emb
+
+    def forward(self, x, sequence_lengths):
+        """Reference protein_encoders.py:120-123: Linear(C -> num_labels) on the pooled features."""
+        feats = self.get_embeddings(x, sequence_lengths)
+        w, b = self.output_layer.weight, self.output_layer.bias
+        if feats.shape[1] % 4 != 0:
+            raise ValueError("output_channels must be a multiple of 4")
+        out = torch.empty(feats.shape[0], w.shape[0], dtype=torch.float32, device=feats.device)
+        L.check(L.lib().pn_gemm_nt(L.ptr(feats), feats.shape[1], L.ptr(w.detach()), w.shape[1], L.ptr(out),
+                                   out.shape[1], feats.shape[0], w.shape[0], w.shape[1], L.ptr(b.detach()),
+                                   None, None, None, None, -1, L.stream_ptr()))
+        return out
+
+    @classmethod
+    def from_pretrained(cls, weights_path: str, num_labels: int, input_channels: int, output_channels: int,
+                        kernel_size: int, activation, dilation_base: int, num_resnet_blocks: int,
+                        bottleneck_factor: float):
+        """Reference protein_encoders.py:125-153 + utils/proteinfer.py:7-41 (TF-variable pickle)."""
+        from ..utils.proteinfer import transfer_tf_weights_to_torch
+
+        model = cls(num_labels, input_channels, output_channels, kernel_size, activation, dilation_base,
+                    num_resnet_blocks, bottleneck_factor)
+        transfer_tf_weights_to_torch(model, weights_path)
+        return model

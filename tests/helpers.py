@@ -1,0 +1,93 @@
+"""Shared helpers for the parity tests: build protnote_amd modules from a reference-style state dict."""
+import numpy as np
+import torch
+
+
+def make_encoder(sd, prefix, cfg, device):
+    from protnote_amd.models.protein_encoders import ProteInfer
+
+    enc = ProteInfer(num_labels=int(cfg["num_labels"]), input_channels=int(cfg["input_channels"]),
+                     output_channels=int(cfg["output_channels"]), kernel_size=int(cfg["kernel_size"]),
+                     activation=torch.nn.ReLU, dilation_base=int(cfg["dilation_base"]),
+                     num_resnet_blocks=int(cfg["num_resnet_blocks"]),
+                     bottleneck_factor=float(cfg["bottleneck_factor"]))
+    sub = {k[len(prefix):]: v.clone() for k, v in sd.items() if k.startswith(prefix)}
+    enc.load_state_dict(sub)
+    return enc.to(device)
+
+
+def npz_cfg(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def make_protnote(g, device, fusion=None, **over):
+    from protnote_amd.models.ProtNote import ProtNote
+    from oracle import protnote_oracle as O
+
+    sd = O.as_torch_sd(g, "sd/")
+    ecfg = npz_cfg(g, "enc_cfg_")
+    hcfg = {k: v.item() for k, v in npz_cfg(g, "head_cfg_").items()}
+    enc = make_encoder(sd, "sequence_encoder.", ecfg, "cpu")
+    hcfg.update(over)
+    model = ProtNote(sequence_encoder=enc, label_encoder=None, feature_fusion=fusion or str(g["fusion"]), **hcfg)
+    model.load_state_dict(sd)
+    return model.to(device), sd
+
+
+def random_encoder_sd(cfg, gen):
+    """Reference-layout ProteInfer state dict with randomised BN stats so activations stay O(1)."""
+    C, Cin, k = cfg["output_channels"], cfg["input_channels"], cfg["kernel_size"]
+    Cb = int(np.floor(C * cfg["bottleneck_factor"]))
+    sd = {}
+
+    def conv(name, co, ci, kk):
+        sd[name + ".weight"] = torch.randn(co, ci, kk, generator=gen) * (1.6 / (ci * kk) ** 0.5)
+        sd[name + ".bias"] = torch.randn(co, generator=gen) * 0.2
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=gen) + 0.5
+        sd[name + ".bias"] = torch.randn(c, generator=gen) * 0.3
+        sd[name + ".running_mean"] = torch.randn(c, generator=gen) * 0.3
+        sd[name + ".running_var"] = torch.rand(c, generator=gen) * 1.5 + 0.5
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    conv("conv1", C, Cin, k)
+    for i in range(cfg["num_resnet_blocks"]):
+        p = f"resnet_blocks.{i}."
+        bn(p + "bn_activation_1.0", C)
+        conv(p + "masked_conv1", Cb, C, k)
+        bn(p + "bn_activation_2.0", Cb)
+        conv(p + "masked_conv2", C, Cb, 1)
+    sd["output_layer.weight"] = torch.randn(cfg["num_labels"], C, generator=gen) * (1.0 / C ** 0.5)
+    sd["output_layer.bias"] = torch.randn(cfg["num_labels"], generator=gen) * 0.1
+    return sd
+
+
+def random_head_sd(gen, pdim, ldim, d, h_proj, n_proj, h_out, n_out, in_mult=2):
+    sd = {}
+
+    def lin(name, o, i, bias=False):
+        sd[name + ".weight"] = torch.randn(o, i, generator=gen) * (1.6 / i ** 0.5)
+        if bias:
+            sd[name + ".bias"] = torch.randn(o, generator=gen) * 0.2
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=gen) + 0.5
+        sd[name + ".bias"] = torch.randn(c, generator=gen) * 0.3
+        sd[name + ".running_mean"] = torch.randn(c, generator=gen) * 0.3
+        sd[name + ".running_var"] = torch.rand(c, generator=gen) * 1.5 + 0.5
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    for pre, din in (("W_p.", pdim), ("W_l.", ldim)):
+        dims = [din] + [h_proj] * (n_proj - 1) + [d]
+        for i in range(n_proj):
+            lin(f"{pre}{4 * i}", dims[i + 1], dims[i])
+            if i < n_proj - 1:
+                bn(f"{pre}{4 * i + 1}", dims[i + 1])
+    idx = 0
+    for i in range(n_out):
+        lin(f"output_layer.{idx}", h_out, in_mult * d if i == 0 else h_out)
+        bn(f"output_layer.{idx + 1}", h_out)
+        idx += 4 if i < n_out - 1 else 3
+    lin(f"output_layer.{idx}", 1, h_out, bias=True)
+    return sd

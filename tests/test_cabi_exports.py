@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/protnote_hip.h declares (no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from protnote_amd.build import build_lib
+
+    return build_lib(verbose=False)
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "protnote_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/protnote_hip.h but not exported"
+
+
+def test_binding_covers_header(built_lib):
+    from protnote_amd import _lib
+
+    assert sorted(_lib.exported_symbols()) == _declared()
+    assert _lib.lib().pn_version() >= 1
+
+
+def test_cpu_tensors_fail_loudly():
+    import torch
+    from protnote_amd.models.protein_encoders import ProteInfer
+
+    enc = ProteInfer(5, 20, 8, 9, torch.nn.ReLU, 3, 1, 0.5)
+    for p in enc.parameters():
+        p.requires_grad = False
+    with pytest.raises(RuntimeError, match="HIP device"):
+        enc.get_embeddings(torch.zeros(1, 20, 16), torch.tensor([16]))
+
+
+def test_struct_sizes_match_c(built_lib, tmp_path):
+    """ctypes mirrors of the descriptor structs must have the C compiler's layout."""
+    import subprocess
+    from protnote_amd import _lib
+
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "protnote_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   "sizeof(pn_bn),sizeof(pn_res_block),sizeof(pn_encoder),sizeof(pn_mlp),sizeof(pn_pairhead));}")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(t) for t in (_lib.pn_bn, _lib.pn_res_block, _lib.pn_encoder, _lib.pn_mlp,
+                                       _lib.pn_pairhead)]
+    assert got == want

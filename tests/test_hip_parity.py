@@ -1,0 +1,147 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle and the reference-generated golden
+vectors.  Tolerance (BASELINE.json north_star): logits within 1e-3 of the fp32 CPU path; the kernels are
+exact-f32 MFMA so the tests hold them to 2e-4 abs on O(1) values."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import make_encoder, make_protnote, npz_cfg, random_encoder_sd, random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,variant", [(128, 128, 32, 0), (300, 200, 100, 0), (257, 70, 36, 1), (1, 5, 4, 0),
+                                            (513, 550, 1100, -1), (64, 3072, 1024, 0)])
+def test_gemm_nt(M, N, K, variant):
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    # asymmetric W so a transposed C-write cannot pass
+    W = torch.randn(N, K, generator=g) + torch.arange(N)[:, None] * 0.01
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+    Cd = torch.full((M, N), float("nan"), device=DEV)
+    cs = torch.zeros(N, dtype=torch.float64, device=DEV)
+    cq = torch.zeros(N, dtype=torch.float64, device=DEV)
+    L.check(L.lib().pn_gemm_nt(L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(Cd), N, M, N, K, L.ptr(bd), None, None, L.ptr(cs),
+                               L.ptr(cq), variant, L.stream_ptr()))
+    torch.cuda.synchronize()
+    out = Cd.cpu().double()
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-6 * scale * max(1, K ** 0.5)
+    np.testing.assert_allclose(cs.cpu().numpy(), ref.sum(0).numpy(), rtol=1e-5, atol=1e-4 * scale)
+    np.testing.assert_allclose(cq.cpu().numpy(), (ref ** 2).sum(0).numpy(), rtol=1e-5)
+
+
+def test_gemm_nt_affine_relu():
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 200, 96, 52
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    s, t = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    ref = torch.relu(A.double() * s.double() + t.double()) @ W.double().T
+    Cd = torch.empty(M, N, device=DEV)
+    Ad, Wd, sd_, td = A.to(DEV), W.to(DEV), s.to(DEV), t.to(DEV)  # keep alive across the async launch
+    L.check(L.lib().pn_gemm_nt(L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(Cd), N, M, N, K, None,
+                               L.ptr(sd_), L.ptr(td), None, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (Cd.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- encoder
+def test_encoder_golden_eval_and_train(golden_dir):
+    g = _g(golden_dir, "encoder_small.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    enc = make_encoder(sd, "", npz_cfg(g, "cfg_"), DEV)
+    for p in enc.parameters():
+        p.requires_grad = False
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    enc.eval()
+    emb = enc.get_embeddings(x, lens)
+    np.testing.assert_allclose(emb.cpu().numpy(), g["eval/embeddings"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(enc(x, lens).cpu().numpy(), g["eval/logits"], atol=2e-4, rtol=1e-4)
+    # pad-length invariance (bucketed padding is parity-safe): pad to 260
+    x2 = torch.zeros(x.shape[0], 20, 260, device=DEV)
+    x2[:, :, : x.shape[2]] = x
+    np.testing.assert_allclose(enc.get_embeddings(x2, lens).cpu().numpy(), g["eval/embeddings_pad260"], atol=1e-4,
+                               rtol=1e-4)
+    # train-mode BN of the frozen encoder + running-stat drift
+    enc.train()
+    emb_t = enc.get_embeddings(x, lens)
+    np.testing.assert_allclose(emb_t.cpu().numpy(), g["train/embeddings"], atol=2e-4, rtol=1e-4)
+    after = O.as_torch_sd(g, "sd_after_train/")
+    got = {k: v.cpu() for k, v in enc.state_dict().items()}
+    for k, v in after.items():
+        np.testing.assert_allclose(got[k].numpy(), v.numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("B,Lmax,lens", [(3, 96, [96, 1, 40]), (2, 400, [400, 333])])
+def test_encoder_full_width_vs_oracle(B, Lmax, lens):
+    """Real channel counts (1100 / 550, k=9, dilations 1..81) against the oracle on the same seeded inputs."""
+    cfg = dict(num_labels=11, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+               num_resnet_blocks=5, bottleneck_factor=0.5)
+    gen = torch.Generator().manual_seed(11)
+    sd = random_encoder_sd(cfg, gen)
+    ids = torch.randint(0, 20, (B, Lmax), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    lens_t = torch.tensor(lens)
+    ref = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, x, lens_t)
+    enc = make_encoder(sd, "", cfg, DEV).eval()
+    for p in enc.parameters():
+        p.requires_grad = False
+    emb = enc.get_embeddings(x.to(DEV), lens_t.to(DEV))
+    err = (emb.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+# ----------------------------------------------------------------------------------------------- ProtNote eval
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "similarity"])
+def test_protnote_eval_golden(golden_dir, fusion):
+    g = _g(golden_dir, f"protnote_small_{fusion}.npz")
+    model, _ = make_protnote(g, DEV)
+    model.eval()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"]).to(DEV)
+    with torch.no_grad():
+        model.inference_descriptions_per_label = 2
+        ens, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+        model.inference_descriptions_per_label = 1
+        raw, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+    np.testing.assert_allclose(raw.cpu().numpy(), g["eval/logits_raw"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(ens.cpu().numpy(), g["eval/logits_ens2"], atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,NL,chunk", [(8, 300, None), (5, 77, 10), (130, 33, 7)])
+def test_pairhead_eval_real_width_vs_oracle(B, NL, chunk):
+    """d=1024, h=3072, 3 hidden layers (base_config.yaml) on a small pair grid, vs the oracle's naive
+    materialised-joint-tensor formulation."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(5)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    model.pair_label_chunk = chunk
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    err = (out.cpu() - ref).abs().max().item()
+    assert ref.abs().max().item() > 0.5  # logits are O(1): the tolerance is not vacuous
+    assert err < 1e-3, err
+    assert err < 3e-4, err
