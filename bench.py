@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py - ProtNote train step (fwd + bwd + clip + Adam) on MI355X, BASELINE.json configs[2]/[3].
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimisation step of the hot path on one batch of synthetic input per GPU: frozen
+ProteInfer encoder forward (train-mode BN) -> W_p / W_l -> pair-grid MLP head with train-mode BatchNorm over
+all B x N_L pairs -> BCE loss -> backward -> (N>1: RCCL all-reduce of the flat gradient) -> clip + Adam.
+Per GPU: B=256 proteins, L=512, N_L=32102 labels (weak scaling).  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0 (metric: protein-label pairs/s, whole job).
+
+`roofline` describes the dominant kernel family (the 3072x3072 f32-MFMA GEMMs over the 8.2M-row pair grid):
+achieved = 2*rows*h*h FLOP per launch / mean launch duration from hipEvents recorded on the launch stream
+inside the timed region (pn_prof_begin/end); peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, dense f32).
+`cpu_baseline` times the CPU oracle's train step (a port of the reference algorithm, pinned to reference
+golden vectors) on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+KIND_NAMES = {
+    0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
+    12: "nt:bn_relu(z)->rowdot", 22: "nt:pairsum_relu->rowdot", 3: "nt:plain->scale",
+    100: "tn:plain x plain", 101: "tn:plain x bn_relu", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
+    112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
+}
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def build_model(device, seed=42):
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.protein_encoders import ProteInfer
+
+    torch.manual_seed(seed)
+    # configs/base_config.yaml: embed_sequences_params + params (PROJECTION_HEAD_*, OUTPUT_MLP_*, FEATURE_FUSION)
+    enc = ProteInfer(num_labels=32102, input_channels=20, output_channels=1100, kernel_size=9,
+                     activation=torch.nn.ReLU, dilation_base=3, num_resnet_blocks=5, bottleneck_factor=0.5)
+    model = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024, sequence_encoder=enc,
+                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, outout_mlp_add_batchnorm=True,
+                     projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
+                     label_embedding_noising_alpha=20.0, feature_fusion="concatenation", temperature=0.07)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():  # random BN statistics/affine so activations and logits are O(1)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.5)
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False  # TRAIN_SEQUENCE_ENCODER: False
+    return model.to(device)
+
+
+def synthetic_batch(B, L, NL, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 20, (B, L), generator=g)
+    onehots = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    return {
+        "sequence_onehots": onehots.to(device),
+        "sequence_lengths": torch.full((B,), L, dtype=torch.int64, device=device),
+        "label_embeddings": torch.randn(NL, 1024, generator=g).to(device),
+        "label_token_counts": torch.randint(3, 40, (NL,), generator=g).to(device),
+        "label_multihots": (torch.rand(B, NL, generator=g) < 1.6e-3).to(torch.int64).to(device),
+    }
+
+
+def cpu_baseline(seconds_hint=20.0):
+    """Oracle train step (reference algorithm restated, f32, torch-CPU) on a bounded sample: B=4 proteins,
+    L=512, N_L=2048 labels, full-width model."""
+    from oracle import protnote_oracle as O
+    from tests.helpers import random_encoder_sd, random_head_sd
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+                num_resnet_blocks=5, bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
+    B, L, NL = 4, 512, 2048
+    ids = torch.randint(0, 20, (B, L), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    lens = torch.full((B,), L, dtype=torch.int64)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 1.6e-3).to(torch.int64)
+    u = torch.rand(NL, 1024, generator=gen)
+    cnt = torch.full((NL,), 5)
+    t0 = time.time()
+    O.train_step(sd, x, lens, lab, y, loss="BCE", noise_alpha=20.0, noise_u=u, label_token_counts=cnt)
+    dt = time.time() - t0
+    return {"value": B * NL / dt, "unit": "protein-label pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 oracle train step (fwd+bwd+clip+Adam), B={B}, L={L}, N_L={NL}, full-width model, "
+                      f"{dt:.1f} s on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--labels", type=int, default=32102)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from protnote_amd import _lib
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.distributed import init_from_env
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+    import torch.distributed as dist
+
+    rank, local, world = init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = build_model(dev)
+    model.train()
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
+    B, L, NL = args.batch, args.seq_len, args.labels
+    batch = synthetic_batch(B, L, NL, dev, seed=1000 + rank)
+    counts = torch.zeros(3, NL, dtype=torch.float32, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
+    sync()
+    _lib.prof_begin()
+    t0 = time.time()
+    loss = None
+    for _ in range(args.steps):
+        loss = train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
+    sync()
+    elapsed = time.time() - t0
+    prof = _lib.prof_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        pairs = world * B * NL * args.steps
+        kernels = {}
+        for kind, (cnt, ms, fl) in sorted(prof.items()):
+            kernels[KIND_NAMES.get(kind, str(kind))] = {
+                "launches": cnt, "ms_total": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0}
+        # dominant family: launches that contract over the full pair grid with a 3072x3072 weight
+        big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12}
+        if not big:
+            big = prof
+        tot_ms = sum(v[1] for v in big.values())
+        tot_fl = sum(v[2] for v in big.values())
+        n_launch = sum(v[0] for v in big.values())
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "protein-label pairs/sec (fwd+bwd)", "value": pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3]: train step fwd+bwd+clip+Adam, BCE loss, per-GPU batch "
+                                   f"{B} x L={L}, {NL} GO-sized label set, random-init ProteInfer(1100ch,5 blocks)+"
+                                   "ProtNote(concatenation head 3x3072, 4-layer projections), frozen encoder",
+                       "global_batch": world * B, "seq_len": L, "n_labels": NL,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": loss_val},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "pair-grid 3072x3072 f32-MFMA GEMM family (gemm_nt_kernel / gemm_tn_kernel)",
+                         "launches": n_launch, "avg_ms_per_launch": tot_ms / max(n_launch, 1),
+                         "flops_per_launch": tot_fl / max(n_launch, 1)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,80 @@ size_t pn_similarity_ws_bytes(int B, int NL);
 int pn_similarity_fwd(const float* P_e, const float* L_e, int B, int NL, int d, float temperature,
                       float* logits /* [B][NL] */, void* ws, size_t ws_bytes, void* stream);
 
+/* ================================ training path ================================ */
+
+/* gradient destinations (device pointers, each the shape of the matching parameter; NULL = not wanted) */
+typedef struct pn_mlp_grads {
+  float* dw[PN_MAX_LAYERS];
+  float* dgamma[PN_MAX_LAYERS];
+  float* dbeta[PN_MAX_LAYERS];
+} pn_mlp_grads;
+
+typedef struct pn_pairhead_grads {
+  float* dw[PN_MAX_LAYERS];
+  float* dgamma[PN_MAX_LAYERS];
+  float* dbeta[PN_MAX_LAYERS];
+  float* dw_out; /* [h] */
+  float* db_out; /* [1] */
+} pn_pairhead_grads;
+
+/* W_p / W_l with train-mode BatchNorm1d (batch statistics over `rows`, running-stat update) - the
+ * training-time self.W_p(P_f) / self.W_l(L_f) of ProtNote.py:270-271 - and its backward.  `save` carries
+ * the pre-activations and BN statistics from forward to backward (size: *_train_save_bytes). */
+size_t pn_mlp_rows_train_save_bytes(const pn_mlp* m, int rows);
+size_t pn_mlp_rows_train_ws_bytes(const pn_mlp* m, int rows);
+int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* save,
+                          size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int rows, const float* dy, const pn_mlp_grads* gr,
+                    float* dx /* or NULL */, void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+
+/* Training-mode pair head (ProtNote.py:286-293 under model.train(): BatchNorm statistics over the whole
+ * B x NL pair grid).  Forward stores the h-wide pre-activations of hidden layers 2..n in `save`
+ * ((nlayers-1) * (B*NL + chunk) * h floats); backward walks them in label chunks and reuses the consumed
+ * part of each buffer for the propagated gradient.  logits / dl are on the label-major pair grid [j*B+i]. */
+size_t pn_pairhead_train_save_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);
+size_t pn_pairhead_train_ws_bytes(const pn_pairhead* hd, int B, int NL);
+int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                          float* logits_pairs, int label_chunk, void* save, size_t save_bytes, void* ws,
+                          size_t ws_bytes, void* stream);
+int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL, const float* dl_pairs,
+                    const pn_pairhead_grads* gr, float* dP_e, float* dL_e, int label_chunk, void* save,
+                    size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+
+/* Loss forward + d(mean loss)/dlogit + per-label TP/FN/FP in one pass over logits [B][N]
+ * (utils/losses.py:190-213 FocalLoss, :275-276 BCEWithLogits(pos_weight); ProtNoteTrainer.py:61-83).
+ * kind 0 = BCE, 1 = focal.  Exactly one of targets_f32 / targets_i64 is non-NULL.  tp/fn/fp (each [N], f32
+ * holding integer counts) are ACCUMULATED into when non-NULL.  ws: >= 256 bytes. */
+int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                    int kind, float pos_weight, float gamma, float alpha, float smoothing, float threshold,
+                    float* loss_out, float* dlogits, float* tp, float* fn, float* fp, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* calculate_tp_fn_fp (ProtNoteTrainer.py:61-83) on probabilities; outputs are overwritten. */
+int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                float threshold, float* tp, float* fn, float* fp, void* stream);
+
+/* clip_grad_norm_(max_norm) + Adam / AdamW step on flat f32 buffers (ProtNoteTrainer.py:745-755);
+ * max_norm <= 0 disables clipping; norm_out (optional, [1]) receives the total gradient norm. */
+int pn_clip_adam_step(float* w, const float* g, float* m, float* v, long n, float max_norm, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, float* norm_out, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* dst[c][r] = src[r][c] (pair-grid <-> [B][N] re-layout of logits / dlogits) */
+int pn_transpose(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, void* stream);
+
+/* C[M][N] = A[R][M]^T B[R][N]  (split-K f32-MFMA contraction over rows; unit tests / building block) */
+int pn_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, long R, int M, int N,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
+ * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
+ * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller
+ * must have synchronised the device first.  flops = 2*M*N*K of each launch (arithmetic actually issued).
+ * Returns the number of kinds written. */
+int pn_prof_begin(void);
+int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops);
+
 /* ---- generic f32-MFMA GEMM (unit tests / building block): C[M][N] = relu?(A*s+t)[M][K] W[N][K]^T + bias */
 int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K,
                const float* bias, const float* a_scale, const float* a_shift, double* col_sum,

@@ -44,6 +44,16 @@ class pn_pairhead(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
 
 
+class pn_mlp_grads(C.Structure):
+    _fields_ = [("dw", C.c_void_p * PN_MAX_LAYERS), ("dgamma", C.c_void_p * PN_MAX_LAYERS),
+                ("dbeta", C.c_void_p * PN_MAX_LAYERS)]
+
+
+class pn_pairhead_grads(C.Structure):
+    _fields_ = [("dw", C.c_void_p * PN_MAX_LAYERS), ("dgamma", C.c_void_p * PN_MAX_LAYERS),
+                ("dbeta", C.c_void_p * PN_MAX_LAYERS), ("dw_out", C.c_void_p), ("db_out", C.c_void_p)]
+
+
 _lib = None
 
 _SIGS = {
@@ -64,6 +74,35 @@ _SIGS = {
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pn_similarity_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_mlp_rows_train_save_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
+    "pn_mlp_rows_train_ws_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
+    "pn_mlp_rows_fwd_train": (C.c_int, [C.POINTER(pn_mlp), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_mlp_rows_bwd": (C.c_int, [C.POINTER(pn_mlp), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.POINTER(pn_mlp_grads), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    "pn_pairhead_train_save_bytes": (C.c_size_t, [C.POINTER(pn_pairhead), C.c_int, C.c_int, C.c_int]),
+    "pn_pairhead_train_ws_bytes": (C.c_size_t, [C.POINTER(pn_pairhead), C.c_int, C.c_int]),
+    "pn_pairhead_fwd_train": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "pn_pairhead_bwd": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.POINTER(pn_pairhead_grads), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_tp_fn_fp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pn_clip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "pn_transpose": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
+    "pn_gemm_tn": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                             C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_prof_begin": (C.c_int, []),
+    "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]),
     "pn_gemm_nt": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              C.c_void_p]),
@@ -125,3 +164,17 @@ def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def prof_begin():
+    check(lib().pn_prof_begin())
+
+
+def prof_end():
+    """-> {kind: (launches, total_ms, total_flops)} (synchronises the device first)."""
+    torch.cuda.synchronize()
+    n = 64
+    kinds, counts = (C.c_int * n)(), (C.c_long * n)()
+    ms, fl = (C.c_double * n)(), (C.c_double * n)()
+    got = lib().pn_prof_end(n, kinds, counts, ms, fl)
+    return {int(kinds[i]): (int(counts[i]), float(ms[i]), float(fl[i])) for i in range(got)}

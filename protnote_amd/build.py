@@ -7,9 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "protnote_hip.hip")]
 HDR = [os.path.join(HERE, "csrc", "gemm_engine.hpp"),
        os.path.join(HERE, "csrc", "gemm_tn.hpp"),
+       os.path.join(HERE, "csrc", "train_kernels.hpp"),
        os.path.join(os.path.dirname(HERE), "include", "protnote_hip.h")]
 LIB = os.path.join(HERE, "libprotnote_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 
 def stale() -> bool:

@@ -16,7 +16,13 @@ namespace pn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3 };
+// A_DZ_*: BatchNorm+ReLU backward fused into the operand load.  With u = s*z + t the forward activation
+// was relu(u); given the upstream gradient g of that activation,
+//     dz = (u > 0 ? g * cs[k] : 0) + p[k] + q[k] * z
+// where cs/p/q are per-column vectors prepared by k_bn_bwd_finalize (cs = s, or s*w_out for the last
+// hidden layer whose upstream gradient is the rank-1 dlogit[r] * w_out[k]).
+//   A_DZ_ELEM: g = G[r][k] (stored gradient matrix);  A_DZ_ROWG: g = gvec[r] (one scalar per row).
+enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3, A_DZ_ELEM = 4, A_DZ_ROWG = 5 };
 enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3 };
 
 struct GemmParams {
@@ -28,7 +34,7 @@ struct GemmParams {
   long lda;
   const float* a_scale;  // per-k affine (A_AFFINE_RELU, optional for A_CONV): relu(x*scale+shift)
   const float* a_shift;
-  const float* A2;       // A_PAIRSUM_RELU: relu(A[r % pairB] + A2[r / pairB])
+  const float* A2;       // A_PAIRSUM_RELU: relu(A[r % pairB] + A2[r / pairB]);  A_DZ_ELEM: G (ld = lda2)
   long lda2;
   int pairB;
   const int* lens;       // A_CONV / E_CONV: int32 sequence lengths [M / L]
@@ -52,6 +58,11 @@ struct GemmParams {
   const float* row_scale;  // E_SCALE_RC: acc * row_scale[m] * col_scale[n] * alpha
   const float* col_scale;
   float alpha;
+  // ---- A_DZ_* (A = z matrix, a_scale/a_shift = s,t of the forward BN fold) ----
+  const float* gvec;   // A_DZ_ROWG: per-row upstream scalar
+  const float* dz_cs;  // per-k vectors
+  const float* dz_p;
+  const float* dz_q;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   const float* arow[NQA];
   const float* arow2[NQA];
   int a_t[NQA], a_len[NQA];
+  float a_g[NQA];
 #pragma unroll
   for (int q = 0; q < NQA; ++q) {
     int r = row0 + r_in + q * RPP;
@@ -112,6 +124,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
       a_t[q] = 0;
       a_len[q] = 0;
     }
+    if constexpr (AK == A_DZ_ELEM) arow2[q] = p.A2 + (long)r * p.lda2;
+    a_g[q] = 0.f;
+    if constexpr (AK == A_DZ_ROWG) a_g[q] = p.gvec[r];
   }
   const float* brow[NQB];
   bool bvalid[NQB];
@@ -128,6 +143,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 
   float4 ra[NQA], ra2[NQA], rb[NQB];
   float4 rsc = make_float4(0, 0, 0, 0), rsh = make_float4(0, 0, 0, 0);
+  float4 rcs = make_float4(0, 0, 0, 0), rp = make_float4(0, 0, 0, 0), rq = make_float4(0, 0, 0, 0);
   unsigned avalid = 0;
 
   auto fetch = [&](int s) {
@@ -152,13 +168,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
 #pragma unroll
       for (int q = 0; q < NQA; ++q) {
         ra[q] = kok ? ld4(arow[q] + c) : make_float4(0, 0, 0, 0);
-        if constexpr (AK == A_PAIRSUM_RELU) ra2[q] = kok ? ld4(arow2[q] + c) : make_float4(0, 0, 0, 0);
+        if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM)
+          ra2[q] = kok ? ld4(arow2[q] + c) : make_float4(0, 0, 0, 0);
       }
       avalid = kok ? 0xffffffffu : 0u;
-      if constexpr (AK == A_AFFINE_RELU) {
+      if constexpr (AK == A_AFFINE_RELU || AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
         if (kok) {
           rsc = ld4(p.a_scale + c);
           rsh = ld4(p.a_shift + c);
+        }
+      }
+      if constexpr (AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
+        if (kok) {
+          rcs = ld4(p.dz_cs + c);
+          rp = ld4(p.dz_p + c);
+          rq = ld4(p.dz_q + c);
         }
       }
     }
@@ -187,6 +211,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
         v.y = relu(v.y + ra2[q].y);
         v.z = relu(v.z + ra2[q].z);
         v.w = relu(v.w + ra2[q].w);
+      } else if constexpr (AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
+        if (ok) {
+          float4 g;
+          if constexpr (AK == A_DZ_ELEM) g = ra2[q];
+          else g = make_float4(a_g[q], a_g[q], a_g[q], a_g[q]);
+          v.x = (fmaf(v.x, rsc.x, rsh.x) > 0.f ? g.x * rcs.x : 0.f) + fmaf(rq.x, v.x, rp.x);
+          v.y = (fmaf(v.y, rsc.y, rsh.y) > 0.f ? g.y * rcs.y : 0.f) + fmaf(rq.y, v.y, rp.y);
+          v.z = (fmaf(v.z, rsc.z, rsh.z) > 0.f ? g.z * rcs.z : 0.f) + fmaf(rq.z, v.z, rp.z);
+          v.w = (fmaf(v.w, rsc.w, rsh.w) > 0.f ? g.w * rcs.w : 0.f) + fmaf(rq.w, v.w, rp.w);
+        }
       } else if constexpr (AK == A_CONV) {
         if (conv_affine && ok) {
           v.x = relu(fmaf(v.x, rsc.x, rsh.x));

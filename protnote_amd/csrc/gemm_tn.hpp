@@ -1,0 +1,225 @@
+// f32-MFMA "TN" GEMM engine for gfx950: weight-gradient contraction over the (huge) row dimension,
+//     Cpart[split][m][n] = sum_{r in split}  Agen[r][m] * Bgen[r][n]
+// Both operands are row-major [R][cols] in HBM, i.e. K-major for this contraction; their tiles are staged
+// global -> registers (generator applied: BN/ReLU backward for A, BN+ReLU forward recompute for B) ->
+// LDS [BK][cols+4] and read as single dwords (lane l: k = l>>5, col = l&31 -> 32 consecutive banks, conflict
+// free).  Split-K over row ranges; partial tiles are written (not atomically added) to Cpart and summed in
+// split order by k_splitk_reduce, so weight gradients are bit-reproducible.
+// Grid: x = output tiles (n fastest), y = row split, so all tiles of one row range are co-scheduled and the
+// streamed dz / activation rows are shared through L2 / Infinity Cache.
+#pragma once
+#include "gemm_engine.hpp"
+
+namespace pn {
+
+enum { TA_PLAIN = 0, TA_DZ_ELEM = 1, TA_DZ_ROWG = 2 };
+enum { TB_PLAIN = 0, TB_AFFINE_RELU = 1, TB_PAIRSUM_RELU = 2 };
+
+struct TnParams {
+  long R;               // contraction extent (rows)
+  long rows_per_split;  // multiple of BK
+  int M, N;             // output tile space: m indexes A columns, n indexes B columns
+  // ---- A generator ----
+  const float* A;  // TA_PLAIN: the matrix; TA_DZ_*: z (pre-activation)
+  long lda;
+  const float* G;  // TA_DZ_ELEM: upstream gradient matrix
+  long ldg;
+  const float* gvec;  // TA_DZ_ROWG: per-row upstream scalar
+  const float* m_s;   // per-m vectors of the dz generator (see gemm_engine.hpp A_DZ_*)
+  const float* m_t;
+  const float* m_cs;
+  const float* m_p;
+  const float* m_q;
+  // ---- B generator ----
+  const float* B;  // TB_PLAIN: X; TB_AFFINE_RELU: relu(b_s*Y + b_t); TB_PAIRSUM_RELU: relu(B[r % pairB] + B2[r / pairB])
+  long ldb;
+  const float* b_s;
+  const float* b_t;
+  const float* B2;
+  long ldb2;
+  int pairB;
+  // ---- output ----
+  float* Cpart;  // [nsplit][M][ldc]
+  long ldc;
+};
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int LDM = BM + 4, LDN = BN + 4;
+  constexpr int STAGE = BK * (LDM + LDN);
+  constexpr int NQ = 4;  // (BK rows * 32 float4 per row) / 256 threads
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn;
+  const int tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const long r_begin = (long)split * p.rows_per_split;
+  long r_end = r_begin + p.rows_per_split;
+  if (r_end > p.R) r_end = p.R;
+
+  const int c4 = tid & 31;  // float4 column within the tile row
+  const int rr = tid >> 5;  // 0..7: tile row (k) within a pass
+  const int am = m0 + 4 * c4;
+  const int bn = n0 + 4 * c4;
+  const bool a_ok = am < p.M;  // M, N are multiples of 4
+  const bool b_ok = bn < p.N;
+
+  // per-column constants of the generators never change along K: keep them in registers
+  float4 ms = make_float4(0, 0, 0, 0), mt = ms, mcs = ms, mp = ms, mq = ms, bs = ms, bt = ms;
+  if constexpr (TA != TA_PLAIN) {
+    if (a_ok) {
+      ms = ld4(p.m_s + am);
+      mt = ld4(p.m_t + am);
+      mcs = ld4(p.m_cs + am);
+      mp = ld4(p.m_p + am);
+      mq = ld4(p.m_q + am);
+    }
+  }
+  if constexpr (TB == TB_AFFINE_RELU) {
+    if (b_ok) {
+      bs = ld4(p.b_s + bn);
+      bt = ld4(p.b_t + bn);
+    }
+  }
+
+  float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
+  unsigned rowok = 0;
+
+  auto fetch = [&](long k0) {
+    rowok = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const long r = k0 + rr + 8 * q;
+      const bool ok = r < r_end;
+      rowok |= (ok ? 1u : 0u) << q;
+      const float4 z4 = make_float4(0, 0, 0, 0);
+      ra[q] = (ok && a_ok) ? ld4(p.A + r * p.lda + am) : z4;
+      if constexpr (TA == TA_DZ_ELEM) rg[q] = (ok && a_ok) ? ld4(p.G + r * p.ldg + am) : z4;
+      if constexpr (TA == TA_DZ_ROWG) {
+        const float g = ok ? p.gvec[r] : 0.f;
+        rg[q] = make_float4(g, g, g, g);
+      }
+      if constexpr (TB == TB_PAIRSUM_RELU) {
+        const long j = r / p.pairB;
+        const long i = r - j * p.pairB;
+        rb[q] = (ok && b_ok) ? ld4(p.B + i * p.ldb + bn) : z4;
+        rb2[q] = (ok && b_ok) ? ld4(p.B2 + j * p.ldb2 + bn) : z4;
+      } else {
+        rb[q] = (ok && b_ok) ? ld4(p.B + r * p.ldb + bn) : z4;
+      }
+    }
+  };
+
+  auto commit = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BK * LDM;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = (rowok >> q) & 1u;
+      float4 a = ra[q];
+      if constexpr (TA != TA_PLAIN) {
+        if (ok && a_ok) {
+          const float4 g = rg[q];
+          a.x = (fmaf(a.x, ms.x, mt.x) > 0.f ? g.x * mcs.x : 0.f) + fmaf(mq.x, a.x, mp.x);
+          a.y = (fmaf(a.y, ms.y, mt.y) > 0.f ? g.y * mcs.y : 0.f) + fmaf(mq.y, a.y, mp.y);
+          a.z = (fmaf(a.z, ms.z, mt.z) > 0.f ? g.z * mcs.z : 0.f) + fmaf(mq.z, a.z, mp.z);
+          a.w = (fmaf(a.w, ms.w, mt.w) > 0.f ? g.w * mcs.w : 0.f) + fmaf(mq.w, a.w, mp.w);
+        }
+      }
+      float4 b = rb[q];
+      if constexpr (TB == TB_AFFINE_RELU) {
+        if (ok && b_ok) {
+          b.x = relu(fmaf(b.x, bs.x, bt.x));
+          b.y = relu(fmaf(b.y, bs.y, bt.y));
+          b.z = relu(fmaf(b.z, bs.z, bt.z));
+          b.w = relu(fmaf(b.w, bs.w, bt.w));
+        }
+      } else if constexpr (TB == TB_PAIRSUM_RELU) {
+        b.x = relu(b.x + rb2[q].x);
+        b.y = relu(b.y + rb2[q].y);
+        b.z = relu(b.z + rb2[q].z);
+        b.w = relu(b.w + rb2[q].w);
+      }
+      *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = a;
+      *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = b;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fcol = lane & 31;
+  const int fk = lane >> 5;
+
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * STAGE + fk * LDM + wm * 64 + fcol;
+    const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 + fcol;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a0 = As[(2 * kk) * LDM], a1 = As[(2 * kk) * LDM + 32];
+      const float b0 = Bs[(2 * kk) * LDN], b1 = Bs[(2 * kk) * LDN + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  if (r_begin < r_end) {
+    fetch(r_begin);
+    commit(0);
+    __syncthreads();
+    int cur = 0;
+    for (long k0 = r_begin; k0 < r_end; k0 += BK) {
+      const bool more = (k0 + BK) < r_end;
+      if (more) fetch(k0 + BK);
+      compute(cur);
+      if (more) commit(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  float* out = p.Cpart + (long)split * p.M * p.ldc;
+  const int hl = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + fcol;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        if (m < p.M && n < p.N) out[(long)m * p.ldc + n] = acc[i][j][e];
+      }
+    }
+}
+
+constexpr int TN_LDS_BYTES = 2 * 32 * (132 + 132) * (int)sizeof(float);
+
+// dst[m][n] (ld = ldd) = sum_s part[s][m][n] (ld = ldp)
+__global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, int M, int N, long ldp,
+                                float* __restrict__ dst, long ldd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (long)m * N);
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += part[((long)s * M + m) * ldp + n];
+  dst[(long)m * ldd + n] = a;
+}
+
+}  // namespace pn

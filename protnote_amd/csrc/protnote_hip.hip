@@ -59,6 +59,77 @@ struct Bump {
 };
 
 // ------------------------------------------------------------------------------------------------
+// optional per-launch timing of the GEMM kernels (hipEvents on the launch stream; bench.py roofline)
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+struct ProfRec {
+  int kind;  // family*100 + operand kind*10 + epilogue kind  (family 0: NT engine, 1: TN engine)
+  double flops;
+  hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+extern "C" int pn_prof_begin(void) {
+  for (auto& r : g_prof) {
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+
+// Stops recording and aggregates per kernel kind.  Caller must have synchronised the stream(s).
+extern "C" int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops) {
+  g_prof_on = false;
+  int n = 0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+    int k = -1;
+    for (int i = 0; i < n; ++i)
+      if (kinds[i] == r.kind) k = i;
+    if (k < 0) {
+      if (n >= max_kinds) continue;
+      k = n++;
+      kinds[k] = r.kind;
+      counts[k] = 0;
+      total_ms[k] = 0;
+      total_flops[k] = 0;
+    }
+    counts[k] += 1;
+    total_ms[k] += ms;
+    total_flops[k] += r.flops;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return n;
+}
+
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(int kind, double flops, hipStream_t s) : on(g_prof_on && g_prof.size() < 100000), st(s) {
+    if (on) {
+      r.kind = kind;
+      r.flops = flops;
+      hipEventCreate(&r.e0);
+      hipEventCreate(&r.e1);
+      hipEventRecord(r.e0, st);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(r.e1, st);
+      g_prof.push_back(r);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // GEMM launch
 // ------------------------------------------------------------------------------------------------
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
@@ -78,7 +149,10 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   const long tm = (p.M + Cfg::BM - 1) / Cfg::BM;
   const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
   if (tm * tn > 0x7fffffffL) return fail("gemm: grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+  {
+    ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -650,4 +724,650 @@ extern "C" int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, fl
     return launch_gemm<A_AFFINE_RELU, E_STORE>(p, v, (hipStream_t)stream);
   }
   return launch_gemm<A_PLAIN, E_STORE>(p, v, (hipStream_t)stream);
+}
+
+// ================================================================================================
+//                                      TRAINING PATH
+// ================================================================================================
+#include "gemm_tn.hpp"
+#include "train_kernels.hpp"
+
+static int transpose_into(const float* src, long lds_, int rows, int cols, float* dst, long ldd, hipStream_t st) {
+  hipLaunchKernelGGL(k_transpose, dim3(nblk(cols, 32), nblk(rows, 32)), dim3(256), 0, st, src, lds_, rows, cols, dst,
+                     ldd);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// choose the row split of a TN contraction: enough workgroups to fill 256 CUs x 2 several times over,
+// bounded by the partial-tile scratch the caller provided.
+static int tn_pick_split(long R, int M, int N, size_t part_cap_floats) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long slabs = (R + 31) / 32;
+  long ns = (4608 + tiles - 1) / tiles;
+  if (ns > slabs / 8) ns = slabs / 8;
+  if (ns < 1) ns = 1;
+  const long cap = (long)(part_cap_floats / ((size_t)M * N));
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+template <int TA, int TB>
+static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
+  auto kern = gemm_tn_kernel<TA, TB>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M % 4 || p.N % 4) return fail("gemm_tn: M and N must be multiples of 4");
+  if (p.R <= 0) return fail("gemm_tn: empty contraction");
+  int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats);
+  if (ns == 1) {
+    p.Cpart = dst;
+    p.ldc = ldd;
+    p.rows_per_split = (p.R + 31) / 32 * 32;
+  } else {
+    if (part == nullptr) return fail("gemm_tn: no partial buffer");
+    p.Cpart = part;
+    p.ldc = p.N;
+    long rps = (p.R + ns - 1) / ns;
+    p.rows_per_split = (rps + 31) / 32 * 32;
+    ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
+  }
+  const unsigned tiles = (unsigned)(((p.M + 127) / 128) * ((p.N + 127) / 128));
+  {
+    ProfScope ps(100 + TA * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
+    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(256), TN_LDS_BYTES, st, p);
+  }
+  HIP_OK(hipGetLastError());
+  if (ns > 1) {
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nblk((long)p.M * p.N, 256)), dim3(256), 0, st, (const float*)part, ns,
+                       p.M, p.N, (long)p.N, dst, ldd);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+static TnParams tn_zero() {
+  TnParams p;
+  memset(&p, 0, sizeof(p));
+  p.pairB = 1;
+  return p;
+}
+
+static const size_t TN_PART_FLOATS_MAX = (size_t)8 * 3072 * 3072;
+
+// ------------------------------------------------------------------------------------------------
+// row MLP (W_p / W_l), train forward + backward
+// ------------------------------------------------------------------------------------------------
+struct MlpSave {
+  float* Y[PN_MAX_LAYERS];
+  float *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS], *mean[PN_MAX_LAYERS], *invstd[PN_MAX_LAYERS];
+};
+
+static bool mlp_save_carve(const pn_mlp* m, int rows, Bump& bp, MlpSave& s) {
+  for (int l = 0; l + 1 < m->nlayers; ++l) {
+    const int h = m->dims[l + 1];
+    s.Y[l] = bp.take<float>((size_t)rows * h);
+    s.s[l] = bp.take<float>(h);
+    s.t[l] = bp.take<float>(h);
+    s.mean[l] = bp.take<float>(h);
+    s.invstd[l] = bp.take<float>(h);
+  }
+  return bp.ok;
+}
+
+struct MlpTrainWs {
+  double *S1, *S2;  // also forward column sum / sumsq
+  float *cs, *p, *q, *G[2], *WT, *part;
+  size_t part_floats;
+};
+
+static bool mlp_train_ws_carve(const pn_mlp* m, int rows, Bump& bp, MlpTrainWs& w) {
+  int hmax = 0;
+  size_t wmax = 0;
+  for (int l = 0; l < m->nlayers; ++l) {
+    if (l + 1 < m->nlayers && m->dims[l + 1] > hmax) hmax = m->dims[l + 1];
+    const size_t e = (size_t)m->dims[l] * m->dims[l + 1];
+    if (e > wmax) wmax = e;
+  }
+  if (hmax == 0) hmax = 4;
+  w.S1 = bp.take<double>(hmax);
+  w.S2 = bp.take<double>(hmax);
+  w.cs = bp.take<float>(hmax);
+  w.p = bp.take<float>(hmax);
+  w.q = bp.take<float>(hmax);
+  w.G[0] = bp.take<float>((size_t)rows * hmax);
+  w.G[1] = bp.take<float>((size_t)rows * hmax);
+  w.WT = bp.take<float>(wmax);
+  w.part_floats = wmax * 8 < TN_PART_FLOATS_MAX ? wmax * 8 : TN_PART_FLOATS_MAX;
+  w.part = bp.take<float>(w.part_floats);
+  return bp.ok;
+}
+
+extern "C" size_t pn_mlp_rows_train_save_bytes(const pn_mlp* m, int rows) {
+  Bump bp(nullptr, (size_t)-1);
+  MlpSave s;
+  mlp_save_carve(m, rows, bp, s);
+  return bp.off + 256;
+}
+
+extern "C" size_t pn_mlp_rows_train_ws_bytes(const pn_mlp* m, int rows) {
+  Bump bp(nullptr, (size_t)-1);
+  MlpTrainWs w;
+  mlp_train_ws_carve(m, rows, bp, w);
+  return bp.off + 256;
+}
+
+static int mlp_check(const pn_mlp* m, int ldx) {
+  if (m->nlayers < 1 || m->nlayers > PN_MAX_LAYERS) return fail("mlp: bad layer count %d", m->nlayers);
+  for (int i = 0; i <= m->nlayers; ++i)
+    if (m->dims[i] % 4 != 0) return fail("mlp: dims[%d]=%d not a multiple of 4", i, m->dims[i]);
+  if (ldx % 4 != 0) return fail("mlp: ldx %% 4 != 0");
+  for (int i = 0; i + 1 < m->nlayers; ++i) {
+    if (m->bn[i].weight == nullptr) return fail("mlp train: layer %d has no BatchNorm (unsupported)", i);
+    if (m->bias[i] != nullptr) return fail("mlp train: Linear bias with BatchNorm unsupported");
+  }
+  if (m->bias[m->nlayers - 1] != nullptr) return fail("mlp train: bias on the last Linear unsupported");
+  return 0;
+}
+
+extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* save,
+                                     size_t save_bytes, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PN_OK(mlp_check(m, ldx));
+  Bump bs(save, save_bytes), bw(ws, ws_bytes);
+  MlpSave sv;
+  MlpTrainWs w;
+  if (!mlp_save_carve(m, rows, bs, sv)) return fail("mlp train: save buffer too small");
+  if (!mlp_train_ws_carve(m, rows, bw, w)) return fail("mlp train: workspace too small");
+  const float* in = x;
+  long ldin = ldx;
+  for (int l = 0; l < m->nlayers; ++l) {
+    const bool last = (l + 1 == m->nlayers);
+    const int N = m->dims[l + 1];
+    GemmParams p = gp_zero();
+    p.M = rows; p.N = N; p.Nstore = N; p.Kseg = m->dims[l];
+    p.A = in; p.lda = ldin; p.W = m->w[l]; p.ldw = m->dims[l];
+    p.C = last ? y : sv.Y[l]; p.ldc = N;
+    if (!last) {
+      HIP_OK(hipMemsetAsync(w.S1, 0, N * sizeof(double), st));
+      HIP_OK(hipMemsetAsync(w.S2, 0, N * sizeof(double), st));
+      p.col_sum = w.S1; p.col_sumsq = w.S2;
+    }
+    if (l == 0) {
+      PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(N), st)));
+    } else {
+      p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
+      PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, pick_variant(N), st)));
+    }
+    if (!last) {
+      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(N, 256)), dim3(256), 0, st, m->bn[l], (const double*)w.S1,
+                         (const double*)w.S2, (double)rows, m->bn_eps, m->bn_momentum, N, N, sv.s[l], sv.t[l],
+                         sv.mean[l], sv.invstd[l]);
+      HIP_OK(hipGetLastError());
+      in = sv.Y[l];
+      ldin = N;
+    }
+  }
+  return 0;
+}
+
+extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int rows, const float* dy,
+                               const pn_mlp_grads* gr, float* dx, void* save, size_t save_bytes, void* ws,
+                               size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PN_OK(mlp_check(m, ldx));
+  Bump bs(save, save_bytes), bw(ws, ws_bytes);
+  MlpSave sv;
+  MlpTrainWs w;
+  if (!mlp_save_carve(m, rows, bs, sv)) return fail("mlp bwd: save buffer too small");
+  if (!mlp_train_ws_carve(m, rows, bw, w)) return fail("mlp bwd: workspace too small");
+  const int n = m->nlayers;
+  const float* G = dy;  // gradient wrt the OUTPUT of layer l's Linear ... see below
+  long ldg = m->dims[n];
+  int gsel = 0;
+  for (int l = n - 1; l >= 0; --l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const bool last = (l == n - 1);
+    // For the last layer G = dY (plain).  For hidden layers G = d(relu(bn(Y_l))) and dY_l is generated.
+    if (!last) {
+      HIP_OK(hipMemsetAsync(w.S1, 0, N * sizeof(double), st));
+      HIP_OK(hipMemsetAsync(w.S2, 0, N * sizeof(double), st));
+      StatsParams sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.R = rows; sp.C = N; sp.rows_per_block = 1024;
+      sp.Z = sv.Y[l]; sp.ldz = N; sp.G = G; sp.ldg = ldg;
+      sp.s = sv.s[l]; sp.t = sv.t[l]; sp.mean = sv.mean[l]; sp.invstd = sv.invstd[l];
+      sp.S1 = w.S1; sp.S2 = w.S2; sp.pairB = 1;
+      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(N, 1024), nblk(rows, 1024)), dim3(256), 0, st, sp);
+      hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(N, 256)), dim3(256), 0, st, (const double*)w.S1,
+                         (const double*)w.S2, (const double*)nullptr, (double)rows, N, m->bn[l].weight,
+                         (const float*)sv.s[l], (const float*)sv.mean[l], (const float*)sv.invstd[l],
+                         (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[l], gr->dbeta[l], (float*)nullptr);
+      HIP_OK(hipGetLastError());
+    }
+    // dW_l[N][K] = dY_l^T X_l
+    TnParams tp = tn_zero();
+    tp.R = rows; tp.M = N; tp.N = K;
+    if (last) {
+      tp.A = G; tp.lda = ldg;
+    } else {
+      tp.A = sv.Y[l]; tp.lda = N; tp.G = G; tp.ldg = ldg;
+      tp.m_s = sv.s[l]; tp.m_t = sv.t[l]; tp.m_cs = w.cs; tp.m_p = w.p; tp.m_q = w.q;
+    }
+    if (l == 0) {
+      tp.B = x; tp.ldb = ldx;
+      if (last) PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+      else PN_OK((launch_tn<TA_DZ_ELEM, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+    } else {
+      tp.B = sv.Y[l - 1]; tp.ldb = K; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
+      if (last) PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+      else PN_OK((launch_tn<TA_DZ_ELEM, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+    }
+    // dX_l[rows][K] = dY_l W_l   (NT engine against W_l^T)
+    if (l > 0 || dx != nullptr) {
+      PN_OK(transpose_into(m->w[l], K, N, K, w.WT, N, st));  // WT[K][N]
+      GemmParams p = gp_zero();
+      p.M = rows; p.N = K; p.Nstore = K; p.Kseg = N;
+      p.W = w.WT; p.ldw = N;
+      float* out = (l == 0) ? dx : w.G[gsel];
+      p.C = out; p.ldc = K;
+      if (last) {
+        p.A = G; p.lda = ldg;
+        PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(K), st)));
+      } else {
+        p.A = sv.Y[l]; p.lda = N; p.A2 = G; p.lda2 = ldg;
+        p.a_scale = sv.s[l]; p.a_shift = sv.t[l]; p.dz_cs = w.cs; p.dz_p = w.p; p.dz_q = w.q;
+        PN_OK((launch_gemm<A_DZ_ELEM, E_STORE>(p, pick_variant(K), st)));
+      }
+      G = out;
+      ldg = K;
+      gsel ^= 1;
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair head, train forward + backward
+// ------------------------------------------------------------------------------------------------
+struct PairSave {
+  float *A1, *B1, *Ap, *Bp;
+  float *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS], *mean[PN_MAX_LAYERS], *invstd[PN_MAX_LAYERS];
+  float* zbuf[PN_MAX_LAYERS];  // l >= 1: (R + S) rows x h; z_l lives at row offset S
+};
+
+static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& bp, PairSave& s) {
+  const int h = hd->h;
+  const long R = (long)B * NL;
+  s.A1 = bp.take<float>((size_t)B * h);
+  s.B1 = bp.take<float>((size_t)NL * h);
+  s.Ap = bp.take<float>((size_t)B * h);
+  s.Bp = bp.take<float>((size_t)NL * h);
+  for (int l = 0; l < hd->nlayers; ++l) {
+    s.s[l] = bp.take<float>(h);
+    s.t[l] = bp.take<float>(h);
+    s.mean[l] = bp.take<float>(h);
+    s.invstd[l] = bp.take<float>(h);
+  }
+  s.zbuf[0] = nullptr;
+  for (int l = 1; l < hd->nlayers; ++l) s.zbuf[l] = bp.take<float>((size_t)(R + S) * h);
+  return bp.ok;
+}
+
+struct PairTrainWs {
+  double *sumA, *sqA, *sumB, *sqB, *S1, *S2, *dwacc, *scal;
+  float *cs, *p, *q, *WT, *weff, *dweff, *part, *dA1, *dB1;
+  size_t part_floats;
+};
+
+static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, PairTrainWs& w) {
+  const int h = hd->h, d = hd->d;
+  w.sumA = bp.take<double>(h);
+  w.sqA = bp.take<double>(h);
+  w.sumB = bp.take<double>(h);
+  w.sqB = bp.take<double>(h);
+  w.S1 = bp.take<double>(h);
+  w.S2 = bp.take<double>(h);
+  w.dwacc = bp.take<double>(h);
+  w.scal = bp.take<double>(4);
+  w.cs = bp.take<float>(h);
+  w.p = bp.take<float>(h);
+  w.q = bp.take<float>(h);
+  const size_t wt = (size_t)h * (h > 2 * d ? h : 2 * d);
+  w.WT = bp.take<float>(wt);
+  w.weff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * d) : nullptr;
+  w.dweff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * d) : nullptr;
+  w.part_floats = (size_t)8 * h * h < TN_PART_FLOATS_MAX ? (size_t)8 * h * h : TN_PART_FLOATS_MAX;
+  w.part = bp.take<float>(w.part_floats);
+  w.dA1 = bp.take<float>((size_t)B * h);
+  w.dB1 = bp.take<float>((size_t)NL * h);
+  return bp.ok;
+}
+
+static long pair_chunk_rows(int B, int NL, int label_chunk) {
+  long c = label_chunk <= 0 ? 256 : label_chunk;
+  if (c > NL) c = NL;
+  return c * (long)B;
+}
+
+extern "C" size_t pn_pairhead_train_save_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk) {
+  Bump bp(nullptr, (size_t)-1);
+  PairSave s;
+  pair_save_carve(hd, B, NL, pair_chunk_rows(B, NL, label_chunk), bp, s);
+  return bp.off + 256;
+}
+
+extern "C" size_t pn_pairhead_train_ws_bytes(const pn_pairhead* hd, int B, int NL) {
+  Bump bp(nullptr, (size_t)-1);
+  PairTrainWs w;
+  pair_train_ws_carve(hd, B, NL, bp, w);
+  return bp.off + 256;
+}
+
+static int pair_check(const pn_pairhead* hd, int B, int NL) {
+  if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported", hd->nlayers);
+  if (hd->fusion != 0 && hd->fusion != 1) return fail("pairhead: fusion %d not implemented", hd->fusion);
+  if (hd->d % 4 || hd->h % 4) return fail("pairhead: d and h must be multiples of 4");
+  if ((long)B * NL > 0x7fffffffL) return fail("pairhead: pair grid too large");
+  for (int l = 0; l < hd->nlayers; ++l) {
+    if (hd->bn[l].weight != nullptr && hd->bias[l] != nullptr)
+      return fail("pairhead: Linear bias together with BatchNorm is not supported");
+  }
+  return 0;
+}
+
+__global__ void k_diff_weight_grad(const float* __restrict__ dweff, float* __restrict__ dw, int h, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)h * d) return;
+  const int n = (int)(i / d), k = (int)(i - (long)n * d);
+  const float ga = dweff[(long)n * 2 * d + k], gb = dweff[(long)n * 2 * d + d + k];
+  float* row = dw + (long)n * 3 * d;
+  row[k] = ga;
+  row[d + k] = gb;
+  row[2 * d + k] = ga - gb;
+}
+
+extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                                     float* logits_pairs, int label_chunk, void* save, size_t save_bytes, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PN_OK(pair_check(hd, B, NL));
+  for (int l = 0; l < hd->nlayers; ++l)
+    if (hd->bn[l].weight == nullptr) return fail("pairhead train: layer %d has no BatchNorm (unsupported)", l);
+  const int h = hd->h, d = hd->d, n = hd->nlayers;
+  const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
+  Bump bs(save, save_bytes), bw(ws, ws_bytes);
+  PairSave sv;
+  PairTrainWs w;
+  if (!pair_save_carve(hd, B, NL, S, bs, sv)) return fail("pairhead train: save buffer too small");
+  if (!pair_train_ws_carve(hd, B, NL, bw, w)) return fail("pairhead train: workspace too small");
+
+  const float* w1 = hd->w[0];
+  long ldw1 = hd->in_dim;
+  if (hd->fusion == 1) {
+    hipLaunchKernelGGL(k_diff_weight, dim3(nblk((long)h * 2 * d, 256)), dim3(256), 0, st, hd->w[0], w.weff, h, d);
+    w1 = w.weff;
+    ldw1 = 2 * d;
+  }
+  HIP_OK(hipMemsetAsync(w.sumA, 0, 4 * al256(h * sizeof(double)), st));  // sumA, sqA, sumB, sqB are contiguous
+  {
+    GemmParams p = gp_zero();
+    p.M = B; p.N = h; p.Nstore = h; p.Kseg = d;
+    p.A = P_e; p.lda = d; p.W = w1; p.ldw = ldw1; p.C = sv.A1; p.ldc = h;
+    p.col_sum = w.sumA; p.col_sumsq = w.sqA;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+    p.M = NL; p.A = L_e; p.W = w1 + d; p.C = sv.B1; p.col_sum = w.sumB; p.col_sumsq = w.sqB;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+  }
+  hipLaunchKernelGGL(k_bn_fold_pair, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.sumA,
+                     (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL,
+                     hd->bn_eps, hd->bn_momentum, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]);
+  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, (const float*)sv.A1, (long)h,
+                     sv.Ap, (long)h, (long)B, h, (const float*)sv.s[0], (const float*)sv.t[0]);
+  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, (const float*)sv.B1, (long)h,
+                     sv.Bp, (long)h, (long)NL, h, (const float*)sv.s[0], (const float*)nullptr);
+  HIP_OK(hipGetLastError());
+
+  for (int l = 1; l < n; ++l) {
+    float* z = sv.zbuf[l] + (size_t)S * h;
+    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
+    GemmParams p = gp_zero();
+    p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
+    p.W = hd->w[l]; p.ldw = h; p.C = z; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
+    if (l == 1) {
+      p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
+      PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+    } else {
+      p.A = sv.zbuf[l - 1] + (size_t)S * h; p.lda = h; p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
+      PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+    }
+    hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[l], (const double*)w.S1,
+                       (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[l], sv.t[l],
+                       sv.mean[l], sv.invstd[l]);
+    HIP_OK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_rowdot_rows, dim3(nblk(R, 4)), dim3(256), 0, st,
+                     (const float*)(sv.zbuf[n - 1] + (size_t)S * h), (long)h, R, h, (const float*)sv.s[n - 1],
+                     (const float*)sv.t[n - 1], hd->w_out, hd->b_out, logits_pairs);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                               const float* dl_pairs, const pn_pairhead_grads* gr, float* dP_e, float* dL_e,
+                               int label_chunk, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PN_OK(pair_check(hd, B, NL));
+  const int h = hd->h, d = hd->d, n = hd->nlayers;
+  const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
+  Bump bs(save, save_bytes), bw(ws, ws_bytes);
+  PairSave sv;
+  PairTrainWs w;
+  if (!pair_save_carve(hd, B, NL, S, bs, sv)) return fail("pairhead bwd: save buffer too small");
+  if (!pair_train_ws_carve(hd, B, NL, bw, w)) return fail("pairhead bwd: workspace too small");
+
+  // d b_out = sum_r dl[r]
+  HIP_OK(hipMemsetAsync(w.scal, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(k_sum, dim3(1024), dim3(256), 0, st, dl_pairs, R, w.scal);
+  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)w.scal, gr->db_out, 1, 1.f);
+  HIP_OK(hipGetLastError());
+
+  const float* G = nullptr;  // gradient wrt relu(bn(z_l)) for the layer being processed (rows [0,R) of a zbuf)
+  const long stats_rows = 4096;
+  for (int l = n - 1; l >= 1; --l) {
+    const bool top = (l == n - 1);
+    float* z = sv.zbuf[l] + (size_t)S * h;
+    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.dwacc, 0, h * sizeof(double), st));
+    StatsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.R = R; sp.C = h; sp.rows_per_block = stats_rows; sp.pairB = 1;
+    sp.Z = z; sp.ldz = h;
+    sp.s = sv.s[l]; sp.t = sv.t[l]; sp.mean = sv.mean[l]; sp.invstd = sv.invstd[l];
+    sp.S1 = w.S1; sp.S2 = w.S2; sp.dw = w.dwacc;
+    const dim3 sg(nblk(h, 1024), nblk(R, stats_rows));
+    if (top) {
+      sp.gvec = dl_pairs; sp.w = hd->w_out;
+      hipLaunchKernelGGL((k_bn_bwd_stats<1, 0>), sg, dim3(256), 0, st, sp);
+    } else {
+      sp.G = G; sp.ldg = h;
+      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), sg, dim3(256), 0, st, sp);
+    }
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
+                       (const double*)w.S2, (const double*)(top ? w.dwacc : nullptr), (double)R, h,
+                       hd->bn[l].weight, (const float*)sv.s[l], (const float*)sv.mean[l],
+                       (const float*)sv.invstd[l], top ? hd->w_out : (const float*)nullptr, w.cs, w.p, w.q,
+                       gr->dgamma[l], gr->dbeta[l], top ? gr->dw_out : (float*)nullptr);
+    HIP_OK(hipGetLastError());
+
+    // dW_l = dz_l^T h_{l-1}
+    TnParams tp = tn_zero();
+    tp.R = R; tp.M = h; tp.N = h;
+    tp.A = z; tp.lda = h; tp.m_s = sv.s[l]; tp.m_t = sv.t[l]; tp.m_cs = w.cs; tp.m_p = w.p; tp.m_q = w.q;
+    if (top) tp.gvec = dl_pairs;
+    else { tp.G = G; tp.ldg = h; }
+    if (l == 1) {
+      tp.B = sv.Ap; tp.ldb = h; tp.B2 = sv.Bp; tp.ldb2 = h; tp.pairB = B;
+      if (top) PN_OK((launch_tn<TA_DZ_ROWG, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+      else PN_OK((launch_tn<TA_DZ_ELEM, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+    } else {
+      tp.B = sv.zbuf[l - 1] + (size_t)S * h; tp.ldb = h; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
+      if (top) PN_OK((launch_tn<TA_DZ_ROWG, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+      else PN_OK((launch_tn<TA_DZ_ELEM, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+    }
+
+    // dh_{l-1} = dz_l W_l, written chunk by chunk over the part of zbuf[l] already consumed (ring)
+    PN_OK(transpose_into(hd->w[l], h, h, h, w.WT, h, st));
+    for (long r0 = 0; r0 < R; r0 += S) {
+      const long rows = (R - r0 < S) ? R - r0 : S;
+      GemmParams p = gp_zero();
+      p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
+      p.A = z + (size_t)r0 * h; p.lda = h;
+      p.a_scale = sv.s[l]; p.a_shift = sv.t[l]; p.dz_cs = w.cs; p.dz_p = w.p; p.dz_q = w.q;
+      p.W = w.WT; p.ldw = h;
+      p.C = sv.zbuf[l] + (size_t)r0 * h; p.ldc = h;
+      if (top) {
+        p.gvec = dl_pairs + r0;
+        PN_OK((launch_gemm<A_DZ_ROWG, E_STORE>(p, 0, st)));
+      } else {
+        p.A2 = G + (size_t)r0 * h; p.lda2 = h;
+        PN_OK((launch_gemm<A_DZ_ELEM, E_STORE>(p, 0, st)));
+      }
+    }
+    G = sv.zbuf[l];
+  }
+
+  // ---- layer 0 (separable): z1[i,j] = A1[i] + B1[j], upstream gradient G = dh_0 over the pair grid ----
+  HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
+  HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
+  {
+    StatsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.R = R; sp.C = h; sp.rows_per_block = stats_rows;
+    sp.G = G; sp.ldg = h; sp.A = sv.A1; sp.lda = h; sp.B2 = sv.B1; sp.ldb2 = h; sp.pairB = B;
+    sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
+    sp.S1 = w.S1; sp.S2 = w.S2;
+    hipLaunchKernelGGL((k_bn_bwd_stats<0, 1>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
+                       (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
+                       (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
+                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr);
+    PairRedParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.B = B; rp.NL = NL; rp.C = h; rp.DH = G; rp.ldh = h;
+    rp.A = sv.A1; rp.lda = h; rp.Bm = sv.B1; rp.ldb = h;
+    rp.s = sv.s[0]; rp.t = sv.t[0]; rp.cs = w.cs; rp.p = w.p; rp.q = w.q;
+    rp.out = w.dB1; rp.ldo = h;
+    hipLaunchKernelGGL((k_pair_reduce<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
+    rp.out = w.dA1;
+    hipLaunchKernelGGL((k_pair_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+    HIP_OK(hipGetLastError());
+  }
+  // dW_0: [h][in_dim];  concatenation: [dA1^T P_e | dB1^T L_e]
+  float* dwa = hd->fusion == 1 ? w.dweff : gr->dw[0];
+  const long ldd = hd->fusion == 1 ? 2 * d : hd->in_dim;
+  {
+    TnParams tp = tn_zero();
+    tp.R = B; tp.M = h; tp.N = d; tp.A = w.dA1; tp.lda = h; tp.B = P_e; tp.ldb = d;
+    PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, dwa, ldd, w.part, w.part_floats, st)));
+    tp.R = NL; tp.A = w.dB1; tp.B = L_e;
+    PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, dwa + d, ldd, w.part, w.part_floats, st)));
+  }
+  const float* w1 = hd->w[0];
+  long ldw1 = hd->in_dim;
+  if (hd->fusion == 1) {
+    hipLaunchKernelGGL(k_diff_weight_grad, dim3(nblk((long)h * d, 256)), dim3(256), 0, st, (const float*)w.dweff,
+                       gr->dw[0], h, d);
+    hipLaunchKernelGGL(k_diff_weight, dim3(nblk((long)h * 2 * d, 256)), dim3(256), 0, st, hd->w[0], w.weff, h, d);
+    HIP_OK(hipGetLastError());
+    w1 = w.weff;
+    ldw1 = 2 * d;
+  }
+  // dP_e = dA1 W1a, dL_e = dB1 W1b
+  for (int side = 0; side < 2; ++side) {
+    float* out = side == 0 ? dP_e : dL_e;
+    if (out == nullptr) continue;
+    PN_OK(transpose_into(w1 + (side ? d : 0), ldw1, h, d, w.WT, h, st));  // WT[d][h]
+    GemmParams p = gp_zero();
+    p.M = side == 0 ? B : NL; p.N = d; p.Nstore = d; p.Kseg = h;
+    p.A = side == 0 ? w.dA1 : w.dB1; p.lda = h; p.W = w.WT; p.ldw = h; p.C = out; p.ldc = d;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss + metrics, optimiser, layout helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B,
+                               int N, int kind, float pos_weight, float gamma, float alpha, float smoothing,
+                               float threshold, float* loss_out, float* dlogits, float* tp, float* fn, float* fp,
+                               void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ws_bytes < 256) return fail("loss: workspace too small");
+  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("loss: pass exactly one target array");
+  double* acc = (double*)ws;
+  HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), st));
+  LossParams p;
+  memset(&p, 0, sizeof(p));
+  p.logits = logits; p.tf = targets_f32; p.ti = targets_i64; p.B = B; p.N = N; p.kind = kind;
+  p.pos_weight = pos_weight; p.gamma = gamma; p.alpha = alpha; p.smoothing = smoothing; p.threshold = threshold;
+  p.grad_scale = 1.f / ((float)B * (float)N);
+  p.dlogits = dlogits; p.loss_sum = acc; p.tp = tp; p.fn = fn; p.fp = fp;
+  p.rows_per_block = 32;
+  hipLaunchKernelGGL(k_loss, dim3(nblk(N, 256), nblk(B, 32)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)acc, loss_out, 1,
+                     1.f / ((float)B * (float)N));
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                           float threshold, float* tp, float* fn, float* fp, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("tp_fn_fp: pass exactly one target array");
+  HIP_OK(hipMemsetAsync(tp, 0, N * sizeof(float), st));
+  HIP_OK(hipMemsetAsync(fn, 0, N * sizeof(float), st));
+  HIP_OK(hipMemsetAsync(fp, 0, N * sizeof(float), st));
+  hipLaunchKernelGGL(k_tp_fn_fp, dim3(nblk(N, 256), nblk(B, 64)), dim3(256), 0, st, probs, targets_f32, targets_i64,
+                     B, N, threshold, tp, fn, fp, 64);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_clip_adam_step(float* w, const float* g, float* m, float* v, long n, float max_norm, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ws_bytes < 256) return fail("adam: workspace too small");
+  if (step < 1) return fail("adam: step must be >= 1");
+  double* acc = (double*)ws;
+  HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), st));
+  hipLaunchKernelGGL(k_sumsq, dim3(2048), dim3(256), 0, st, g, n, acc);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(k_adam, dim3(2048), dim3(256), 0, st, w, g, m, v, n, (const double*)acc, max_norm, lr, beta1,
+                     beta2, eps, bc1, bc2s, weight_decay, norm_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_transpose(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, void* stream) {
+  return transpose_into(src, ld_src, rows, cols, dst, ld_dst, (hipStream_t)stream);
+}
+
+extern "C" int pn_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, long R, int M,
+                          int N, void* ws, size_t ws_bytes, void* stream) {
+  TnParams tp = tn_zero();
+  tp.R = R; tp.M = M; tp.N = N; tp.A = A; tp.lda = lda; tp.B = Bm; tp.ldb = ldb;
+  return launch_tn<TA_PLAIN, TB_PLAIN>(tp, C, ldc, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
 }

@@ -1,0 +1,405 @@
+// HBM-bound passes of the training path (gfx950): BatchNorm-backward column statistics over stored
+// pre-activations, the layer-1 pair-grid reductions, the logits row-dot, loss + metrics, clip + Adam.
+// All are streaming kernels: 16-byte coalesced loads (one wave = 1 KiB of one row), per-thread register
+// accumulation, f64 atomics only once per thread at the end.
+#pragma once
+#include "gemm_engine.hpp"
+
+namespace pn {
+
+// ------------------------------------------------------------------------------------------------
+// BN-backward statistics for one layer.  With u = s*z + t, mask = u > 0, xhat = (z - mean)*invstd:
+//   S1[c] = sum_r du,  S2[c] = sum_r du*xhat,   du = g*mask   (g: matrix G[r][c], or gvec[r]*w[c])
+// and for the row-scalar form also dw[c] = sum_r gvec[r]*relu(u) (gradient of the output neuron).
+// ZK = 1: z is not stored but regenerated on the pair grid, z[r] = A[r % pairB] + B2[r / pairB].
+// grid: x = column slabs of 1024 (256 threads x float4), y = row chunks.
+// ------------------------------------------------------------------------------------------------
+struct StatsParams {
+  long R;
+  int C;
+  long rows_per_block;
+  const float* Z;
+  long ldz;
+  const float* G;
+  long ldg;
+  const float* gvec;
+  const float* w;  // row-scalar form: output-neuron weight
+  const float *s, *t, *mean, *invstd;
+  const float* A;  // pair-generated z
+  long lda;
+  const float* B2;
+  long ldb2;
+  int pairB;
+  double *S1, *S2, *dw;
+};
+
+template <int ROWG, int ZK>
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const StatsParams p) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= p.C) return;
+  const float4 s = ld4(p.s + c), t = ld4(p.t + c), mu = ld4(p.mean + c), is = ld4(p.invstd + c);
+  float4 w = make_float4(1, 1, 1, 1);
+  if constexpr (ROWG) w = ld4(p.w + c);
+  const long r0 = (long)blockIdx.y * p.rows_per_block;
+  long r1 = r0 + p.rows_per_block;
+  if (r1 > p.R) r1 = p.R;
+  double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
+  for (long rb = r0; rb < r1; rb += 128) {
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0};
+    const long re = (rb + 128 < r1) ? rb + 128 : r1;
+#pragma unroll 4
+    for (long r = rb; r < re; ++r) {
+      float4 z;
+      if constexpr (ZK) {
+        const long j = r / p.pairB;
+        const long i = r - j * p.pairB;
+        const float4 za = ld4(p.A + i * p.lda + c), zb = ld4(p.B2 + j * p.ldb2 + c);
+        z = make_float4(za.x + zb.x, za.y + zb.y, za.z + zb.z, za.w + zb.w);
+      } else {
+        z = ld4(p.Z + r * p.ldz + c);
+      }
+      float4 g;
+      if constexpr (ROWG) {
+        const float gr = p.gvec[r];
+        g = make_float4(gr * w.x, gr * w.y, gr * w.z, gr * w.w);
+        aw[0] += gr * relu(fmaf(z.x, s.x, t.x));
+        aw[1] += gr * relu(fmaf(z.y, s.y, t.y));
+        aw[2] += gr * relu(fmaf(z.z, s.z, t.z));
+        aw[3] += gr * relu(fmaf(z.w, s.w, t.w));
+      } else {
+        g = ld4(p.G + r * p.ldg + c);
+      }
+      const float u0 = fmaf(z.x, s.x, t.x) > 0.f ? g.x : 0.f;
+      const float u1 = fmaf(z.y, s.y, t.y) > 0.f ? g.y : 0.f;
+      const float u2 = fmaf(z.z, s.z, t.z) > 0.f ? g.z : 0.f;
+      const float u3 = fmaf(z.w, s.w, t.w) > 0.f ? g.w : 0.f;
+      a1[0] += u0;
+      a1[1] += u1;
+      a1[2] += u2;
+      a1[3] += u3;
+      a2[0] = fmaf(u0, (z.x - mu.x) * is.x, a2[0]);
+      a2[1] = fmaf(u1, (z.y - mu.y) * is.y, a2[1]);
+      a2[2] = fmaf(u2, (z.z - mu.z) * is.z, a2[2]);
+      a2[3] = fmaf(u3, (z.w - mu.w) * is.w, a2[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d1[k] += a1[k];
+      d2[k] += a2[k];
+      dw[k] += aw[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    atomicAdd(&p.S1[c + k], d1[k]);
+    atomicAdd(&p.S2[c + k], d2[k]);
+    if constexpr (ROWG) atomicAdd(&p.dw[c + k], dw[k]);
+  }
+}
+
+// From S1,S2: dgamma = S2, dbeta = S1 and the per-column vectors of the dz generator
+//   dz = (mask ? g*cs : 0) + p + q*z,   cs = s*(w or 1),  q = -s*invstd*S2/R,  p = -s*S1/R - q*mean
+// (s = gamma*invstd).  Without BatchNorm (gamma == nullptr): cs = (w or 1), p = q = 0, dbias = S1.
+__global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const double* dwacc, double count, int C,
+                                  const float* gamma, const float* s, const float* mean, const float* invstd,
+                                  const float* w, float* cs, float* pv, float* qv, float* dgamma, float* dbeta,
+                                  float* dw_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float wc = w ? w[c] : 1.f;
+  if (gamma != nullptr) {
+    const float sc = s[c];
+    const double c1 = S1[c] / count, c2 = S2[c] / count;
+    const float q = (float)(-(double)sc * (double)invstd[c] * c2);
+    cs[c] = sc * wc;
+    qv[c] = q;
+    pv[c] = (float)(-(double)sc * c1 - (double)q * (double)mean[c]);
+    if (dgamma) dgamma[c] = (float)S2[c];
+    if (dbeta) dbeta[c] = (float)S1[c];
+  } else {
+    cs[c] = wc;
+    qv[c] = 0.f;
+    pv[c] = 0.f;
+    if (dbeta) dbeta[c] = (float)S1[c];  // gradient of the Linear bias
+  }
+  if (dw_out && dwacc) dw_out[c] = (float)dwacc[c];
+}
+
+// BatchNorm (train) fold for the separable first pair layer: z1[i,j] = A[i] + Bm[j] over the full B x NL grid:
+// mean = mean_i(A) + mean_j(Bm), biased var = var_i(A) + var_j(Bm) (cross term vanishes on a full grid).
+__global__ void k_bn_fold_pair(pn_bn bn, const double* sumA, const double* sqA, double nA, const double* sumB,
+                               const double* sqB, double nB, float eps, float momentum, int C, float* s, float* t,
+                               float* mean_out, float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double ma = sumA[c] / nA, mb = sumB[c] / nB;
+  double va = sqA[c] / nA - ma * ma, vb = sqB[c] / nB - mb * mb;
+  if (va < 0) va = 0;
+  if (vb < 0) vb = 0;
+  const double mean = ma + mb, var = va + vb, count = nA * nB;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = bn.weight[c] * invstd;
+  s[c] = sc;
+  t[c] = bn.bias[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const double unb = count > 1 ? var * (count / (count - 1.0)) : var;
+  bn.running_mean[c] = (1.f - momentum) * bn.running_mean[c] + momentum * (float)mean;
+  bn.running_var[c] = (1.f - momentum) * bn.running_var[c] + momentum * (float)unb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer-1 reductions of dz1 over the pair grid (dz1 = (mask ? s*dh : 0) + p + q*z1, z1 = A[i] + Bm[j]):
+//   MODE 0: dBm[j][c] = sum_i dz1[i,j,c]   grid (C/1024, NL)   rows of one label are contiguous
+//   MODE 1: dA[i][c]  = sum_j dz1[i,j,c]   grid (C/1024, B)    stride-B rows, 1 KiB per wave per row
+// ------------------------------------------------------------------------------------------------
+struct PairRedParams {
+  int B, NL, C;
+  const float* DH;  // [NL*B][ldh], row r = j*B + i
+  long ldh;
+  const float* A;
+  long lda;
+  const float* Bm;
+  long ldb;
+  const float *s, *t, *cs, *p, *q;
+  float* out;
+  long ldo;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pair_reduce(const PairRedParams P) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= P.C) return;
+  const float4 s = ld4(P.s + c), t = ld4(P.t + c), cs = ld4(P.cs + c), pp = ld4(P.p + c), q = ld4(P.q + c);
+  const int fixed = blockIdx.y;
+  const int n = MODE == 0 ? P.B : P.NL;
+  float4 zf = MODE == 0 ? ld4(P.Bm + (long)fixed * P.ldb + c) : ld4(P.A + (long)fixed * P.lda + c);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  int cnt = 0;
+#pragma unroll 4
+  for (int k = 0; k < n; ++k) {
+    const long r = MODE == 0 ? (long)fixed * P.B + k : (long)k * P.B + fixed;
+    const float4 zv = MODE == 0 ? ld4(P.A + (long)k * P.lda + c) : ld4(P.Bm + (long)k * P.ldb + c);
+    const float4 g = ld4(P.DH + r * P.ldh + c);
+    const float z0 = zf.x + zv.x, z1 = zf.y + zv.y, z2 = zf.z + zv.z, z3 = zf.w + zv.w;
+    a0 += (fmaf(z0, s.x, t.x) > 0.f ? g.x * cs.x : 0.f) + fmaf(q.x, z0, pp.x);
+    a1 += (fmaf(z1, s.y, t.y) > 0.f ? g.y * cs.y : 0.f) + fmaf(q.y, z1, pp.y);
+    a2 += (fmaf(z2, s.z, t.z) > 0.f ? g.z * cs.z : 0.f) + fmaf(q.z, z2, pp.z);
+    a3 += (fmaf(z3, s.w, t.w) > 0.f ? g.w * cs.w : 0.f) + fmaf(q.w, z3, pp.w);
+    if (++cnt == 256) {
+      d0 += a0; d1 += a1; d2 += a2; d3 += a3;
+      a0 = a1 = a2 = a3 = 0.f;
+      cnt = 0;
+    }
+  }
+  d0 += a0; d1 += a1; d2 += a2; d3 += a3;
+  *reinterpret_cast<float4*>(P.out + (long)fixed * P.ldo + c) =
+      make_float4((float)d0, (float)d1, (float)d2, (float)d3);
+}
+
+// logits of the pair grid from the stored last pre-activation: out[r] = b + sum_c relu(s*z[r][c]+t) * w[c];
+// one wave per row.
+__global__ __launch_bounds__(256) void k_rowdot_rows(const float* __restrict__ Z, long ldz, long R, int C,
+                                                      const float* __restrict__ s, const float* __restrict__ t,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      float* __restrict__ out) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float a = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 z = ld4(Z + r * ldz + c), sv = ld4(s + c), tv = ld4(t + c), wv = ld4(w + c);
+    a = fmaf(relu(fmaf(z.x, sv.x, tv.x)), wv.x, a);
+    a = fmaf(relu(fmaf(z.y, sv.y, tv.y)), wv.y, a);
+    a = fmaf(relu(fmaf(z.z, sv.z, tv.z)), wv.z, a);
+    a = fmaf(relu(fmaf(z.w, sv.w, tv.w)), wv.w, a);
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[r] = a + b[0];
+}
+
+// dst[c][r] (ld = ldd) = src[r][c] (ld = lds); 32x32 LDS tiles
+__global__ void k_transpose(const float* __restrict__ src, long lds_, int rows, int cols, float* __restrict__ dst,
+                            long ldd) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < rows && c < cols) ? src[(long)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * ldd + r] = tile[tx][k];
+  }
+}
+
+// double accumulate of a float vector: out[0] += sum(x)
+__global__ void k_sum(const float* __restrict__ x, long n, double* out) {
+  double a = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a += x[i];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
+}
+
+__global__ void k_d2f(const double* in, float* out, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)(in[i] * (double)scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss forward + dL/dlogit + per-label TP/FN/FP in one pass over logits [B][N]
+//   (reference utils/losses.py:190-213,275-276 and ProtNoteTrainer.py:61-83)
+// kind 0: BCEWithLogits(pos_weight) mean; kind 1: focal (gamma, alpha < 0 = off, label smoothing) mean.
+// targets: f32 or i64 multihots.  grad is d(mean loss)/dlogit * grad_scale.
+// grid: x over columns (256 per block), y over row chunks; per-thread column accumulation.
+// ------------------------------------------------------------------------------------------------
+struct LossParams {
+  const float* logits;
+  const float* tf;     // float targets or null
+  const int64_t* ti;   // int64 targets or null
+  int B, N;
+  int kind;
+  float pos_weight, gamma, alpha, smoothing;
+  float threshold;     // on the probability
+  float grad_scale;    // 1/(B*N)
+  float* dlogits;      // [B][N] or null
+  double* loss_sum;    // scalar accumulator
+  float *tp, *fn, *fp; // [N] accumulators (+=) or null
+  int rows_per_block;
+};
+
+__device__ __forceinline__ float softplusf(float x) {  // log(1+exp(x)), stable
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void k_loss(const LossParams p) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.y * p.rows_per_block;
+  int i1 = i0 + p.rows_per_block;
+  if (i1 > p.B) i1 = p.B;
+  double lsum = 0;
+  float tp = 0.f, fn = 0.f, fp = 0.f;
+  if (j < p.N) {
+    for (int i = i0; i < i1; ++i) {
+      const long idx = (long)i * p.N + j;
+      const float x = p.logits[idx];
+      const float y = p.tf ? p.tf[idx] : (float)p.ti[idx];
+      float l, g;
+      const float sp_pos = softplusf(x);   // -log(1-sigmoid)
+      const float sp_neg = softplusf(-x);  // -log(sigmoid)
+      const float sig = 1.f / (1.f + expf(-x));
+      if (p.kind == 0) {
+        // torch BCEWithLogits: pw*y*softplus(-x) + (1-y)*softplus(x)
+        l = p.pos_weight * y * sp_neg + (1.f - y) * sp_pos;
+        g = (1.f - y) * sig - p.pos_weight * y * (1.f - sig);
+      } else {
+        const float ys = p.smoothing > 0.f ? y * (1.f - p.smoothing) + (1.f - y) * p.smoothing : y;
+        const float bce = ys * sp_neg + (1.f - ys) * sp_pos;
+        const float dbce = sig - ys;
+        const float pt = expf(-bce);
+        const float om = 1.f - pt;
+        float mod, dmod;  // (1-pt)^gamma and its derivative wrt bce: gamma*(1-pt)^(gamma-1)*pt
+        if (p.gamma == 2.f) {
+          mod = om * om;
+          dmod = 2.f * om * pt;
+        } else if (p.gamma == 0.f) {
+          mod = 1.f;
+          dmod = 0.f;
+        } else {
+          mod = powf(om, p.gamma);
+          dmod = om > 0.f ? p.gamma * powf(om, p.gamma - 1.f) * pt : 0.f;
+        }
+        l = mod * bce;
+        g = (dmod * bce + mod) * dbce;
+        if (p.alpha >= 0.f) {
+          const float at = p.alpha * ys + (1.f - p.alpha) * (1.f - ys);
+          l *= at;
+          g *= at;
+        }
+      }
+      lsum += (double)l;
+      if (p.dlogits) p.dlogits[idx] = g * p.grad_scale;
+      if (p.tp) {
+        const float pred = sig >= p.threshold ? 1.f : 0.f;
+        tp += pred * y;
+        fn += (1.f - pred) * y;
+        fp += pred * (1.f - y);
+      }
+    }
+    if (p.tp) {
+      atomicAdd(&p.tp[j], tp);
+      atomicAdd(&p.fn[j], fn);
+      atomicAdd(&p.fp[j], fp);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.loss_sum, lsum);
+}
+
+// calculate_tp_fn_fp on probabilities (ProtNoteTrainer.py:61-83): counts are integers held in f32
+__global__ __launch_bounds__(256) void k_tp_fn_fp(const float* __restrict__ probs, const float* tf, const int64_t* ti,
+                                                   int B, int N, float threshold, float* tp, float* fn, float* fp,
+                                                   int rows_per_block) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const int i0 = blockIdx.y * rows_per_block;
+  int i1 = i0 + rows_per_block;
+  if (i1 > B) i1 = B;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const long idx = (long)i * N + j;
+    const float y = tf ? tf[idx] : (float)ti[idx];
+    const float pred = probs[idx] >= threshold ? 1.f : 0.f;
+    a += pred * y;
+    b += (1.f - pred) * y;
+    c += pred * (1.f - y);
+  }
+  atomicAdd(&tp[j], a);
+  atomicAdd(&fn[j], b);
+  atomicAdd(&fp[j], c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam (ProtNoteTrainer.py:745-755) on flat f32 buffers
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sumsq(const float* __restrict__ g, long n, double* out) {
+  double a = 0;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = ld4(g + i);
+      a += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (long k = i; k < n; ++k) a += (double)g[k] * g[k];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
+}
+
+// coef = min(max_norm / (sqrt(sumsq) + 1e-6), 1)  (torch.nn.utils.clip_grad_norm_); max_norm <= 0: no clipping
+__global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       long n, const double* sumsq, float max_norm, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2_sqrt, float weight_decay, float* norm_out) {
+  float coef = 1.f;
+  const float norm = sumsq ? (float)sqrt(*sumsq) : 0.f;
+  if (sumsq && max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gi = g[i] * coef;
+    float wi = w[i];
+    if (weight_decay != 0.f) wi *= (1.f - lr * weight_decay);  // AdamW decoupled decay
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w[i] = wi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace pn

@@ -187,6 +187,12 @@ class ProtNote(nn.Module):
         del keep
         return y
 
+    def _train_chunk(self, B, NL):
+        """Labels per chunk of the backward ring (rows = chunk * B); ~64k pair rows by default."""
+        if self.pair_label_chunk:
+            return int(self.pair_label_chunk)
+        return max(1, min(NL, (64 * 1024) // max(B, 1)))
+
     def _auto_chunk(self, B, NL):
         if self.pair_label_chunk:
             return int(self.pair_label_chunk)

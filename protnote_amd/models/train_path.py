@@ -1,0 +1,186 @@
+"""Training-mode forward/backward of the ProtNote heads on MI355X (reference ProtNote.forward under
+model.train(), ProtNote.py:168-334, driven by ProtNoteTrainer.py:728-738).
+
+The autograd boundary is one torch.autograd.Function around the three trainable stacks (W_p, W_l,
+output_layer): forward and backward are sequences of C-ABI calls (pn_mlp_rows_fwd_train,
+pn_pairhead_fwd_train, pn_pairhead_bwd, pn_mlp_rows_bwd); torch only routes the returned gradient tensors.
+The frozen encoder runs under no_grad with train-mode BatchNorm exactly like the reference."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+def _flat_modules(seq):
+    out = []
+
+    def walk(m):
+        if isinstance(m, nn.Sequential):
+            for c in m:
+                walk(c)
+        else:
+            out.append(m)
+
+    walk(seq)
+    return out
+
+
+def _stack_params(layers):
+    """Canonical parameter order of a [(Linear, BN|None)] stack: lin.weight, [lin.bias], [bn.weight, bn.bias]."""
+    ps = []
+    for lin, bn in layers:
+        ps.append(lin.weight)
+        if lin.bias is not None:
+            ps.append(lin.bias)
+        if bn is not None:
+            ps += [bn.weight, bn.bias]
+    return ps
+
+
+def _save_buf(model, tag, nbytes, device):
+    cache = model.__dict__.setdefault("_pn_train_save", {})
+    buf = cache.get(tag)
+    if buf is None or buf.numel() < nbytes or buf.device != device:
+        cache.pop(tag, None)
+        buf = None
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        cache[tag] = buf
+    return buf
+
+
+class _HeadsTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, P_f, L_f, *params):
+        lib = L.lib()
+        dev = P_f.device
+        st = L.stream_ptr()
+        ctx.model = model
+        ctx.param_list = params
+        B, NL = P_f.shape[0], L_f.shape[0]
+        mp, lp = model._mlp_desc(model.W_p)
+        ml, ll = model._mlp_desc(model.W_l)
+        ctx.P_f, ctx.L_f = P_f, L_f
+
+        def mlp_fwd(m, x, tag):
+            rows = x.shape[0]
+            save = _save_buf(model, tag, lib.pn_mlp_rows_train_save_bytes(C.byref(m), rows), dev)
+            ws = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
+            y = torch.empty(rows, m.dims[m.nlayers], dtype=torch.float32, device=dev)
+            L.check(lib.pn_mlp_rows_fwd_train(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(y), L.ptr(save),
+                                              save.numel(), L.ptr(ws), ws.numel(), st))
+            return y
+
+        P_e = mlp_fwd(mp, P_f, "W_p")
+        L_e = mlp_fwd(ml, L_f, "W_l")
+        ctx.P_e, ctx.L_e = P_e, L_e
+        for _, bn in lp + ll:
+            if bn is not None:
+                bn.num_batches_tracked += 1
+
+        if model.feature_fusion == "similarity":
+            raise NotImplementedError("training with feature_fusion='similarity' is not implemented in protnote_amd")
+        hd, hl = model._pair_desc()
+        chunk = model._train_chunk(B, NL)
+        ctx.chunk = chunk
+        save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev)
+        ws = L.workspace(lib.pn_pairhead_train_ws_bytes(C.byref(hd), B, NL), dev, "train")
+        pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
+        L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
+                                          L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), st))
+        for _, bn in hl[:-1]:
+            if bn is not None:
+                bn.num_batches_tracked += 1
+        logits = torch.empty(B, NL, dtype=torch.float32, device=dev)
+        L.check(lib.pn_transpose(L.ptr(pairs), B, NL, B, L.ptr(logits), NL, st))
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        lib = L.lib()
+        st = L.stream_ptr()
+        P_f, L_f, P_e, L_e = ctx.P_f, ctx.L_f, ctx.P_e, ctx.L_e
+        dev = P_f.device
+        B, NL = P_f.shape[0], L_f.shape[0]
+        dlogits = dlogits.contiguous().float()
+        dl_pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
+        L.check(lib.pn_transpose(L.ptr(dlogits), NL, B, NL, L.ptr(dl_pairs), B, st))
+
+        grads = {}
+
+        def gbuf(p):
+            g = torch.empty_like(p, memory_format=torch.contiguous_format)
+            grads[id(p)] = g
+            return g.data_ptr()
+
+        # ---- pair head ----
+        hd, hl = model._pair_desc()
+        hidden, out = hl[:-1], hl[-1][0]
+        gr = L.pn_pairhead_grads()
+        for i, (lin, bn) in enumerate(hidden):
+            gr.dw[i] = gbuf(lin.weight)
+            if bn is not None:
+                gr.dgamma[i] = gbuf(bn.weight)
+                gr.dbeta[i] = gbuf(bn.bias)
+        gr.dw_out = gbuf(out.weight)
+        gr.db_out = gbuf(out.bias)
+        dP_e = torch.empty_like(P_e)
+        dL_e = torch.empty_like(L_e)
+        save = _save_buf(model, "pair", 0, dev)
+        ws = L.workspace(lib.pn_pairhead_train_ws_bytes(C.byref(hd), B, NL), dev, "train")
+        L.check(lib.pn_pairhead_bwd(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(dl_pairs), C.byref(gr),
+                                    L.ptr(dP_e), L.ptr(dL_e), ctx.chunk, L.ptr(save), save.numel(), L.ptr(ws),
+                                    ws.numel(), st))
+
+        # ---- projection heads ----
+        def mlp_bwd(seq, x, dy, tag):
+            m, layers = model._mlp_desc(seq)
+            g = L.pn_mlp_grads()
+            for i, (lin, bn) in enumerate(layers):
+                g.dw[i] = gbuf(lin.weight)
+                if bn is not None:
+                    g.dgamma[i] = gbuf(bn.weight)
+                    g.dbeta[i] = gbuf(bn.bias)
+            rows = x.shape[0]
+            sv = _save_buf(model, tag, 0, dev)
+            w = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
+            L.check(lib.pn_mlp_rows_bwd(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(dy), C.byref(g), None, L.ptr(sv),
+                                        sv.numel(), L.ptr(w), w.numel(), st))
+
+        mlp_bwd(model.W_p, P_f, dP_e, "W_p")
+        mlp_bwd(model.W_l, L_f, dL_e, "W_l")
+
+        outs = []
+        for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]):
+            outs.append(grads.get(id(p)) if need else None)
+        ctx.model = None
+        return (None, None, None, *outs)
+
+
+def head_parameters(model):
+    from .ProtNote import _split_layers
+
+    ps = _stack_params(_split_layers(model.W_p)) + _stack_params(_split_layers(model.W_l))
+    if model.feature_fusion.startswith("concatenation"):
+        ps += _stack_params(_split_layers(model.output_layer))
+    return ps
+
+
+def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths, L_f, label_token_counts):
+    """Reference ProtNote.forward in training mode (ProtNote.py:219-309)."""
+    with torch.no_grad():
+        L_f = L_f.detach().float().contiguous()
+        if label_token_counts is not None and model.label_embedding_noising_alpha > 0:
+            L_f = model._noised(L_f, torch.rand_like(L_f))
+        if sequence_embeddings is not None and not model.train_sequence_encoder:
+            P_f = sequence_embeddings.detach().float().contiguous()
+        elif sequence_onehots is not None and sequence_lengths is not None:
+            if model.train_sequence_encoder:
+                raise NotImplementedError("TRAIN_SEQUENCE_ENCODER=True is not implemented in protnote_amd")
+            P_f = model.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
+        else:
+            raise ValueError("Incompatible sequence parameters passed to forward method.")
+    L.require_hip(P_f, L_f)
+    return _HeadsTrainFn.apply(model, P_f, L_f, *head_parameters(model))

@@ -1,0 +1,160 @@
+"""GPU parity tests of the training path (train-mode BatchNorm over the pair grid, backward, fused loss,
+clip + Adam) against the reference-generated golden vectors and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import make_protnote, random_encoder_sd, random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_gemm_tn_vs_torch():
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(1)
+    for R, M, N in ((1000, 128, 128), (70001, 200, 52), (33, 4, 260), (5000, 3072, 128)):
+        A = torch.randn(R, M, generator=g)
+        Bm = torch.randn(R, N, generator=g) + torch.arange(N) * 0.01
+        ref = A.double().T @ Bm.double()
+        Ad, Bd = A.to(DEV), Bm.to(DEV)
+        Cd = torch.full((M, N), float("nan"), device=DEV)
+        ws = torch.empty(8 * M * N * 4 + 1024, dtype=torch.uint8, device=DEV)
+        L.check(L.lib().pn_gemm_tn(L.ptr(Ad), M, L.ptr(Bd), N, L.ptr(Cd), N, R, M, N, L.ptr(ws), ws.numel(),
+                                   L.stream_ptr()))
+        torch.cuda.synchronize()
+        err = (Cd.cpu().double() - ref).abs().max().item()
+        assert err <= 3e-6 * ref.abs().max().item() * max(1.0, R ** 0.5 / 8), (R, M, N, err)
+
+
+def test_fused_loss_and_metrics_golden(golden_dir):
+    from protnote_amd.utils.losses import BCEWithLogitsLoss, FocalLoss
+    from protnote_amd.models.ProtNoteTrainer import calculate_tp_fn_fp, calculate_f1, calculate_f1_micro
+
+    g = _g(golden_dir, "losses_metrics.npz")
+    logits = torch.from_numpy(g["logits"]).to(DEV)
+    y = torch.from_numpy(g["multihots"]).to(DEV)
+    cases = [("BCE", BCEWithLogitsLoss(pos_weight=float(g["BCE/pos_weight"]))),
+             ("BCE_pw", BCEWithLogitsLoss(pos_weight=torch.tensor(float(g["BCE_pw/pos_weight"]))))]
+    for name in ("Focal", "Focal_a", "Focal_ls"):
+        gamma, alpha, ls = (float(v) for v in g[name + "/params"])
+        cases.append((name, FocalLoss(alpha=alpha, gamma=gamma, label_smoothing=ls)))
+    for name, fn in cases:
+        for tgt in (y.float(), y):  # the trainer passes .float(); int64 multihots are accepted too
+            lg = logits.clone().requires_grad_(True)
+            l = fn(lg, tgt)
+            l.backward()
+            np.testing.assert_allclose(l.item(), float(g[name + "/loss"]), rtol=2e-6, err_msg=name)
+            np.testing.assert_allclose(lg.grad.cpu().numpy(), g[name + "/dlogits"], atol=2e-10, rtol=2e-5,
+                                       err_msg=name)
+    for th in (0.5, 0.3):
+        tp, fn_, fp = calculate_tp_fn_fp(torch.sigmoid(logits), y, threshold=th)
+        assert np.array_equal(tp.cpu().numpy(), g[f"th{th}/tp"])  # integer counts: bit-exact
+        assert np.array_equal(fn_.cpu().numpy(), g[f"th{th}/fn"])
+        assert np.array_equal(fp.cpu().numpy(), g[f"th{th}/fp"])
+        np.testing.assert_allclose(calculate_f1(tp, fn_, fp).cpu().numpy(), g[f"th{th}/f1"], rtol=1e-6)
+        np.testing.assert_allclose(calculate_f1_micro(tp, fn_, fp).cpu().numpy(), g[f"th{th}/f1_micro"], rtol=1e-6)
+
+
+def _freeze_encoder(model):
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+
+
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff"])
+@pytest.mark.parametrize("loss", ["BCE", "FocalLoss"])
+def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+    from protnote_amd.models.train_path import head_parameters
+
+    g = _g(golden_dir, f"protnote_small_{fusion}.npz")
+    model, _ = make_protnote(g, DEV)
+    _freeze_encoder(model)
+    model.train()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
+    y = torch.from_numpy(g["multihots"]).to(DEV)
+    u = torch.from_numpy(g["train/noise_u"]).to(DEV)
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    cfg = {"params": {"LOSS_FN": loss, "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1, "LABEL_SMOOTHING": 0.0}}
+    loss_fn = get_loss(cfg, bce_pos_weight=torch.tensor(1.0))
+    opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
+    logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, label_token_counts=cnt)
+    l = loss_fn(logits, y.float())
+    l.backward()
+    p = f"train_{loss}/"
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[p + "logits"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(l.item(), float(g[p + "loss"]), rtol=1e-4)
+    named = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith(p + "grad/"):
+            name = k[len(p + "grad/"):]
+            ref = g[k]
+            got = named[name].grad.cpu().numpy()
+            np.testing.assert_allclose(got, ref, atol=2e-5 + 2e-4 * np.abs(ref).max(), err_msg=name)
+    opt.step()
+    np.testing.assert_allclose(opt.last_grad_norm.item(), float(g[p + "grad_norm"]), rtol=2e-4)
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for k in g.files:
+        if k.startswith(p + "sd_after/"):
+            name = k[len(p + "sd_after/"):]
+            np.testing.assert_allclose(got[name], g[k], atol=3e-5, rtol=2e-4, err_msg=name)
+
+
+@pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 9, None)])
+def test_train_real_width_vs_oracle(B, NL, chunk):
+    """d=1024 / h=3072 / 3 hidden layers / 4-layer projection heads: logits, loss and every gradient of one
+    train-mode step against the oracle's autograd on the same seeded inputs."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(21)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    names = O.trainable_names(ref_sd)
+    leaves = {k: ref_sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(ref_sd)
+    work.update(leaves)
+    ref_logits = O.protnote_forward(work, None, None, lab, training=True, sequence_embeddings=P_f)
+    ref_loss = O.bce_loss(ref_logits, y)
+    ref_grads = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    model.pair_label_chunk = chunk
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    l = BCEWithLogitsLoss()(logits, y.to(DEV))
+    l.backward()
+    assert (logits.detach().cpu() - ref_logits.detach()).abs().max().item() < 5e-4
+    np.testing.assert_allclose(l.item(), ref_loss.item(), rtol=1e-4)
+    for name, p in model.named_parameters():
+        ref = ref_grads[name]
+        # ReLU masks of pre-activations within f32 rounding of 0 may flip between CPU and GPU summation
+        # orders; each flip is a rank-1 O(dl * h) perturbation, so compare in the Frobenius norm
+        # (plus a loose max-abs bound) rather than element-wise at 1e-4.
+        diff = p.grad.cpu().double() - ref.double()
+        rel = diff.norm().item() / max(ref.double().norm().item(), 1e-30)
+        assert rel < 2e-3, (name, rel)
+        assert diff.abs().max().item() <= 1e-6 + 5e-2 * ref.abs().max().item(), name
+    # BN running statistics after the train-mode forward
+    got = {k: v.cpu() for k, v in model.state_dict().items()}
+    for k, v in work.items():
+        if k.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got[k].numpy(), v.detach().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
