@@ -77,19 +77,20 @@ def synthetic_batch(B, L, NL, device, seed):
 
 
 def cpu_baseline(seconds_hint=20.0):
-    """Oracle train step (reference algorithm restated, f32, torch-CPU) on a bounded sample: B=4 proteins,
-    L=512, N_L=2048 labels, full-width model."""
+    """Oracle train step (reference algorithm restated, f32, torch-CPU) on a bounded sample of the same
+    workload: B=8 proteins, L=512, N_L=4096 labels, full-width model (~15-25 s of CPU work)."""
     from oracle import protnote_oracle as O
     from tests.helpers import random_encoder_sd, random_head_sd
 
-    cores = os.cpu_count() or 1
+    # torch-CPU GEMMs of this size stop scaling (and regress) far below a 256-thread host: cap the pool
+    cores = int(os.environ.get("PN_CPU_THREADS", min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(0)
     ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
                 num_resnet_blocks=5, bottleneck_factor=0.5)
     sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
     sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
-    B, L, NL = 4, 512, 2048
+    B, L, NL = 8, 512, 4096
     ids = torch.randint(0, 20, (B, L), generator=gen)
     x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
     lens = torch.full((B,), L, dtype=torch.int64)

@@ -67,6 +67,12 @@ struct GemmParams {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+// Make a fetched register quad opaque at this point of the program: the transform math that consumes it
+// cannot be hoisted above (DAG linearisation otherwise floats it in front of the MFMA block, dragging the
+// s_waitcnt vmcnt with it and exposing the global-load latency).
+__device__ __forceinline__ void pin4(float4& v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
 
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const GemmParams p) {
@@ -144,12 +150,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   float4 ra[NQA], ra2[NQA], rb[NQB];
   float4 rsc = make_float4(0, 0, 0, 0), rsh = make_float4(0, 0, 0, 0);
   float4 rcs = make_float4(0, 0, 0, 0), rp = make_float4(0, 0, 0, 0), rq = make_float4(0, 0, 0, 0);
-  unsigned avalid = 0;
+  unsigned avalid = 0, bmask = 0;
 
+  // fetch(): branch-free - every load is issued unconditionally from a clamped (always valid) address and
+  // invalid lanes are zeroed by selects in commit(), so the loads of slab s+1 stay in flight under the
+  // MFMAs of slab s (a predicated load would put an s_waitcnt vmcnt(0) in front of the MFMA block).
   auto fetch = [&](int s) {
     const int seg = s / spt;
     const int c = (s - seg * spt) * BK + 4 * kv;
     const bool kok = c < p.Kseg;
+    const int cc = kok ? c : 0;
     avalid = 0;
     if constexpr (AK == A_CONV) {
       const int sh = (seg - p.nseg / 2) * p.dil;
@@ -157,39 +167,40 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
       for (int q = 0; q < NQA; ++q) {
         const int tt = a_t[q] + sh;
         const bool ok = kok && (a_t[q] < a_len[q]) && (tt >= 0) && (tt < a_len[q]);
-        ra[q] = ok ? ld4(arow[q] + (long)sh * p.lda + c) : make_float4(0, 0, 0, 0);
+        ra[q] = ld4(arow[q] + (long)(ok ? sh : 0) * p.lda + cc);
         avalid |= (ok ? 1u : 0u) << q;
       }
-      if (conv_affine && kok) {
-        rsc = ld4(p.a_scale + c);
-        rsh = ld4(p.a_shift + c);
+      if (conv_affine) {
+        rsc = ld4(p.a_scale + cc);
+        rsh = ld4(p.a_shift + cc);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < NQA; ++q) {
-        ra[q] = kok ? ld4(arow[q] + c) : make_float4(0, 0, 0, 0);
-        if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM)
-          ra2[q] = kok ? ld4(arow2[q] + c) : make_float4(0, 0, 0, 0);
+        ra[q] = ld4(arow[q] + cc);
+        if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM) ra2[q] = ld4(arow2[q] + cc);
       }
       avalid = kok ? 0xffffffffu : 0u;
       if constexpr (AK == A_AFFINE_RELU || AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
-        if (kok) {
-          rsc = ld4(p.a_scale + c);
-          rsh = ld4(p.a_shift + c);
-        }
+        rsc = ld4(p.a_scale + cc);
+        rsh = ld4(p.a_shift + cc);
       }
       if constexpr (AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
-        if (kok) {
-          rcs = ld4(p.dz_cs + c);
-          rp = ld4(p.dz_p + c);
-          rq = ld4(p.dz_q + c);
-        }
+        rcs = ld4(p.dz_cs + cc);
+        rp = ld4(p.dz_p + cc);
+        rq = ld4(p.dz_q + cc);
       }
     }
+    bmask = 0;
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
-      rb[q] = (kok && bvalid[q]) ? ld4(brow[q] + (long)seg * p.Kseg + c) : make_float4(0, 0, 0, 0);
+      rb[q] = ld4(brow[q] + (long)seg * p.Kseg + cc);
+      bmask |= ((kok && bvalid[q]) ? 1u : 0u) << q;
     }
+  };
+
+  auto sel4 = [](bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
   auto commit = [&](int buf) {
@@ -197,43 +208,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     float* Bs = As + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
+      pin4(ra[q]);
+      if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM) pin4(ra2[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) pin4(rb[q]);
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) {
       float4 v = ra[q];
       const bool ok = (avalid >> q) & 1u;
       if constexpr (AK == A_AFFINE_RELU) {
-        if (ok) {
-          v.x = relu(fmaf(v.x, rsc.x, rsh.x));
-          v.y = relu(fmaf(v.y, rsc.y, rsh.y));
-          v.z = relu(fmaf(v.z, rsc.z, rsh.z));
-          v.w = relu(fmaf(v.w, rsc.w, rsh.w));
-        }
+        v.x = relu(fmaf(v.x, rsc.x, rsh.x));
+        v.y = relu(fmaf(v.y, rsc.y, rsh.y));
+        v.z = relu(fmaf(v.z, rsc.z, rsh.z));
+        v.w = relu(fmaf(v.w, rsc.w, rsh.w));
       } else if constexpr (AK == A_PAIRSUM_RELU) {
         v.x = relu(v.x + ra2[q].x);
         v.y = relu(v.y + ra2[q].y);
         v.z = relu(v.z + ra2[q].z);
         v.w = relu(v.w + ra2[q].w);
       } else if constexpr (AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
-        if (ok) {
-          float4 g;
-          if constexpr (AK == A_DZ_ELEM) g = ra2[q];
-          else g = make_float4(a_g[q], a_g[q], a_g[q], a_g[q]);
-          v.x = (fmaf(v.x, rsc.x, rsh.x) > 0.f ? g.x * rcs.x : 0.f) + fmaf(rq.x, v.x, rp.x);
-          v.y = (fmaf(v.y, rsc.y, rsh.y) > 0.f ? g.y * rcs.y : 0.f) + fmaf(rq.y, v.y, rp.y);
-          v.z = (fmaf(v.z, rsc.z, rsh.z) > 0.f ? g.z * rcs.z : 0.f) + fmaf(rq.z, v.z, rp.z);
-          v.w = (fmaf(v.w, rsc.w, rsh.w) > 0.f ? g.w * rcs.w : 0.f) + fmaf(rq.w, v.w, rp.w);
-        }
+        float4 g;
+        if constexpr (AK == A_DZ_ELEM) g = ra2[q];
+        else g = make_float4(a_g[q], a_g[q], a_g[q], a_g[q]);
+        v.x = (fmaf(v.x, rsc.x, rsh.x) > 0.f ? g.x * rcs.x : 0.f) + fmaf(rq.x, v.x, rp.x);
+        v.y = (fmaf(v.y, rsc.y, rsh.y) > 0.f ? g.y * rcs.y : 0.f) + fmaf(rq.y, v.y, rp.y);
+        v.z = (fmaf(v.z, rsc.z, rsh.z) > 0.f ? g.z * rcs.z : 0.f) + fmaf(rq.z, v.z, rp.z);
+        v.w = (fmaf(v.w, rsc.w, rsh.w) > 0.f ? g.w * rcs.w : 0.f) + fmaf(rq.w, v.w, rp.w);
       } else if constexpr (AK == A_CONV) {
-        if (conv_affine && ok) {
+        if (conv_affine) {
           v.x = relu(fmaf(v.x, rsc.x, rsh.x));
           v.y = relu(fmaf(v.y, rsc.y, rsh.y));
           v.z = relu(fmaf(v.z, rsc.z, rsh.z));
           v.w = relu(fmaf(v.w, rsc.w, rsh.w));
         }
       }
-      *reinterpret_cast<float4*>(As + (r_in + q * RPP) * LDK + 4 * kv) = v;
+      *reinterpret_cast<float4*>(As + (r_in + q * RPP) * LDK + 4 * kv) = sel4(ok, v);
     }
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
-      *reinterpret_cast<float4*>(Bs + (r_in + q * RPP) * LDK + 4 * kv) = rb[q];
+      *reinterpret_cast<float4*>(Bs + (r_in + q * RPP) * LDK + 4 * kv) = sel4((bmask >> q) & 1u, rb[q]);
     }
   };
 
@@ -274,13 +288,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   fetch(0);
   commit(0);
   __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
+  for (int s = 0; s + 1 < nslab; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nslab) fetch(s + 1);
-    compute(cur);
-    if (s + 1 < nslab) commit(cur ^ 1);
+    fetch(s + 1);  // global loads of the next slab are issued first ...
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur);  // ... stay in flight under this slab's 64 MFMAs ...
+    __builtin_amdgcn_sched_barrier(0);
+    commit(cur ^ 1);  // ... and are only waited for here (hipcc would otherwise sink them next to the wait)
     __syncthreads();
   }
+  compute((nslab - 1) & 1);
+  __syncthreads();
 
   // ---------------- epilogue ----------------
   const int hl = lane >> 5;  // which 4-row group of each 8

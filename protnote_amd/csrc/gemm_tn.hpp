@@ -94,29 +94,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
   unsigned rowok = 0;
 
+  // branch-free fetch: rows past the split end are clamped to a valid row and zeroed by selects in commit()
+  const long r_last = (r_end > 0 ? r_end : 1) - 1;
+  const int amc = a_ok ? am : 0, bnc = b_ok ? bn : 0;
   auto fetch = [&](long k0) {
     rowok = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const long r = k0 + rr + 8 * q;
+      long r = k0 + rr + 8 * q;
       const bool ok = r < r_end;
       rowok |= (ok ? 1u : 0u) << q;
-      const float4 z4 = make_float4(0, 0, 0, 0);
-      ra[q] = (ok && a_ok) ? ld4(p.A + r * p.lda + am) : z4;
-      if constexpr (TA == TA_DZ_ELEM) rg[q] = (ok && a_ok) ? ld4(p.G + r * p.ldg + am) : z4;
+      r = ok ? r : r_last;
+      ra[q] = ld4(p.A + r * p.lda + amc);
+      if constexpr (TA == TA_DZ_ELEM) rg[q] = ld4(p.G + r * p.ldg + amc);
       if constexpr (TA == TA_DZ_ROWG) {
-        const float g = ok ? p.gvec[r] : 0.f;
+        const float g = p.gvec[r];
         rg[q] = make_float4(g, g, g, g);
       }
       if constexpr (TB == TB_PAIRSUM_RELU) {
-        const long j = r / p.pairB;
-        const long i = r - j * p.pairB;
-        rb[q] = (ok && b_ok) ? ld4(p.B + i * p.ldb + bn) : z4;
-        rb2[q] = (ok && b_ok) ? ld4(p.B2 + j * p.ldb2 + bn) : z4;
+        const unsigned ru = (unsigned)r;  // pair grid < 2^31 rows
+        const unsigned j = ru / (unsigned)p.pairB;
+        const unsigned i = ru - j * (unsigned)p.pairB;
+        rb[q] = ld4(p.B + (long)i * p.ldb + bnc);
+        rb2[q] = ld4(p.B2 + (long)j * p.ldb2 + bnc);
       } else {
-        rb[q] = (ok && b_ok) ? ld4(p.B + r * p.ldb + bn) : z4;
+        rb[q] = ld4(p.B + r * p.ldb + bnc);
       }
     }
+  };
+
+  auto sel4 = [](bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
   auto commit = [&](int buf) {
@@ -124,33 +132,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     float* Bs = As + BK * LDM;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      pin4(ra[q]);
+      pin4(rb[q]);
+      if constexpr (TA != TA_PLAIN) pin4(rg[q]);
+      if constexpr (TB == TB_PAIRSUM_RELU) pin4(rb2[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
       const bool ok = (rowok >> q) & 1u;
       float4 a = ra[q];
       if constexpr (TA != TA_PLAIN) {
-        if (ok && a_ok) {
-          const float4 g = rg[q];
-          a.x = (fmaf(a.x, ms.x, mt.x) > 0.f ? g.x * mcs.x : 0.f) + fmaf(mq.x, a.x, mp.x);
-          a.y = (fmaf(a.y, ms.y, mt.y) > 0.f ? g.y * mcs.y : 0.f) + fmaf(mq.y, a.y, mp.y);
-          a.z = (fmaf(a.z, ms.z, mt.z) > 0.f ? g.z * mcs.z : 0.f) + fmaf(mq.z, a.z, mp.z);
-          a.w = (fmaf(a.w, ms.w, mt.w) > 0.f ? g.w * mcs.w : 0.f) + fmaf(mq.w, a.w, mp.w);
-        }
+        const float4 g = rg[q];
+        a.x = (fmaf(a.x, ms.x, mt.x) > 0.f ? g.x * mcs.x : 0.f) + fmaf(mq.x, a.x, mp.x);
+        a.y = (fmaf(a.y, ms.y, mt.y) > 0.f ? g.y * mcs.y : 0.f) + fmaf(mq.y, a.y, mp.y);
+        a.z = (fmaf(a.z, ms.z, mt.z) > 0.f ? g.z * mcs.z : 0.f) + fmaf(mq.z, a.z, mp.z);
+        a.w = (fmaf(a.w, ms.w, mt.w) > 0.f ? g.w * mcs.w : 0.f) + fmaf(mq.w, a.w, mp.w);
       }
       float4 b = rb[q];
       if constexpr (TB == TB_AFFINE_RELU) {
-        if (ok && b_ok) {
-          b.x = relu(fmaf(b.x, bs.x, bt.x));
-          b.y = relu(fmaf(b.y, bs.y, bt.y));
-          b.z = relu(fmaf(b.z, bs.z, bt.z));
-          b.w = relu(fmaf(b.w, bs.w, bt.w));
-        }
+        b.x = relu(fmaf(b.x, bs.x, bt.x));
+        b.y = relu(fmaf(b.y, bs.y, bt.y));
+        b.z = relu(fmaf(b.z, bs.z, bt.z));
+        b.w = relu(fmaf(b.w, bs.w, bt.w));
       } else if constexpr (TB == TB_PAIRSUM_RELU) {
         b.x = relu(b.x + rb2[q].x);
         b.y = relu(b.y + rb2[q].y);
         b.z = relu(b.z + rb2[q].z);
         b.w = relu(b.w + rb2[q].w);
       }
-      *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = a;
-      *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = b;
+      *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = sel4(ok && a_ok, a);
+      *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = sel4(ok && b_ok, b);
     }
   };
 
@@ -165,17 +176,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   const int fcol = lane & 31;
   const int fk = lane >> 5;
 
+  // Fragment reads are 8-byte: lane l takes columns (2l, 2l+1) of k-row fk, i.e. MFMA tile 0 of a wave owns the
+  // even and tile 1 the odd columns of its 64-wide strip (un-permuted in the epilogue).  The fragments of
+  // k-pair kk+1 are read before the MFMAs of k-pair kk so the LDS latency sits under the matrix pipe.
   auto compute = [&](int buf) {
-    const float* As = smem + buf * STAGE + fk * LDM + wm * 64 + fcol;
-    const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 + fcol;
+    const float* As = smem + buf * STAGE + fk * LDM + wm * 64 + 2 * fcol;
+    const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 + 2 * fcol;
+    float2 a = *reinterpret_cast<const float2*>(As);
+    float2 b = *reinterpret_cast<const float2*>(Bs);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a0 = As[(2 * kk) * LDM], a1 = As[(2 * kk) * LDM + 32];
-      const float b0 = Bs[(2 * kk) * LDN], b1 = Bs[(2 * kk) * LDN + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float2 na = a, nb = b;
+      if (kk + 1 < BK / 2) {
+        na = *reinterpret_cast<const float2*>(As + (2 * kk + 2) * LDM);
+        nb = *reinterpret_cast<const float2*>(Bs + (2 * kk + 2) * LDN);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+      a = na;
+      b = nb;
     }
   };
 
@@ -184,29 +205,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     commit(0);
     __syncthreads();
     int cur = 0;
-    for (long k0 = r_begin; k0 < r_end; k0 += BK) {
-      const bool more = (k0 + BK) < r_end;
-      if (more) fetch(k0 + BK);
+    long k0 = r_begin;
+    for (; k0 + BK < r_end; k0 += BK) {
+      fetch(k0 + BK);
+      __builtin_amdgcn_sched_barrier(0);
       compute(cur);
-      if (more) commit(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      commit(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
+    compute(cur);
   }
 
   float* out = p.Cpart + (long)split * p.M * p.ldc;
   const int hl = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wn * 64 + 2 * fcol;  // columns n, n+1 <- tiles j = 0, 1
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + fcol;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        if (m < p.M && n < p.N) out[(long)m * p.ldc + n] = acc[i][j][e];
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * hl) + i;
+      if (m < p.M && n < p.N)  // N is a multiple of 4 and n is even: n + 1 < N as well
+        *reinterpret_cast<float2*>(out + (long)m * p.ldc + n) = make_float2(acc[i][0][e], acc[i][1][e]);
     }
+  }
 }
 
 constexpr int TN_LDS_BYTES = 2 * 32 * (132 + 132) * (int)sizeof(float);

@@ -188,10 +188,11 @@ class ProtNote(nn.Module):
         return y
 
     def _train_chunk(self, B, NL):
-        """Labels per chunk of the backward ring (rows = chunk * B); ~64k pair rows by default."""
+        """Labels per chunk of the backward ring (rows = chunk * B); ~256k pair rows by default (each chunk is one
+        GEMM launch of ~49k workgroups, so launch tails are <1 %; costs one chunk of slack per stored layer)."""
         if self.pair_label_chunk:
             return int(self.pair_label_chunk)
-        return max(1, min(NL, (64 * 1024) // max(B, 1)))
+        return max(1, min(NL, (256 * 1024) // max(B, 1)))
 
     def _auto_chunk(self, B, NL):
         if self.pair_label_chunk:

@@ -112,7 +112,7 @@ def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
             np.testing.assert_allclose(got[name], g[k], atol=3e-5, rtol=2e-4, err_msg=name)
 
 
-@pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 9, None)])
+@pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 40, 7), (8, 9, None)])
 def test_train_real_width_vs_oracle(B, NL, chunk):
     """d=1024 / h=3072 / 3 hidden layers / 4-layer projection heads: logits, loss and every gradient of one
     train-mode step against the oracle's autograd on the same seeded inputs."""
@@ -125,14 +125,19 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
     lab = torch.randn(NL, 1024, generator=gen)
     y = (torch.rand(B, NL, generator=gen) < 0.2).float()
 
-    ref_sd = {k: v.clone() for k, v in sd.items()}
-    names = O.trainable_names(ref_sd)
-    leaves = {k: ref_sd[k].clone().requires_grad_(True) for k in names}
-    work = dict(ref_sd)
-    work.update(leaves)
-    ref_logits = O.protnote_forward(work, None, None, lab, training=True, sequence_embeddings=P_f)
-    ref_loss = O.bce_loss(ref_logits, y)
-    ref_grads = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+    def oracle(dtype):
+        ref_sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        names = O.trainable_names(ref_sd)
+        leaves = {k: ref_sd[k].clone().requires_grad_(True) for k in names}
+        work = dict(ref_sd)
+        work.update(leaves)
+        lg = O.protnote_forward(work, None, None, lab.to(dtype), training=True, sequence_embeddings=P_f.to(dtype))
+        ls = O.bce_loss(lg, y.to(dtype))
+        return lg.detach(), ls.detach(), dict(zip(names, torch.autograd.grad(ls, [leaves[k] for k in names]))), work
+
+    # ground truth in f64; the reference's own f32 CPU path gives the error scale to hold the GPU to
+    ref_logits, ref_loss, ref_grads, work = oracle(torch.float64)
+    _, _, cpu32_grads, _ = oracle(torch.float32)
 
     model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
                      projection_head_hidden_dim_scale_factor=3)
@@ -142,19 +147,21 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
     logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
     l = BCEWithLogitsLoss()(logits, y.to(DEV))
     l.backward()
-    assert (logits.detach().cpu() - ref_logits.detach()).abs().max().item() < 5e-4
+    assert (logits.detach().cpu().double() - ref_logits).abs().max().item() < 5e-4
     np.testing.assert_allclose(l.item(), ref_loss.item(), rtol=1e-4)
     for name, p in model.named_parameters():
         ref = ref_grads[name]
-        # ReLU masks of pre-activations within f32 rounding of 0 may flip between CPU and GPU summation
-        # orders; each flip is a rank-1 O(dl * h) perturbation, so compare in the Frobenius norm
-        # (plus a loose max-abs bound) rather than element-wise at 1e-4.
-        diff = p.grad.cpu().double() - ref.double()
-        rel = diff.norm().item() / max(ref.double().norm().item(), 1e-30)
-        assert rel < 2e-3, (name, rel)
-        assert diff.abs().max().item() <= 1e-6 + 5e-2 * ref.abs().max().item(), name
+        # ReLU masks of pre-activations within f32 rounding of 0 flip under any change of summation order (each
+        # flip is a rank-1 O(dl*h) change) and every gradient inherits the ~1e-4 abs error of the f32 logits
+        # through dl = sigmoid(x) - y, so element-wise 1e-4 is not meaningful for gradients on large pair grids
+        # (the reference's own f32 CPU path is 5e-4..2e-3 away from f64 at B >= 128; measured, tools/debug_grad.py).
+        # Require the GPU's Frobenius error vs f64 to be of the same class as the f32 CPU path's.
+        nrm = max(ref.norm().item(), 1e-30)
+        rel = (p.grad.cpu().double() - ref).norm().item() / nrm
+        rel_cpu = (cpu32_grads[name].double() - ref).norm().item() / nrm
+        assert rel < max(8 * rel_cpu, 5e-4) and rel < 1e-2, (name, rel, rel_cpu)
     # BN running statistics after the train-mode forward
     got = {k: v.cpu() for k, v in model.state_dict().items()}
     for k, v in work.items():
         if k.endswith(("running_mean", "running_var")):
-            np.testing.assert_allclose(got[k].numpy(), v.detach().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
+            np.testing.assert_allclose(got[k].numpy(), v.detach().float().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
