@@ -1,0 +1,60 @@
+"""Batch assembly with the layout contract of protnote/data/collators.py::collate_variable_sequence_length
+(reference :5-155): right-pad one-hots with zeros to the batch maximum, stack lengths / multihots, take label
+embeddings and token counts from batch[0] only, optional label sub-sampling (randperm / arange / in-batch /
+grid / per-rank partition).  The produced dict is exactly what ProtNote.forward / the trainer consume:
+
+    sequence_onehots [B, A, Lmax] f32 | sequence_ids list[str] | sequence_lengths [B] i64
+    label_embeddings [N, d] f32       | label_token_counts [N] i64 | label_multihots [B, N] i64
+"""
+from typing import Dict, List
+
+import torch
+
+
+def sample_label_indices(batch: List[Dict], label_sample_size=None, distribute_labels=False, shuffle_labels=False,
+                         in_batch_sampling=False, grid_sampler=False, world_size=1, rank=0):
+    """Index selection of reference collators.py:56-98 (None = keep every label)."""
+    if grid_sampler:
+        assert label_sample_size is not None, "Must provide label_sample_size if using grid sampler"
+        assert not in_batch_sampling, "Can't use in batch sampling with grid sampler"
+    else:
+        assert not (in_batch_sampling and (label_sample_size is not None)), \
+            "Cant use both in_batch_sampling with lable_sample_size"
+    num_labels = batch[0]["label_multihots"].shape[0]
+    if label_sample_size:
+        if grid_sampler:
+            return batch[0]["label_idxs"]
+        if not distribute_labels:
+            return torch.randperm(num_labels)[:label_sample_size] if shuffle_labels else torch.arange(label_sample_size)
+        per_part = num_labels // world_size
+        part = torch.arange(rank * per_part, rank * per_part + per_part)
+        return part[torch.randperm(len(part))[: label_sample_size // world_size]]
+    if in_batch_sampling:
+        return torch.where(sum(row["label_multihots"] for row in batch) > 0)[0]
+    return None
+
+
+def collate_variable_sequence_length(batch: List[Dict], label_sample_size=None, distribute_labels=False,
+                                     shuffle_labels=False, in_batch_sampling=False, grid_sampler=False,
+                                     return_label_multihots=True, world_size=1, rank=0):
+    max_length = int(max(int(row["sequence_length"]) for row in batch))
+    idx = sample_label_indices(batch, label_sample_size, distribute_labels, shuffle_labels, in_batch_sampling,
+                               grid_sampler, world_size, rank)
+    first = batch[0]
+    label_embeddings = first["label_embeddings"] if idx is None else first["label_embeddings"][idx]
+    dim = first["sequence_onehots"].shape[0]
+    onehots = torch.zeros(len(batch), dim, max_length, dtype=torch.float32)
+    for b, row in enumerate(batch):
+        n = int(row["sequence_length"])
+        onehots[b, :, :n] = row["sequence_onehots"]
+    out = {
+        "sequence_onehots": onehots,
+        "sequence_ids": [row["sequence_id"] for row in batch],
+        "sequence_lengths": torch.stack([torch.as_tensor(row["sequence_length"]) for row in batch]),
+        "label_embeddings": label_embeddings,
+        "label_token_counts": first["label_token_counts"],
+    }
+    if return_label_multihots:
+        out["label_multihots"] = torch.stack(
+            [row["label_multihots"] if idx is None else row["label_multihots"][idx] for row in batch])
+    return out

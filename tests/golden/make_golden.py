@@ -15,6 +15,8 @@ What is executed (all f32, CPU, torch.manual_seed fixed):
                                          body of the train step (:728-755): loss -> backward ->
                                          clip_grad_norm_(1.0) -> Adam(lr=3e-4).step()
   * protnote/data/collators.py           collate_variable_sequence_length
+  * protnote/data/datasets.py            ProteinDataset label-index bookkeeping on a toy FASTA (vocabularies,
+                                         multihots, embedding-row filter/sort/sample) - integer, bit-exact
 
 Absent third-party modules that are NOT on the arithmetic path are stubbed in sys.modules.
 torchvision.ops.MLP (pinned torchvision==0.15.2 in the reference's setup.py:17) is absent from this
@@ -355,10 +357,105 @@ def golden_collator():
     print("collator.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
 
 
+
+
+# --------------------------------------------------------------------------------------------
+def golden_bookkeeping():
+    """Label-index bookkeeping of protnote/data/datasets.py::ProteinDataset (INT, must be bit-exact):
+    vocabularies, label2int, multihots, embedding-row filter, min/max index per label, sorted / sampled
+    embedding rows.  Runs the reference Dataset on a tiny FASTA + embedding index written to a temp dir."""
+    import logging
+    import tempfile
+
+    import pandas as pd
+    import Bio.SeqIO as SeqIO
+
+    class _Rec:
+        def __init__(self, desc, seq):
+            self.description, self.seq = desc, seq
+
+    def _parse(path, fmt):
+        desc, seq = None, []
+        for line in open(path):
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if desc is not None:
+                    yield _Rec(desc, "".join(seq))
+                desc, seq = line[1:], []
+            elif line:
+                seq.append(line)
+        if desc is not None:
+            yield _Rec(desc, "".join(seq))
+
+    SeqIO.parse = _parse
+    from protnote.data.datasets import ProteinDataset
+
+    fasta = [("P3", "MKTAYIAKQR", ["GO:0003", "GO:0001"]),
+             ("P1", "ACDEFGHIKLMNPQRSTVWY", ["GO:0002"]),
+             ("P2", "MKTAYIAKQR", ["GO:0009"]),           # duplicate sequence -> dropped by DEDUPLICATE
+             ("P4", "GGSGGS", ["GO:0001", "GO:0004", "GO:0002"]),
+             ("P5", "WWYV", ["GO:0004"])]
+    rows = []
+    for gid in ["GO:0004", "GO:0001", "GO:0007", "GO:0002", "GO:0003"]:      # deliberately unsorted, with an unused id
+        for dt in ["name", "label", "synonym_exact", "synonym_exact"]:
+            rows.append({"id": gid, "description_type": dt, "description": f"{gid}-{dt}-{len(rows)}",
+                         "token_count": 3 + len(rows) % 7})
+    index = pd.DataFrame(rows)
+    emb = torch.arange(len(rows), dtype=torch.float32)[:, None].repeat(1, 4) + 0.25
+    out = {"fasta_ids": np.array([f[0] for f in fasta]), "fasta_seqs": np.array([f[1] for f in fasta]),
+           "fasta_labels": np.array([" ".join(f[2]) for f in fasta]),
+           "index_id": index["id"].values.astype(str), "index_type": index["description_type"].values.astype(str),
+           "index_token_count": index["token_count"].values, "embeddings": emb.numpy()}
+    real_load = torch.load
+    torch.load = lambda *a, **k: real_load(*a, **{**k, "weights_only": False})
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fp = os.path.join(d, "toy.fasta")
+            with open(fp, "w") as f:
+                for sid, seq, labs in fasta:
+                    f.write(">" + " ".join([sid] + labs) + "\n" + seq + "\n")
+            ep = os.path.join(d, "emb.pt")
+            torch.save(emb, ep)
+            torch.save(index, os.path.join(d, "emb_index.pt"))
+            for dtype, aug in (("test", "name+label"), ("train", "name+label+synonym_exact")):
+                cfg = {"params": {"AUGMENT_RESIDUE_PROBABILITY": 0.0, "LABEL_AUGMENTATION_DESCRIPTIONS": aug,
+                                  "TRAIN_SUBSET_FRACTION": 1, "TEST_SUBSET_FRACTION": 1, "VALIDATION_SUBSET_FRACTION": 1,
+                                  "INFERENCE_GO_DESCRIPTIONS": "name+label", "EXTRACT_VOCABULARIES_FROM": None,
+                                  "DEDUPLICATE": True, "MAX_SEQUENCE_LENGTH": 15},
+                       "paths": {}, "LABEL_EMBEDDING_PATH": ep}
+                ds = ProteinDataset({"data_path": fp, "dataset_type": dtype}, cfg, logger=logging.getLogger("g"))
+                p = dtype + "/"
+                out[p + "kept_ids"] = np.array([r[1] for r in ds.data])
+                out[p + "label_vocabulary"] = np.array(ds.label_vocabulary)
+                out[p + "amino_acid_vocabulary"] = np.array(ds.amino_acid_vocabulary)
+                out[p + "represented_vocabulary_mask"] = np.array(ds.represented_vocabulary_mask)
+                out[p + "filtered_rows"] = (ds.label_embeddings[:, 0] - 0.25).long().numpy()   # original row ids
+                out[p + "min_idx"] = np.array([ds.label_embeddings_index[g]["min_idx"] for g in ds.label_vocabulary])
+                out[p + "max_idx"] = np.array([ds.label_embeddings_index[g]["max_idx"] for g in ds.label_vocabulary])
+                out[p + "sorted_rows"] = (ds.sorted_label_embeddings[:, 0] - 0.25).long().numpy()
+                out[p + "sorted_token_counts"] = np.asarray(ds.sorted_label_token_counts)
+                np.random.seed(123)
+                se, sc = ds._sample_label_embeddings()
+                out[p + "sampled_rows_seed123"] = (se[:, 0] - 0.25).long().numpy()
+                out[p + "sampled_token_counts_seed123"] = np.asarray(sc)
+                for i in range(len(ds)):
+                    seq, sid, labs = ds.data[i]
+                    ex = ds.process_example(seq, sid, labs)
+                    out[p + f"ex{i}/onehots"] = ex["sequence_onehots"].numpy()
+                    out[p + f"ex{i}/multihots"] = ex["label_multihots"].numpy()
+                    out[p + f"ex{i}/length"] = ex["sequence_length"].numpy()
+    finally:
+        torch.load = real_load
+    np.savez_compressed(os.path.join(OUT, "bookkeeping.npz"), **out)
+    print("bookkeeping.npz", [k for k in out if k.startswith("test/") and "ex" not in k])
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
-    golden_encoder()
-    golden_protnote()
-    golden_losses_metrics()
-    golden_collator()
+    only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
+    jobs = {"encoder": golden_encoder, "protnote": golden_protnote, "losses": golden_losses_metrics,
+            "collator": golden_collator, "bookkeeping": golden_bookkeeping}
+    for name, fn in jobs.items():
+        if not only or name in only:
+            fn()

@@ -1,0 +1,66 @@
+"""Host-side input layout and integer label bookkeeping vs vectors produced by the reference's own collator
+and ProteinDataset (tests/golden/make_golden.py).  Integer work: bit-exact."""
+import os
+
+import numpy as np
+import torch
+
+from protnote_amd.data import labels as LB
+from protnote_amd.data.collators import collate_variable_sequence_length
+
+
+def test_collator_layout(golden_dir):
+    g = np.load(os.path.join(golden_dir, "collator.npz"))
+    lab = torch.from_numpy(g["in/label_embeddings"])
+    cnt = torch.from_numpy(g["in/label_token_counts"])
+    batch = []
+    for i in range(4):
+        ids = torch.from_numpy(g[f"in/ids{i}"])
+        batch.append({"sequence_onehots": torch.nn.functional.one_hot(ids, 20).T.float(), "sequence_id": f"P{i}",
+                      "sequence_length": torch.tensor(len(ids)), "label_multihots": torch.from_numpy(g[f"in/multihots{i}"]),
+                      "label_embeddings": lab, "label_token_counts": cnt})
+    out = collate_variable_sequence_length(batch)
+    for k in ("sequence_onehots", "sequence_lengths", "label_embeddings", "label_token_counts", "label_multihots"):
+        assert np.array_equal(out[k].numpy(), g["out/" + k]), k
+        assert str(out[k].dtype) == str(g["out_dtype/" + k]), k
+    assert out["sequence_ids"] == [f"P{i}" for i in range(4)]
+    # sub-sampling variants keep embeddings and multihots aligned
+    sub = collate_variable_sequence_length(batch, label_sample_size=3)
+    assert np.array_equal(sub["label_embeddings"].numpy(), g["out/label_embeddings"][:3])
+    assert np.array_equal(sub["label_multihots"].numpy(), g["out/label_multihots"][:, :3])
+    inb = collate_variable_sequence_length(batch, in_batch_sampling=True)
+    keep = g["out/label_multihots"].sum(0) > 0
+    assert np.array_equal(inb["label_multihots"].numpy(), g["out/label_multihots"][:, keep])
+
+
+def test_label_bookkeeping_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "bookkeeping.npz"))
+    data = [(s, i, l.split(" ")) for s, i, l in zip(g["fasta_seqs"], g["fasta_ids"], g["fasta_labels"])]
+    idx_ids, idx_types = list(g["index_id"]), list(g["index_type"])
+    tok = g["index_token_count"]
+    for dtype, descr in (("test", ["name", "label"]), ("train", ["name", "label", "synonym_exact"])):
+        p = dtype + "/"
+        recs = LB.deduplicate(data)
+        if dtype == "train":  # MAX_SEQUENCE_LENGTH only trims the train set (datasets.py:162-168)
+            recs = [r for r in recs if len(r[0]) <= 15]
+        assert [r[1] for r in recs] == list(g[p + "kept_ids"])
+        voc = LB.generate_vocabularies(recs)
+        assert voc["label_vocab"] == list(g[p + "label_vocabulary"])
+        assert voc["amino_acid_vocab"] == list(g[p + "amino_acid_vocabulary"])
+        kept, span = LB.embedding_row_index(idx_ids, idx_types, voc["label_vocab"], descr)
+        assert np.array_equal(kept, g[p + "filtered_rows"])
+        assert [span[l][0] for l in voc["label_vocab"]] == list(g[p + "min_idx"])
+        assert [span[l][1] for l in voc["label_vocab"]] == list(g[p + "max_idx"])
+        rows = LB.sorted_embedding_rows(span, voc["label_vocab"])
+        assert np.array_equal(kept[rows], g[p + "sorted_rows"])
+        assert np.array_equal(tok[kept][rows], g[p + "sorted_token_counts"])
+        np.random.seed(123)
+        srows = LB.sampled_embedding_rows(span, voc["label_vocab"])
+        assert np.array_equal(kept[srows], g[p + "sampled_rows_seed123"])
+        assert np.array_equal(tok[kept][srows], g[p + "sampled_token_counts_seed123"])
+        l2i, _ = LB.get_vocab_mappings(voc["label_vocab"])
+        a2i, _ = LB.get_vocab_mappings(voc["amino_acid_vocab"])
+        for i, (seq, sid, labs) in enumerate(recs):
+            assert np.array_equal(LB.label_multihot(labs, l2i).numpy(), g[p + f"ex{i}/multihots"])
+            assert np.array_equal(LB.sequence_onehot(seq, a2i).numpy(), g[p + f"ex{i}/onehots"])
+            assert int(g[p + f"ex{i}/length"]) == len(seq)
