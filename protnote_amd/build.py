@@ -26,7 +26,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SRC
+    extra = os.environ.get("PN_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + SRC
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -12,6 +12,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
+#ifndef PN_OVL
+#define PN_OVL 1
+#endif
+#ifndef PN_MINW
+#define PN_MINW 2
+#endif
+#ifndef PN_BK
+#define PN_BK 32
+#endif
+#ifndef PN_WS
+#define PN_WS 0
+#endif
+#ifndef PN_PRIO
+#define PN_PRIO 0
+#endif
+
 namespace pn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -67,6 +85,20 @@ struct GemmParams {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+
+// Two workgroups share a CU (one wave of each per SIMD).  Left alone they phase-lock: both run their MFMA
+// blocks together (sharing the matrix pipe) and then both stream/transform operands together, leaving the
+// pipe idle ~15 % of the time.  Giving the co-resident waves of a SIMD DIFFERENT static priorities (from
+// the hardware wave slot) makes the higher one own the pipe during its MFMA block and the lower one fill
+// exactly the gaps - the anti-phased schedule - so the pipe stays busy.
+__device__ __forceinline__ void stagger_priority() {
+#if PN_PRIO
+  const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;  // HW_REG_HW_ID.wave_id[1:0]
+  if (slot == 1) __builtin_amdgcn_s_setprio(1);
+  else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+  else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+#endif
+}
 // Make a fetched register quad opaque at this point of the program: the transform math that consumes it
 // cannot be hoisted above (DAG linearisation otherwise floats it in front of the MFMA block, dragging the
 // s_waitcnt vmcnt with it and exposing the global-load latency).
@@ -75,7 +107,15 @@ __device__ __forceinline__ void pin4(float4& v) {
 }
 
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) void gemm_nt_kernel(const GemmParams p) {
+  // WS (wave specialisation): the workgroup has 2 x WAVES_M*WAVES_N waves.  Waves [0, NW) are CONSUMERS - they
+  // only read MFMA fragments from LDS and issue matrix ops, so the matrix pipe never waits on HBM/L2 latency,
+  // address arithmetic or operand transforms.  Waves [NW, 2NW) are PRODUCERS - they stream the next slab
+  // global -> registers -> (BN/ReLU/mask/dz transform) -> LDS while the consumers compute the current one.
+  // One s_barrier per slab hands the double-buffered LDS stage over.
+  constexpr bool WS = PN_WS != 0;
+  constexpr bool OVL = PN_OVL != 0 && !WS;  // non-WS only: weave commit() into the second half of the MFMA block
+  constexpr int VPM = (AK == A_DZ_ELEM || AK == A_DZ_ROWG) ? 5 : 3;  // VALU ops scheduled per MFMA
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;
   constexpr int BN = WAVES_N * WN * 32;
@@ -88,12 +128,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   constexpr int STAGE = (BM + BN) * LDK;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  stagger_priority();
 
+  constexpr int NTB = NT * (WS ? 2 : 1);  // threads in the workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WAVES_N;
-  const int wn = wave % WAVES_N;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_producer = WS ? (wave >= WAVES_M * WAVES_N) : true;
+  const bool is_consumer = WS ? (wave < WAVES_M * WAVES_N) : true;
+  const int cw = WS ? (wave % (WAVES_M * WAVES_N)) : wave;  // consumer wave index (tile position)
+  const int wm = cw / WAVES_N;
+  const int wn = cw % WAVES_N;
+  const int ltid = WS ? (tid & (NT - 1)) : tid;  // loader thread index (producer waves when WS)
 
   const int ntn = (p.Nstore + BN - 1) / BN;
   const int tile_n = blockIdx.x % ntn;
@@ -101,8 +147,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   const int row0 = tile_m * BM;
   const int col0 = tile_n * BN;
 
-  const int kv = tid % KV;
-  const int r_in = tid / KV;
+  const int kv = ltid % KV;
+  const int r_in = ltid / KV;
 
   // ---------------- per-thread operand row state ----------------
   const float* arow[NQA];
@@ -199,13 +245,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     }
   };
 
-  auto sel4 = [](bool ok, float4 v) {
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-  };
-
-  auto commit = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDK;
+  auto pin_fetched = [&]() {
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       pin4(ra[q]);
@@ -213,6 +253,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     }
 #pragma unroll
     for (int q = 0; q < NQB; ++q) pin4(rb[q]);
+  };
+
+  auto sel4 = [](bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  };
+
+  auto commit = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       float4 v = ra[q];
@@ -262,11 +311,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, auto kk0_c, auto kk1_c) {
+    constexpr int KK0 = decltype(kk0_c)::value, KK1 = decltype(kk1_c)::value;
     const float* As = smem + buf * STAGE + (wm * WM * 32 + frag_row) * LDK + frag_k;
     const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + frag_k;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
+    for (int kk = KK0; kk < KK1; ++kk) {
       float4 a[WM], b[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK + kk * 8);
@@ -285,20 +335,134 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   };
 
   // ---------------- main loop: register-prefetch double buffering, one barrier per slab ----------------
+  using std::integral_constant;
+  constexpr int KH = BK / 16;  // half of the BK/8 fragment steps
+
+  // consumer-side slab product with register double-buffered fragments: the ds_read_b128s of fragment step
+  // kk+1 are issued before the 4*WM*WN MFMAs of step kk, so LDS latency sits under the matrix pipe even
+  // with a single consumer wave per SIMD.
+  auto compute_ws = [&](int buf) {
+    const float* As = smem + buf * STAGE + (wm * WM * 32 + frag_row) * LDK + frag_k;
+    const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + frag_k;
+    float4 a[2][WM], b[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const int c = kk & 1;
+      if (kk + 1 < BK / 8) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          a[c ^ 1][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK + (kk + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          b[c ^ 1][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].x, b[c][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].y, b[c][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].z, b[c][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].w, b[c][j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if constexpr (WS) {
+    if (is_producer) {
+      fetch(0);
+      pin_fetched();
+      commit(0);
+      if (nslab > 1) fetch(1);
+    }
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+      if (is_producer) {
+        if (s + 1 < nslab) {
+          pin_fetched();
+          commit((s + 1) & 1);            // waits for the loads of slab s+1 (issued one slab ago)
+          if (s + 2 < nslab) fetch(s + 2);  // and immediately puts slab s+2 in flight
+        }
+      } else {
+        compute_ws(s & 1);
+      }
+      __syncthreads();
+    }
+  } else {
   fetch(0);
+  pin_fetched();
   commit(0);
   __syncthreads();
+#if defined(PN_ABL) && PN_ABL == 1  // ablation: MFMA + LDS fragment reads only
+  for (int s = 0; s + 1 < nslab; ++s)
+    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
+#elif defined(PN_ABL) && PN_ABL == 2  // ablation: operand streaming only
+  for (int s = 0; s + 1 < nslab; ++s) {
+    fetch(s + 1);
+    pin_fetched();
+    commit((s & 1) ^ 1);
+    __syncthreads();
+  }
+#elif defined(PN_ABL) && PN_ABL == 4  // ablation: global loads + MFMA, no transform / ds_write
+  for (int s = 0; s + 1 < nslab; ++s) {
+    fetch(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pin_fetched();
+    __syncthreads();
+  }
+#elif defined(PN_ABL) && PN_ABL == 5  // ablation: transform + ds_write + MFMA, no global loads
+  for (int s = 0; s + 1 < nslab; ++s) {
+    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pin_fetched();
+    commit((s & 1) ^ 1);
+    __syncthreads();
+  }
+#elif defined(PN_ABL) && PN_ABL == 6  // ablation: MFMA + barrier only
+  for (int s = 0; s + 1 < nslab; ++s) {
+    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
+    __syncthreads();
+  }
+#else
   for (int s = 0; s + 1 < nslab; ++s) {
     const int cur = s & 1;
     fetch(s + 1);  // global loads of the next slab are issued first ...
     __builtin_amdgcn_sched_barrier(0);
-    compute(cur);  // ... stay in flight under this slab's 64 MFMAs ...
+    // ... and stay in flight under the first half of this slab's MFMAs ...
+    compute(cur, integral_constant<int, 0>{}, integral_constant<int, KH>{});
     __builtin_amdgcn_sched_barrier(0);
-    commit(cur ^ 1);  // ... and are only waited for here (hipcc would otherwise sink them next to the wait)
+    pin_fetched();  // (keeps hipcc from floating the consumer math, and its vmcnt wait, above this point)
+    // ... then the operand transform + LDS stores of slab s+1 are woven between the second half's MFMAs
+    // (one matrix op, then a few VALU / one ds_write while the matrix pipe is busy), so the only
+    // non-overlapped part of the slab is the barrier itself.
+    compute(cur, integral_constant<int, KH>{}, integral_constant<int, BK / 8>{});
+    commit(cur ^ 1);
+    if constexpr (OVL) {
+      constexpr int NM = (BK / 8 - KH) * 4 * WM * WN;  // MFMAs in the second half
+      constexpr int NRD = WM + WN;                      // ds_read_b128 per fragment step
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i % (4 * WM * WN) == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+#if !defined(PN_ABL) || PN_ABL != 3
     __syncthreads();
+#endif
   }
-  compute((nslab - 1) & 1);
+#endif
+  compute((nslab - 1) & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
   __syncthreads();
+
+  }
 
   // ---------------- epilogue ----------------
   const int hl = lane >> 5;  // which 4-row group of each 8
@@ -306,10 +470,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
   const bool want_stats = (EK == E_STORE || EK == E_CONV) && (p.col_sum != nullptr);
   float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
   if (want_stats) {
-    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
+    for (int i = tid; i < 2 * BN; i += NTB) red[i] = 0.f;
     __syncthreads();
   }
 
+  if (is_consumer) {
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = col0 + (wn * WN + j) * 32 + cl;
@@ -372,9 +537,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
       }
     }
   }
+  }  // is_consumer
   if (want_stats) {
     __syncthreads();
-    for (int i = tid; i < BN; i += NT) {
+    for (int i = tid; i < BN; i += NTB) {
       const int col = col0 + i;
       if (col < p.N) {
         atomicAdd(&p.col_sum[col], (double)red[i]);
@@ -383,6 +549,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
     }
   }
   if constexpr (EK == E_ROWDOT) {
+    if (is_consumer) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -399,6 +566,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(const Ge
         if (cl == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
       }
     }
+    }
   }
 }
 
@@ -406,7 +574,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int BK>
 struct GemmCfg {
   static constexpr int BM = WAVES_M * WM * 32;
   static constexpr int BN = WAVES_N * WN * 32;
-  static constexpr int NT = WAVES_M * WAVES_N * 64;
+  static constexpr int NT = WAVES_M * WAVES_N * 64 * (PN_WS ? 2 : 1);
   static constexpr int LDS_BYTES = 2 * (BM + BN) * (BK + 4) * (int)sizeof(float);
 };
 

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   constexpr int NQ = 4;  // (BK rows * 32 float4 per row) / 256 threads
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  stagger_priority();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

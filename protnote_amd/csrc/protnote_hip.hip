@@ -160,8 +160,8 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
 // variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64)
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
-  if (variant == 1) return launch_gemm_cfg<AK, EK, 4, 1, 1, 2, 32>(p, st);
-  return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, 32>(p, st);
+  if (variant == 1) return launch_gemm_cfg<AK, EK, 4, 1, 1, 2, PN_BK>(p, st);
+  return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK>(p, st);
 }
 
 static int pick_variant(int n) {
