@@ -164,6 +164,12 @@ int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const float* L_e, i
                     const pn_pairhead_grads* gr, float* dP_e, float* dL_e, int label_chunk, void* save,
                     size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of the similarity head (ProtNote.py:281-284 under autograd): dlogits [B][NL] -> dP_e [B][d],
+ * dL_e [NL][d]; the L2 normalisations are recomputed. */
+size_t pn_similarity_train_ws_bytes(int B, int NL, int d);
+int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int NL, int d, float temperature,
+                      const float* dlogits, float* dP_e, float* dL_e, void* ws, size_t ws_bytes, void* stream);
+
 /* Loss forward + d(mean loss)/dlogit + per-label TP/FN/FP in one pass over logits [B][N]
  * (utils/losses.py:190-213 FocalLoss, :275-276 BCEWithLogits(pos_weight); ProtNoteTrainer.py:61-83).
  * kind 0 = BCE, 1 = focal.  Exactly one of targets_f32 / targets_i64 is non-NULL.  tp/fn/fp (each [N], f32

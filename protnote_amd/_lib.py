@@ -89,6 +89,9 @@ _SIGS = {
     "pn_pairhead_bwd": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.POINTER(pn_pairhead_grads), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_similarity_train_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pn_similarity_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1371,3 +1371,97 @@ extern "C" int pn_gemm_tn(const float* A, long lda, const float* Bm, long ldb, f
   tp.R = R; tp.M = M; tp.N = N; tp.A = A; tp.lda = lda; tp.B = Bm; tp.ldb = ldb;
   return launch_tn<TA_PLAIN, TB_PLAIN>(tp, C, ldc, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// similarity head, training (ProtNote.py:281-284 + autograd):  logits = (P^ L^T) / T,  X^ = X / max(|X|, eps)
+// ------------------------------------------------------------------------------------------------
+// xhat[r][:] = x[r][:] * rs[r]
+__global__ void k_scale_rows(const float* __restrict__ x, const float* __restrict__ rs, float* __restrict__ out,
+                             long rows, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * d) return;
+  out[i] = x[i] * rs[i / d];
+}
+
+// dx = rs * (dxhat - xhat * <xhat, dxhat>)   (rows with |x| < eps: normalisation is x/eps, dx = dxhat/eps)
+__global__ void k_normalize_bwd(const float* __restrict__ xhat, const float* __restrict__ dxhat,
+                                const float* __restrict__ rs, float alpha, float* __restrict__ dx, int rows, int d) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* xh = xhat + (long)r * d;
+  const float* dh = dxhat + (long)r * d;
+  float dot = 0.f;
+  for (int c = lane; c < d; c += 64) dot = fmaf(xh[c], dh[c], dot);
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  const float s = rs[r];
+  const bool clamped = s >= 1e12f;  // |x| <= 1e-12: F.normalize divides by eps, a constant
+  for (int c = lane; c < d; c += 64) dx[(long)r * d + c] = alpha * s * (clamped ? dh[c] : dh[c] - xh[c] * dot);
+}
+
+struct SimWs {
+  float *rs, *cs, *Ph, *Lh, *dPh, *dLh, *T1, *PhT;
+};
+static bool sim_carve(int B, int NL, int d, Bump& bp, SimWs& w) {
+  const int Bp = ld4(B);
+  w.rs = bp.take<float>(B);
+  w.cs = bp.take<float>(NL);
+  w.Ph = bp.take<float>((size_t)B * d);
+  w.Lh = bp.take<float>((size_t)NL * d);
+  w.dPh = bp.take<float>((size_t)Bp * d);
+  w.dLh = bp.take<float>((size_t)NL * d);
+  w.T1 = bp.take<float>((size_t)NL * Bp);   // dlogits^T, zero-padded columns
+  w.PhT = bp.take<float>((size_t)d * Bp);   // P^^T, zero-padded columns
+  return bp.ok;
+}
+
+extern "C" size_t pn_similarity_train_ws_bytes(int B, int NL, int d) {
+  Bump bp(nullptr, (size_t)-1);
+  SimWs w;
+  sim_carve(B, NL, d, bp, w);
+  return bp.off + 256;
+}
+
+// dP_e, dL_e from dlogits [B][NL] (any NL: rows of dlogits need not be 16-byte aligned - everything goes
+// through the zero-padded transpose T1 = dlogits^T [NL][ld4(B)]); the normalisations are recomputed.
+extern "C" int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int NL, int d, float temperature,
+                                 const float* dlogits, float* dP_e, float* dL_e, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (d % 4) return fail("similarity bwd: d must be a multiple of 4");
+  Bump bp(ws, ws_bytes);
+  SimWs w;
+  if (!sim_carve(B, NL, d, bp, w)) return fail("similarity bwd: workspace too small");
+  const int Bp = ld4(B);
+  hipLaunchKernelGGL(k_rownorm_inv, dim3(nblk(B, 4)), dim3(256), 0, st, P_e, (long)d, B, d, w.rs);
+  hipLaunchKernelGGL(k_rownorm_inv, dim3(nblk(NL, 4)), dim3(256), 0, st, L_e, (long)d, NL, d, w.cs);
+  hipLaunchKernelGGL(k_scale_rows, dim3(nblk((long)B * d, 256)), dim3(256), 0, st, P_e, (const float*)w.rs, w.Ph,
+                     (long)B, d);
+  hipLaunchKernelGGL(k_scale_rows, dim3(nblk((long)NL * d, 256)), dim3(256), 0, st, L_e, (const float*)w.cs, w.Lh,
+                     (long)NL, d);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemsetAsync(w.T1, 0, (size_t)NL * Bp * sizeof(float), st));
+  HIP_OK(hipMemsetAsync(w.PhT, 0, (size_t)d * Bp * sizeof(float), st));
+  PN_OK(transpose_into(dlogits, NL, B, NL, w.T1, Bp, st));  // T1[j][i] = dl[i][j]
+  PN_OK(transpose_into(w.Ph, d, B, d, w.PhT, Bp, st));       // PhT[k][i] = P^[i][k]
+  const float alpha = 1.f / temperature;
+  // dP^[i][k] = sum_j T1[j][i] L^[j][k]   (contraction over the NL rows)
+  {
+    TnParams tp = tn_zero();
+    tp.R = NL; tp.M = Bp; tp.N = d; tp.A = w.T1; tp.lda = Bp; tp.B = w.Lh; tp.ldb = d;
+    PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, w.dPh, d, nullptr, 0, st)));
+  }
+  // dL^[j][k] = sum_i T1[j][i] P^[i][k]
+  {
+    GemmParams p = gp_zero();
+    p.M = NL; p.N = d; p.Nstore = d; p.Kseg = Bp;
+    p.A = w.T1; p.lda = Bp; p.W = w.PhT; p.ldw = Bp; p.C = w.dLh; p.ldc = d;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+  }
+  hipLaunchKernelGGL(k_normalize_bwd, dim3(nblk(B, 4)), dim3(256), 0, st, (const float*)w.Ph, (const float*)w.dPh,
+                     (const float*)w.rs, alpha, dP_e, B, d);
+  hipLaunchKernelGGL(k_normalize_bwd, dim3(nblk(NL, 4)), dim3(256), 0, st, (const float*)w.Lh, (const float*)w.dLh,
+                     (const float*)w.cs, alpha, dL_e, NL, d);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

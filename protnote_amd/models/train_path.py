@@ -80,7 +80,7 @@ class _HeadsTrainFn(torch.autograd.Function):
                 bn.num_batches_tracked += 1
 
         if model.feature_fusion == "similarity":
-            raise NotImplementedError("training with feature_fusion='similarity' is not implemented in protnote_amd")
+            return model._similarity(P_e, L_e)
         hd, hl = model._pair_desc()
         chunk = model._train_chunk(B, NL)
         ctx.chunk = chunk
@@ -105,8 +105,6 @@ class _HeadsTrainFn(torch.autograd.Function):
         dev = P_f.device
         B, NL = P_f.shape[0], L_f.shape[0]
         dlogits = dlogits.contiguous().float()
-        dl_pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
-        L.check(lib.pn_transpose(L.ptr(dlogits), NL, B, NL, L.ptr(dl_pairs), B, st))
 
         grads = {}
 
@@ -114,6 +112,18 @@ class _HeadsTrainFn(torch.autograd.Function):
             g = torch.empty_like(p, memory_format=torch.contiguous_format)
             grads[id(p)] = g
             return g.data_ptr()
+
+        if model.feature_fusion == "similarity":
+            d = P_e.shape[1]
+            dP_e = torch.empty_like(P_e)
+            dL_e = torch.empty_like(L_e)
+            ws = L.workspace(lib.pn_similarity_train_ws_bytes(B, NL, d), dev, "train")
+            L.check(lib.pn_similarity_bwd(L.ptr(P_e), L.ptr(L_e), B, NL, d, float(model.temperature), L.ptr(dlogits),
+                                          L.ptr(dP_e), L.ptr(dL_e), L.ptr(ws), ws.numel(), st))
+            return _HeadsTrainFn._finish(ctx, model, lib, st, dev, P_f, L_f, dP_e, dL_e, grads, gbuf)
+
+        dl_pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
+        L.check(lib.pn_transpose(L.ptr(dlogits), NL, B, NL, L.ptr(dl_pairs), B, st))
 
         # ---- pair head ----
         hd, hl = model._pair_desc()
@@ -134,6 +144,10 @@ class _HeadsTrainFn(torch.autograd.Function):
                                     L.ptr(dP_e), L.ptr(dL_e), ctx.chunk, L.ptr(save), save.numel(), L.ptr(ws),
                                     ws.numel(), st))
 
+        return _HeadsTrainFn._finish(ctx, model, lib, st, dev, P_f, L_f, dP_e, dL_e, grads, gbuf)
+
+    @staticmethod
+    def _finish(ctx, model, lib, st, dev, P_f, L_f, dP_e, dL_e, grads, gbuf):
         # ---- projection heads ----
         def mlp_bwd(seq, x, dy, tag):
             m, layers = model._mlp_desc(seq)

@@ -145,3 +145,48 @@ def test_pairhead_eval_real_width_vs_oracle(B, NL, chunk):
     assert ref.abs().max().item() > 0.5  # logits are O(1): the tolerance is not vacuous
     assert err < 1e-3, err
     assert err < 3e-4, err
+
+
+def test_zero_shot_bucketed_padding_and_label_swap():
+    """BASELINE configs[4] behaviour on a small model: variable-length sequences padded to bucket sizes give
+    the same logits as padding to the batch maximum, and swapping the label table (GO -> EC sized, 2
+    descriptions per label, ensembled) between calls needs no model re-creation."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.protein_encoders import ProteInfer
+
+    gen = torch.Generator().manual_seed(9)
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=64, kernel_size=9, dilation_base=3,
+                num_resnet_blocks=5, bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, 64, 32, 16, 48, 4, 48, 3))
+    enc = ProteInfer(activation=torch.nn.ReLU, **ecfg)
+    model = ProtNote(protein_embedding_dim=64, label_embedding_dim=32, latent_dim=16, sequence_encoder=enc,
+                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, inference_descriptions_per_label=2)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    lens = torch.tensor([700, 33, 1500, 128, 2048, 5])
+    ids = torch.randint(0, 20, (len(lens), 2048), generator=gen)
+    go = torch.randn(2 * 37, 32, generator=gen)
+    ec = torch.randn(2 * 11, 32, generator=gen)
+
+    def run(rows, lmax, labels):
+        x = torch.nn.functional.one_hot(ids[rows, :lmax], 20).permute(0, 2, 1).float().contiguous()
+        with torch.no_grad():
+            out, _ = model(sequence_onehots=x.to(DEV), sequence_lengths=lens[rows].to(DEV),
+                           label_embeddings=labels.to(DEV))
+        return out.cpu()
+
+    full = run(torch.arange(6), 2048, go)
+    osd = {k: v.clone() for k, v in sd.items()}
+    ref = O.protnote_forward(osd, torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float(), lens, go,
+                             descriptions_per_label=2)
+    assert (full - ref).abs().max().item() < 5e-4
+    buckets = {128: [1, 3, 5], 1024: [0], 2048: [2, 4]}
+    for lmax, rows in buckets.items():
+        part = run(torch.tensor(rows), lmax, go)
+        assert (part - full[rows]).abs().max().item() < 2e-5, lmax
+    ec_out = run(torch.arange(6), 2048, ec)  # runtime label-table swap
+    ref_ec = O.protnote_forward(osd, torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float(), lens, ec,
+                                descriptions_per_label=2)
+    assert ec_out.shape == (6, 11) and (ec_out - ref_ec).abs().max().item() < 5e-4
