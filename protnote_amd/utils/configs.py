@@ -1,0 +1,80 @@
+"""Config surface of the reference (protnote/utils/configs.py + configs/base_config.yaml): YAML load, the
+`--override KEY VALUE ...` rule (python-literal values, null/true/false spelled the YAML way), and the mapping
+from config keys to the model constructors that bin/main.py:383-446 performs.  Only what the hot path needs:
+no path prefixing, loggers or label-embedding cache-name mangling (I/O side, out of scope)."""
+from ast import literal_eval
+
+import yaml
+
+
+def load_config(path: str) -> dict:
+    with open(path) as f:
+        return yaml.safe_load(f)
+
+
+def try_literal_eval(val):
+    """Reference configs.py:38-48: 'null'/'true'/'false' are recognised, everything else goes through
+    ast.literal_eval and falls back to the raw string."""
+    if isinstance(val, str):
+        low = val.lower()
+        if low == "null":
+            return None
+        if low == "true":
+            return True
+        if low == "false":
+            return False
+    try:
+        return literal_eval(val)
+    except (ValueError, SyntaxError):
+        return val
+
+
+def override_config(config: dict, overrides) -> dict:
+    """Reference configs.py:51-71: flat `KEY VALUE KEY VALUE ...`; a key must already exist in params or paths."""
+    if overrides is None:
+        return config
+    if len(overrides) % 2 != 0:
+        raise ValueError("Overrides must be provided as key-value pairs.")
+    for key, value in zip(overrides[::2], overrides[1::2]):
+        found = False
+        for section in ("params", "embed_sequences_params"):
+            if key in config.get(section, {}):
+                config[section][key] = try_literal_eval(value)
+                found = True
+        for section in config.get("paths", {}).values():
+            if isinstance(section, dict) and key in section:
+                section[key] = value
+                found = True
+        if not found:
+            raise KeyError(f"Key '{key}' not found in the 'params' or 'paths' section of the config.")
+    return config
+
+
+def build_models(config: dict, num_labels: int = None, label_encoder=None, feature_fusion: str = None):
+    """ProteInfer + ProtNote exactly as bin/main.py:396-446 builds them from `params` /
+    `embed_sequences_params` (random-initialised encoder; weights then come from load_state_dict)."""
+    import torch
+
+    from ..models.ProtNote import ProtNote
+    from ..models.protein_encoders import ProteInfer
+
+    p, e = config["params"], config["embed_sequences_params"]
+    enc = ProteInfer(num_labels=num_labels or e["PROTEINFER_NUM_GO_LABELS"], input_channels=e["INPUT_CHANNELS"],
+                     output_channels=e["OUTPUT_CHANNELS"], kernel_size=e["KERNEL_SIZE"], activation=torch.nn.ReLU,
+                     dilation_base=e["DILATION_BASE"], num_resnet_blocks=e["NUM_RESNET_BLOCKS"],
+                     bottleneck_factor=e["BOTTLENECK_FACTOR"])
+    model = ProtNote(
+        protein_embedding_dim=p["PROTEIN_EMBEDDING_DIM"], label_embedding_dim=p["LABEL_EMBEDDING_DIM"],
+        latent_dim=p["LATENT_EMBEDDING_DIM"], label_embedding_pooling_method=p["LABEL_EMBEDDING_POOLING_METHOD"],
+        sequence_embedding_dropout=p["SEQUENCE_EMBEDDING_DROPOUT"], label_embedding_dropout=p["LABEL_EMBEDDING_DROPOUT"],
+        label_embedding_noising_alpha=p["LABEL_EMBEDDING_NOISING_ALPHA"], label_encoder=label_encoder,
+        sequence_encoder=enc, inference_descriptions_per_label=len(p["INFERENCE_GO_DESCRIPTIONS"].split("+")),
+        output_mlp_hidden_dim_scale_factor=p["OUTPUT_MLP_HIDDEN_DIM_SCALE_FACTOR"],
+        output_mlp_num_layers=p["OUTPUT_MLP_NUM_LAYERS"], output_neuron_bias=None,
+        outout_mlp_add_batchnorm=p["OUTPUT_MLP_BATCHNORM"], residual_connection=p["RESIDUAL_CONNECTION"],
+        projection_head_num_layers=p["PROJECTION_HEAD_NUM_LAYERS"], dropout=p["OUTPUT_MLP_DROPOUT"],
+        projection_head_hidden_dim_scale_factor=p["PROJECTION_HEAD_HIDDEN_DIM_SCALE_FACTOR"],
+        label_encoder_num_trainable_layers=p["LABEL_ENCODER_NUM_TRAINABLE_LAYERS"],
+        train_sequence_encoder=p["TRAIN_SEQUENCE_ENCODER"], feature_fusion=feature_fusion or p["FEATURE_FUSION"],
+        temperature=p["SUPCON_TEMP"])
+    return enc, model

@@ -1,0 +1,77 @@
+"""The base_config.yaml surface the hot path depends on: key names -> constructor kwargs, --override rule."""
+import pytest
+import yaml
+
+from protnote_amd.utils import configs as CF
+
+CFG = yaml.safe_load("""
+params:
+  LEARNING_RATE: 0.0003
+  PROTEIN_EMBEDDING_DIM: 1100
+  LABEL_EMBEDDING_DIM: 1024
+  LATENT_EMBEDDING_DIM: 1024
+  OUTPUT_MLP_HIDDEN_DIM_SCALE_FACTOR: 3
+  OUTPUT_MLP_NUM_LAYERS: 3
+  OUTPUT_MLP_BATCHNORM: True
+  RESIDUAL_CONNECTION: False
+  OUTPUT_MLP_DROPOUT: 0.0
+  LABEL_EMBEDDING_DROPOUT: 0.0
+  SEQUENCE_EMBEDDING_DROPOUT: 0.0
+  PROJECTION_HEAD_NUM_LAYERS: 4
+  PROJECTION_HEAD_HIDDEN_DIM_SCALE_FACTOR: 3
+  FEATURE_FUSION: concatenation
+  LABEL_EMBEDDING_POOLING_METHOD: mean
+  LABEL_EMBEDDING_NOISING_ALPHA: 20.0
+  LABEL_ENCODER_NUM_TRAINABLE_LAYERS: 0
+  TRAIN_SEQUENCE_ENCODER: False
+  INFERENCE_GO_DESCRIPTIONS: name+label
+  SUPCON_TEMP: 0.07
+  CLIP_VALUE: 1
+  LOSS_FN: FocalLoss
+embed_sequences_params:
+  INPUT_CHANNELS: 20
+  OUTPUT_CHANNELS: 1100
+  KERNEL_SIZE: 9
+  DILATION_BASE: 3
+  NUM_RESNET_BLOCKS: 5
+  BOTTLENECK_FACTOR: 0.5
+  PROTEINFER_NUM_GO_LABELS: 32102
+paths:
+  data_paths:
+    TRAIN_DATA_PATH: a.fasta
+""")
+
+
+def test_override_rule():
+    import copy
+
+    c = CF.override_config(copy.deepcopy(CFG), ["CLIP_VALUE", "null", "LOSS_FN", "BCE", "OUTPUT_MLP_BATCHNORM",
+                                                "false", "LEARNING_RATE", "1e-3", "TRAIN_DATA_PATH", "b.fasta"])
+    assert c["params"]["CLIP_VALUE"] is None and c["params"]["LOSS_FN"] == "BCE"
+    assert c["params"]["OUTPUT_MLP_BATCHNORM"] is False and c["params"]["LEARNING_RATE"] == 1e-3
+    assert c["paths"]["data_paths"]["TRAIN_DATA_PATH"] == "b.fasta"
+    with pytest.raises(KeyError):
+        CF.override_config(copy.deepcopy(CFG), ["NOT_A_KEY", "1"])
+    with pytest.raises(ValueError):
+        CF.override_config(copy.deepcopy(CFG), ["CLIP_VALUE"])
+
+
+def test_build_models_matches_reference_parameter_counts():
+    import copy
+
+    cfg = copy.deepcopy(CFG)
+    cfg["embed_sequences_params"]["PROTEINFER_NUM_GO_LABELS"] = 8  # keep the unused classifier small
+    enc, model = CF.build_models(cfg)
+    named = dict(model.named_parameters())
+    # SURVEY 2.2 K16 [probed on the reference]: 25 417 728 W_p + 25 184 256 W_l + 25 187 329 output_layer
+    count = lambda pre: sum(v.numel() for k, v in named.items() if k.startswith(pre))
+    assert count("W_p.") == 25_417_728 and count("W_l.") == 25_184_256 and count("output_layer.") == 25_187_329
+    trunk = sum(v.numel() for k, v in named.items() if k.startswith("sequence_encoder.") and "output_layer" not in k)
+    assert trunk == 30_473_850
+    assert model.inference_descriptions_per_label == 2 and model.temperature == 0.07
+    keys = set(model.state_dict())
+    for k in ("W_p.0.weight", "W_p.1.running_mean", "W_p.12.weight", "W_l.9.num_batches_tracked",
+              "output_layer.0.weight", "output_layer.9.bias", "output_layer.11.weight", "output_layer.11.bias",
+              "sequence_encoder.conv1.weight", "sequence_encoder.resnet_blocks.4.bn_activation_2.0.running_var",
+              "sequence_encoder.resnet_blocks.0.masked_conv1.bias", "sequence_encoder.output_layer.weight"):
+        assert k in keys, k
