@@ -31,7 +31,7 @@ import torch  # noqa: E402
 KIND_NAMES = {
     0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
     12: "nt:bn_relu(z)->rowdot", 22: "nt:pairsum_relu->rowdot", 3: "nt:plain->scale",
-    100: "tn:plain x plain", 101: "tn:plain x bn_relu", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
+    100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
 }
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
@@ -78,7 +78,7 @@ def synthetic_batch(B, L, NL, device, seed):
 
 def cpu_baseline(seconds_hint=20.0):
     """Oracle train step (reference algorithm restated, f32, torch-CPU) on a bounded sample of the same
-    workload: B=8 proteins, L=512, N_L=4096 labels, full-width model (~15-25 s of CPU work)."""
+    workload: B=16 proteins, L=512, N_L=8192 labels, full-width model (~20 s of CPU work on 32 threads)."""
     from oracle import protnote_oracle as O
     from tests.helpers import random_encoder_sd, random_head_sd
 
@@ -90,7 +90,7 @@ def cpu_baseline(seconds_hint=20.0):
                 num_resnet_blocks=5, bottleneck_factor=0.5)
     sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
     sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
-    B, L, NL = 8, 512, 4096
+    B, L, NL = 16, 512, 8192
     ids = torch.randint(0, 20, (B, L), generator=gen)
     x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
     lens = torch.full((B,), L, dtype=torch.int64)

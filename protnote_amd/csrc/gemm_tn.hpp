@@ -59,8 +59,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   const int ntn = (p.N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % ntn;
-  const int tile_m = blockIdx.x / ntn;
+  const int ntm = (p.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
+    // XCD-aware order: workgroup x of a split runs on XCD x % 8; give each XCD one (ntm/2) x (ntn/4) region of
+    // the tile grid so it streams 1/2 of dz and 1/4 of the activations through its L2 instead of all of dz
+    // and 1/8 of the activations (24x24 tiles: 18 instead of 27 distinct operand tiles per slab and XCD).
+    const int rm = ntm / 2, rn = ntn / 4;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    tile_m = (xcd >> 2) * rm + w / rn;
+    tile_n = (xcd & 3) * rn + w % rn;
+  } else {
+    tile_n = blockIdx.x % ntn;
+    tile_m = blockIdx.x / ntn;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const long r_begin = (long)split * p.rows_per_split;
@@ -95,9 +107,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
   unsigned rowok = 0;
 
-  // branch-free fetch: rows past the split end are clamped to a valid row and zeroed by selects in commit()
-  const long r_last = (r_end > 0 ? r_end : 1) - 1;
+  // branch-free fetch: rows past the split end are clamped to the split's first row and zeroed by selects in
+  // commit().  The pair-grid decode (i = r % B, j = r / B) of the thread's first row is carried incrementally
+  // from slab to slab (one division per workgroup lifetime instead of four per slab).
   const int amc = a_ok ? am : 0, bnc = b_ok ? bn : 0;
+  const unsigned pB = (unsigned)p.pairB;
+  unsigned pi0 = 0, pj0 = 0;
+  if constexpr (TB == TB_PAIRSUM_RELU) {
+    const unsigned ru = (unsigned)(r_begin + rr);
+    pj0 = ru / pB;
+    pi0 = ru - pj0 * pB;
+  }
   auto fetch = [&](long k0) {
     rowok = 0;
 #pragma unroll
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
       long r = k0 + rr + 8 * q;
       const bool ok = r < r_end;
       rowok |= (ok ? 1u : 0u) << q;
-      r = ok ? r : r_last;
+      r = ok ? r : r_begin;
       ra[q] = ld4(p.A + r * p.lda + amc);
       if constexpr (TA == TA_DZ_ELEM) rg[q] = ld4(p.G + r * p.ldg + amc);
       if constexpr (TA == TA_DZ_ROWG) {
@@ -113,13 +133,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
         rg[q] = make_float4(g, g, g, g);
       }
       if constexpr (TB == TB_PAIRSUM_RELU) {
-        const unsigned ru = (unsigned)r;  // pair grid < 2^31 rows
-        const unsigned j = ru / (unsigned)p.pairB;
-        const unsigned i = ru - j * (unsigned)p.pairB;
+        unsigned i = pi0 + 8 * q, j = pj0;
+        while (i >= pB) {  // at most one iteration when B >= 24
+          i -= pB;
+          ++j;
+        }
+        i = ok ? i : 0;
+        j = ok ? j : 0;
         rb[q] = ld4(p.B + (long)i * p.ldb + bnc);
         rb2[q] = ld4(p.B2 + (long)j * p.ldb2 + bnc);
       } else {
         rb[q] = ld4(p.B + r * p.ldb + bnc);
+      }
+    }
+    if constexpr (TB == TB_PAIRSUM_RELU) {  // advance the carried decode by one slab
+      pi0 += BK;
+      while (pi0 >= pB) {
+        pi0 -= pB;
+        ++pj0;
       }
     }
   };

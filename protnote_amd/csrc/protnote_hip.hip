@@ -149,9 +149,17 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   const long tm = (p.M + Cfg::BM - 1) / Cfg::BM;
   const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
   if (tm * tn > 0x7fffffffL) return fail("gemm: grid too large");
+  GemmParams pp = p;
+  pp.xcd_order = (PN_XCD && tn % 8 == 0 && tm >= 16) ? 1 : 0;  // h = 3072 column tiles (24) over a tall grid
+  long grid = tm * tn;
+  if (pp.xcd_order) {
+    const long nblk8 = ((tm + 7) / 8) * (tn / 8);
+    grid = ((nblk8 + 7) / 8) * 8 * 64;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
   {
     ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tm * tn)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -1209,39 +1217,50 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
                        gr->dgamma[l], gr->dbeta[l], top ? gr->dw_out : (float*)nullptr);
     HIP_OK(hipGetLastError());
 
+    // dz_l materialised once, in place: over z_l itself for the top layer (its upstream gradient is the rank-1
+    // dl * w_out), over the incoming gradient buffer for inner layers.
+    float* dz;
+    {
+      DzParams dp;
+      memset(&dp, 0, sizeof(dp));
+      dp.R = R; dp.C = h; dp.rows_per_block = 512;
+      dp.Z = z; dp.ldz = h; dp.s = sv.s[l]; dp.t = sv.t[l]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q; dp.ldo = h;
+      const dim3 dg(nblk(h, 1024), nblk(R, 512));
+      if (top) {
+        dp.gvec = dl_pairs; dp.out = z; dz = z;
+        hipLaunchKernelGGL((k_dz_apply<1>), dg, dim3(256), 0, st, dp);
+      } else {
+        dp.G = G; dp.ldg = h; dp.out = const_cast<float*>(G); dz = const_cast<float*>(G);
+        hipLaunchKernelGGL((k_dz_apply<0>), dg, dim3(256), 0, st, dp);
+      }
+      HIP_OK(hipGetLastError());
+    }
+
     // dW_l = dz_l^T h_{l-1}
     TnParams tp = tn_zero();
     tp.R = R; tp.M = h; tp.N = h;
-    tp.A = z; tp.lda = h; tp.m_s = sv.s[l]; tp.m_t = sv.t[l]; tp.m_cs = w.cs; tp.m_p = w.p; tp.m_q = w.q;
-    if (top) tp.gvec = dl_pairs;
-    else { tp.G = G; tp.ldg = h; }
+    tp.A = dz; tp.lda = h;
     if (l == 1) {
       tp.B = sv.Ap; tp.ldb = h; tp.B2 = sv.Bp; tp.ldb2 = h; tp.pairB = B;
-      if (top) PN_OK((launch_tn<TA_DZ_ROWG, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
-      else PN_OK((launch_tn<TA_DZ_ELEM, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+      PN_OK((launch_tn<TA_PLAIN, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
     } else {
       tp.B = sv.zbuf[l - 1] + (size_t)S * h; tp.ldb = h; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
-      if (top) PN_OK((launch_tn<TA_DZ_ROWG, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
-      else PN_OK((launch_tn<TA_DZ_ELEM, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
+      PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
     }
 
-    // dh_{l-1} = dz_l W_l, written chunk by chunk over the part of zbuf[l] already consumed (ring)
+    // dh_{l-1} = dz_l W_l.  Inner layers: dz_l sits in the other buffer, so the result goes straight over the
+    // (now dead) z_l.  Top layer: dz_l sits in z_l's own buffer at row offset S, so the result is written chunk
+    // by chunk over the part already consumed (ring with one chunk of slack).
     PN_OK(transpose_into(hd->w[l], h, h, h, w.WT, h, st));
-    for (long r0 = 0; r0 < R; r0 += S) {
-      const long rows = (R - r0 < S) ? R - r0 : S;
+    const long step = top ? S : R;
+    for (long r0 = 0; r0 < R; r0 += step) {
+      const long rows = (R - r0 < step) ? R - r0 : step;
       GemmParams p = gp_zero();
       p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
-      p.A = z + (size_t)r0 * h; p.lda = h;
-      p.a_scale = sv.s[l]; p.a_shift = sv.t[l]; p.dz_cs = w.cs; p.dz_p = w.p; p.dz_q = w.q;
+      p.A = dz + (size_t)r0 * h; p.lda = h;
       p.W = w.WT; p.ldw = h;
       p.C = sv.zbuf[l] + (size_t)r0 * h; p.ldc = h;
-      if (top) {
-        p.gvec = dl_pairs + r0;
-        PN_OK((launch_gemm<A_DZ_ROWG, E_STORE>(p, 0, st)));
-      } else {
-        p.A2 = G + (size_t)r0 * h; p.lda2 = h;
-        PN_OK((launch_gemm<A_DZ_ELEM, E_STORE>(p, 0, st)));
-      }
+      PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
     }
     G = sv.zbuf[l];
   }

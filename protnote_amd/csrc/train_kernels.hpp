@@ -97,6 +97,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const StatsParams p) {
   }
 }
 
+// Materialise dz = (s*z+t > 0 ? g*cs : 0) + p + q*z for a whole layer in one streaming pass (g = G[r][c] or
+// gvec[r]); `out` may alias Z or G (pure element-wise).  Both backward GEMMs of the layer then read a plain
+// operand instead of regenerating dz per tile (it is consumed 24x by dW and 24x by dh).
+struct DzParams {
+  long R;
+  int C;
+  long rows_per_block;
+  const float* Z;
+  long ldz;
+  const float* G;
+  long ldg;
+  const float* gvec;
+  const float *s, *t, *cs, *p, *q;
+  float* out;
+  long ldo;
+};
+
+template <int ROWG>
+__global__ __launch_bounds__(256) void k_dz_apply(const DzParams P) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= P.C) return;
+  const float4 s = ld4(P.s + c), t = ld4(P.t + c), cs = ld4(P.cs + c), pp = ld4(P.p + c), q = ld4(P.q + c);
+  const long r0 = (long)blockIdx.y * P.rows_per_block;
+  long r1 = r0 + P.rows_per_block;
+  if (r1 > P.R) r1 = P.R;
+#pragma unroll 4
+  for (long r = r0; r < r1; ++r) {
+    const float4 z = ld4(P.Z + r * P.ldz + c);
+    float4 g;
+    if constexpr (ROWG) {
+      const float gr = P.gvec[r];
+      g = make_float4(gr, gr, gr, gr);
+    } else {
+      g = ld4(P.G + r * P.ldg + c);
+    }
+    float4 o;
+    o.x = (fmaf(z.x, s.x, t.x) > 0.f ? g.x * cs.x : 0.f) + fmaf(q.x, z.x, pp.x);
+    o.y = (fmaf(z.y, s.y, t.y) > 0.f ? g.y * cs.y : 0.f) + fmaf(q.y, z.y, pp.y);
+    o.z = (fmaf(z.z, s.z, t.z) > 0.f ? g.z * cs.z : 0.f) + fmaf(q.z, z.z, pp.z);
+    o.w = (fmaf(z.w, s.w, t.w) > 0.f ? g.w * cs.w : 0.f) + fmaf(q.w, z.w, pp.w);
+    *reinterpret_cast<float4*>(P.out + r * P.ldo + c) = o;
+  }
+}
+
 // From S1,S2: dgamma = S2, dbeta = S1 and the per-column vectors of the dz generator
 //   dz = (mask ? g*cs : 0) + p + q*z,   cs = s*(w or 1),  q = -s*invstd*S2/R,  p = -s*S1/R - q*mean
 // (s = gamma*invstd).  Without BatchNorm (gamma == nullptr): cs = (w or 1), p = q = 0, dbias = S1.
