@@ -84,7 +84,7 @@ struct GemmParams {
   const float* dz_cs;  // per-k vectors
   const float* dz_p;
   const float* dz_q;
-  int xcd_order;  // 1: XCD-aware 8x8 tile-block order (set by the launcher when the tile grid suits it)
+  int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -147,19 +147,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
 
   const int ntn = (p.Nstore + BN - 1) / BN;
   int tile_m, tile_n;
-  if (PN_XCD && p.xcd_order) {
+  if (PN_XCD && p.xcd_bc > 0) {
   // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and
-  // each XCD has its own 4 MB L2.  Give every XCD whole 8x8 blocks of output tiles, one block (= the 64
-  // workgroups resident on its 32 CUs) at a time: inside a block each A row-panel and each W column-panel is
-  // shared by 8 workgroups through that L2, and a row-panel is needed by ceil(ntn/8) XCDs instead of all 8.
+  // each XCD has its own 4 MB L2.  Give every XCD whole br x bc blocks of output tiles, one block (= the
+  // workgroups resident on its 32 CUs) at a time: inside a block each A row-panel is shared by bc and each W
+  // column-panel by br workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
   const int ntm = (p.M + BM - 1) / BM;
-  const int nbn = (ntn + 7) / 8;
-  const int nbm = (ntm + 7) / 8;
+  const int br = p.xcd_br, bc = p.xcd_bc, bsz = br * bc;
+  const int nbn = ntn / bc;
+  const int nbm = (ntm + br - 1) / br;
   const int xw = blockIdx.x >> 3;
-  const int gb = (xw >> 6) * 8 + (blockIdx.x & 7);
+  const int gb = (xw / bsz) * 8 + (blockIdx.x & 7);
   if (gb >= nbm * nbn) return;
-  tile_m = (gb / nbn) * 8 + ((xw & 63) >> 3);
-  tile_n = (gb % nbn) * 8 + (xw & 7);
+  const int r = xw % bsz;
+  tile_m = (gb / nbn) * br + r / bc;
+  tile_n = (gb % nbn) * bc + r % bc;
   if (tile_m >= ntm || tile_n >= ntn) return;
   } else {
   tile_n = blockIdx.x % ntn;

@@ -43,12 +43,16 @@ struct TnParams {
   long ldc;
 };
 
-template <int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
-  constexpr int BM = 128, BN = 128, BK = 32;
+// BIG = false: 128x128 output tile, 4 waves (2x2, each 64x64), 2 workgroups/CU.
+// BIG = true : 256x256 output tile, 8 waves (4x2, each 64x128), 1 workgroup/CU - half the operand traffic per flop.
+template <int TA, int TB, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnParams p) {
+  constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128, BK = 32;
+  constexpr int NGN = BIG ? 2 : 1;        // 64-column groups per wave along n
+  constexpr int C4 = BM / 4;              // float4 per tile row (BM == BN)
   constexpr int LDM = BM + 4, LDN = BN + 4;
   constexpr int STAGE = BK * (LDM + LDN);
-  constexpr int NQ = 4;  // (BK rows * 32 float4 per row) / 256 threads
+  constexpr int NQ = 4;  // (BK rows * C4 float4 per row) / threads
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   stagger_priority();
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves (small) or 4x2 waves (BIG)
 
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
@@ -79,8 +83,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   long r_end = r_begin + p.rows_per_split;
   if (r_end > p.R) r_end = p.R;
 
-  const int c4 = tid & 31;  // float4 column within the tile row
-  const int rr = tid >> 5;  // 0..7: tile row (k) within a pass
+  const int c4 = tid & (C4 - 1);  // float4 column within the tile row
+  const int rr = tid / C4;        // 0..7: tile row (k) within a pass
   const int am = m0 + 4 * c4;
   const int bn = n0 + 4 * c4;
   const bool a_ok = am < p.M;  // M, N are multiples of 4
@@ -197,11 +201,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2 * NGN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2 * NGN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -213,22 +217,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   // k-pair kk+1 are read before the MFMAs of k-pair kk so the LDS latency sits under the matrix pipe.
   auto compute = [&](int buf) {
     const float* As = smem + buf * STAGE + fk * LDM + wm * 64 + 2 * fcol;
-    const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 + 2 * fcol;
+    const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 * NGN + 2 * fcol;
     float2 a = *reinterpret_cast<const float2*>(As);
-    float2 b = *reinterpret_cast<const float2*>(Bs);
+    float2 b[NGN];
+#pragma unroll
+    for (int g = 0; g < NGN; ++g) b[g] = *reinterpret_cast<const float2*>(Bs + g * 64);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float2 na = a, nb = b;
+      float2 na = a, nb[NGN];
+#pragma unroll
+      for (int g = 0; g < NGN; ++g) nb[g] = b[g];
       if (kk + 1 < BK / 2) {
         na = *reinterpret_cast<const float2*>(As + (2 * kk + 2) * LDM);
-        nb = *reinterpret_cast<const float2*>(Bs + (2 * kk + 2) * LDN);
+#pragma unroll
+        for (int g = 0; g < NGN; ++g) nb[g] = *reinterpret_cast<const float2*>(Bs + (2 * kk + 2) * LDN + g * 64);
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NGN; ++g) {
+        acc[0][2 * g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[g].x, acc[0][2 * g], 0, 0, 0);
+        acc[0][2 * g + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[g].y, acc[0][2 * g + 1], 0, 0, 0);
+        acc[1][2 * g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[g].x, acc[1][2 * g], 0, 0, 0);
+        acc[1][2 * g + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[g].y, acc[1][2 * g + 1], 0, 0, 0);
+      }
       a = na;
-      b = nb;
+#pragma unroll
+      for (int g = 0; g < NGN; ++g) b[g] = nb[g];
     }
   };
 
@@ -254,17 +267,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
   const int hl = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int n = n0 + wn * 64 + 2 * fcol;  // columns n, n+1 <- tiles j = 0, 1
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * hl) + i;
-      if (m < p.M && n < p.N)  // N is a multiple of 4 and n is even: n + 1 < N as well
-        *reinterpret_cast<float2*>(out + (long)m * p.ldc + n) = make_float2(acc[i][0][e], acc[i][1][e]);
+    for (int g = 0; g < NGN; ++g) {
+      const int n = n0 + wn * 64 * NGN + g * 64 + 2 * fcol;  // columns n, n+1 <- tiles 2g, 2g+1
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * hl) + i;
+        if (m < p.M && n < p.N)  // N is a multiple of 4 and n is even: n + 1 < N as well
+          *reinterpret_cast<float2*>(out + (long)m * p.ldc + n) = make_float2(acc[i][2 * g][e], acc[i][2 * g + 1][e]);
+      }
     }
   }
 }
 
 constexpr int TN_LDS_BYTES = 2 * 32 * (132 + 132) * (int)sizeof(float);
+constexpr int TN_LDS_BYTES_BIG = 2 * 32 * (260 + 260) * (int)sizeof(float);
 
 // dst[m][n] (ld = ldd) = sum_s part[s][m][n] (ld = ldp)
 __global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, int M, int N, long ldp,

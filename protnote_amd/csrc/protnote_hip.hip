@@ -150,11 +150,15 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
   if (tm * tn > 0x7fffffffL) return fail("gemm: grid too large");
   GemmParams pp = p;
-  pp.xcd_order = (PN_XCD && tn % 8 == 0 && tm >= 16) ? 1 : 0;  // h = 3072 column tiles (24) over a tall grid
+  // XCD-aware block order for tall grids over h = 3072 columns: 64 (128x128 tiles, 2 workgroups/CU) or
+  // 32 (256x256 tiles, 1 workgroup/CU) workgroups are resident per XCD
+  const int resident = (Cfg::BM * Cfg::BN >= 256 * 256) ? 32 : 64;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  pp.xcd_br = pp.xcd_bc ? resident / pp.xcd_bc : 0;
   long grid = tm * tn;
-  if (pp.xcd_order) {
-    const long nblk8 = ((tm + 7) / 8) * (tn / 8);
-    grid = ((nblk8 + 7) / 8) * 8 * 64;
+  if (pp.xcd_bc) {
+    const long nblk = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk + 7) / 8) * 8 * resident;
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
   {
@@ -165,9 +169,17 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   return 0;
 }
 
-// variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64)
+// variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64);
+// variant 2: 256x256 tile (4x2 waves of 64x128, one workgroup per CU) - half the operand traffic per flop
+#ifndef PN_BIG
+#define PN_BIG 1
+#endif
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
+  if constexpr (EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) {
+    if (PN_BIG && variant == 0 && p.N % 256 == 0 && p.M >= 65536)
+      return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
+  }
   if (variant == 1) return launch_gemm_cfg<AK, EK, 4, 1, 1, 2, PN_BK>(p, st);
   return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK>(p, st);
 }
@@ -747,12 +759,13 @@ static int transpose_into(const float* src, long lds_, int rows, int cols, float
   return 0;
 }
 
-// choose the row split of a TN contraction: enough workgroups to fill 256 CUs x 2 several times over,
+// choose the row split of a TN contraction: enough workgroups to fill the chip several times over,
 // bounded by the partial-tile scratch the caller provided.
-static int tn_pick_split(long R, int M, int N, size_t part_cap_floats) {
-  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile, int resident_per_cu) {
+  const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   const long slabs = (R + 31) / 32;
-  long ns = (4608 + tiles - 1) / tiles;
+  const long target = 9L * 256 * resident_per_cu;  // ~9 full waves of resident workgroups
+  long ns = (target + tiles - 1) / tiles;
   if (ns > slabs / 8) ns = slabs / 8;
   if (ns < 1) ns = 1;
   const long cap = (long)(part_cap_floats / ((size_t)M * N));
@@ -761,19 +774,19 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats) {
   return (int)ns;
 }
 
-template <int TA, int TB>
-static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_kernel<TA, TB>;
+template <int TA, int TB, bool BIG>
+static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
+  auto kern = gemm_tn_kernel<TA, TB, BIG>;
+  constexpr int TILE = BIG ? 256 : 128;
+  constexpr int LDS = BIG ? TN_LDS_BYTES_BIG : TN_LDS_BYTES;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done[dev] = true;
   }
-  if (p.M % 4 || p.N % 4) return fail("gemm_tn: M and N must be multiples of 4");
-  if (p.R <= 0) return fail("gemm_tn: empty contraction");
-  int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats);
+  int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats, TILE, BIG ? 1 : 2);
   if (ns == 1) {
     p.Cpart = dst;
     p.ldc = ldd;
@@ -786,10 +799,10 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
     p.rows_per_split = (rps + 31) / 32 * 32;
     ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
   }
-  const unsigned tiles = (unsigned)(((p.M + 127) / 128) * ((p.N + 127) / 128));
+  const unsigned tiles = (unsigned)(((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE));
   {
     ProfScope ps(100 + TA * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
-    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(256), TN_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(BIG ? 512 : 256), LDS, st, p);
   }
   HIP_OK(hipGetLastError());
   if (ns > 1) {
@@ -800,6 +813,16 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
   return 0;
 }
 
+template <int TA, int TB>
+static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
+  if (p.M % 4 || p.N % 4) return fail("gemm_tn: M and N must be multiples of 4");
+  if (p.R <= 0) return fail("gemm_tn: empty contraction");
+  // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction)
+  if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536)
+    return launch_tn_cfg<TA, TB, true>(p, dst, ldd, part, part_cap_floats, st);
+  return launch_tn_cfg<TA, TB, false>(p, dst, ldd, part, part_cap_floats, st);
+}
+
 static TnParams tn_zero() {
   TnParams p;
   memset(&p, 0, sizeof(p));
@@ -807,7 +830,7 @@ static TnParams tn_zero() {
   return p;
 }
 
-static const size_t TN_PART_FLOATS_MAX = (size_t)8 * 3072 * 3072;
+static const size_t TN_PART_FLOATS_MAX = (size_t)16 * 3072 * 3072;
 
 // ------------------------------------------------------------------------------------------------
 // row MLP (W_p / W_l), train forward + backward
@@ -1051,7 +1074,7 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.WT = bp.take<float>(wt);
   w.weff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * d) : nullptr;
   w.dweff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * d) : nullptr;
-  w.part_floats = (size_t)8 * h * h < TN_PART_FLOATS_MAX ? (size_t)8 * h * h : TN_PART_FLOATS_MAX;
+  w.part_floats = (size_t)16 * h * h < TN_PART_FLOATS_MAX ? (size_t)16 * h * h : TN_PART_FLOATS_MAX;
   w.part = bp.take<float>(w.part_floats);
   w.dA1 = bp.take<float>((size_t)B * h);
   w.dB1 = bp.take<float>((size_t)NL * h);
