@@ -169,6 +169,7 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   return 0;
 }
 
+static int rowdot_nparts(int n);
 // variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64);
 // variant 2: 256x256 tile (4x2 waves of 64x128, one workgroup per CU) - half the operand traffic per flop
 #ifndef PN_BIG
@@ -180,8 +181,15 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
     if (PN_BIG && variant == 0 && p.N % 256 == 0 && p.M >= 65536)
       return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
   }
+  if constexpr (EK == E_ROWDOT) {  // partial-slab count depends on the tile: decided by N alone (rowdot_nparts)
+    if (PN_BIG && p.N % 256 == 0) return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
+  }
   if (variant == 1) return launch_gemm_cfg<AK, EK, 4, 1, 1, 2, PN_BK>(p, st);
   return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK>(p, st);
+}
+
+static int rowdot_nparts(int n) {  // column tiles x WAVES_N partial slabs written by the E_ROWDOT epilogue
+  return (PN_BIG && n % 256 == 0) ? (n / 256) * 2 : ((n + 127) / 128) * 2;
 }
 
 static int pick_variant(int n) {
@@ -582,7 +590,7 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
   const int nz = hd->nlayers >= 4 ? 2 : (hd->nlayers == 3 ? 1 : 0);
   w.z[0] = nz >= 1 ? bp.take<float>((size_t)crow * h) : nullptr;
   w.z[1] = nz >= 2 ? bp.take<float>((size_t)crow * h) : nullptr;
-  w.nparts = ((h + 127) / 128) * 2;  // variant 0: BN=128, WAVES_N=2
+  w.nparts = rowdot_nparts(h);
   w.partials = bp.take<float>((size_t)w.nparts * crow);
   for (int i = 0; i < hd->nlayers; ++i) {
     w.s[i] = bp.take<float>(h);
