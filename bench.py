@@ -128,8 +128,7 @@ def main():
     rank, local, world = init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", torch.cuda.current_device())  # set by init_from_env (LOCAL_RANK)
 
     model = build_model(dev)
     model.train()

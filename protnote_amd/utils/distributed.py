@@ -14,12 +14,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        # one process per GPU; PN_SHARE_GPU=1 lets several ranks share device 0 (single-GPU dry runs over gloo)
+        torch.cuda.set_device(0 if os.environ.get("PN_SHARE_GPU") == "1" else local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            backend = os.environ.get("PN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
     return rank, local, world
 
 
