@@ -43,8 +43,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // where cs/p/q are per-column vectors prepared by k_bn_bwd_finalize (cs = s, or s*w_out for the last
 // hidden layer whose upstream gradient is the rank-1 dlogit[r] * w_out[k]).
 //   A_DZ_ELEM: g = G[r][k] (stored gradient matrix);  A_DZ_ROWG: g = gvec[r] (one scalar per row).
-enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3, A_DZ_ELEM = 4, A_DZ_ROWG = 5 };
-enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3 };
+//   A_PAIRPROD: A[r % pairB][k] * A2[r / pairB][k]  (the P (.) L block of concatenation_prod, ProtNote.py:139-150)
+enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3, A_DZ_ELEM = 4, A_DZ_ROWG = 5, A_PAIRPROD = 6 };
+// E_PAIRADD: E_STORE plus the separable part of the first pair layer, out = acc + X1[r % pairB][n] + X2[r / pairB][n]
+enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3, E_PAIRADD = 4 };
 
 struct GemmParams {
   int M, N;          // output rows / true output columns
@@ -84,6 +86,10 @@ struct GemmParams {
   const float* dz_cs;  // per-k vectors
   const float* dz_p;
   const float* dz_q;
+  const float* padd1;  // E_PAIRADD
+  long ldp1;
+  const float* padd2;
+  long ldp2;
   int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
 };
 
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
   for (int q = 0; q < NQA; ++q) {
     int r = row0 + r_in + q * RPP;
     if (r > p.M - 1) r = p.M - 1;  // clamp: duplicates are discarded by the epilogue
-    if constexpr (AK == A_PAIRSUM_RELU) {
+    if constexpr (AK == A_PAIRSUM_RELU || AK == A_PAIRPROD) {
       const int j = r / p.pairB;
       const int i = r - j * p.pairB;
       arow[q] = p.A + (long)i * p.lda;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
 #pragma unroll
       for (int q = 0; q < NQA; ++q) {
         ra[q] = ld4(arow[q] + cc);
-        if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM) ra2[q] = ld4(arow2[q] + cc);
+        if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM || AK == A_PAIRPROD) ra2[q] = ld4(arow2[q] + cc);
       }
       avalid = kok ? 0xffffffffu : 0u;
       if constexpr (AK == A_AFFINE_RELU || AK == A_DZ_ELEM || AK == A_DZ_ROWG) {
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       pin4(ra[q]);
-      if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM) pin4(ra2[q]);
+      if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM || AK == A_PAIRPROD) pin4(ra2[q]);
     }
 #pragma unroll
     for (int q = 0; q < NQB; ++q) pin4(rb[q]);
@@ -294,6 +300,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
         v.y = relu(fmaf(v.y, rsc.y, rsh.y));
         v.z = relu(fmaf(v.z, rsc.z, rsh.z));
         v.w = relu(fmaf(v.w, rsc.w, rsh.w));
+      } else if constexpr (AK == A_PAIRPROD) {
+        v.x *= ra2[q].x;
+        v.y *= ra2[q].y;
+        v.z *= ra2[q].z;
+        v.w *= ra2[q].w;
       } else if constexpr (AK == A_PAIRSUM_RELU) {
         v.x = relu(v.x + ra2[q].x);
         v.y = relu(v.y + ra2[q].y);
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
   // ---------------- epilogue ----------------
   const int hl = lane >> 5;  // which 4-row group of each 8
   const int cl = lane & 31;
-  const bool want_stats = (EK == E_STORE || EK == E_CONV) && (p.col_sum != nullptr);
+  const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_sum != nullptr);
   float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
   if (want_stats) {
     for (int i = tid; i < 2 * BN; i += NTB) red[i] = 0.f;
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
     const bool cok = col < p.N;
     float s1 = 0.f, s2 = 0.f;
     float bj = 0.f, es = 0.f, et = 0.f, ew = 0.f, cs = 0.f;
-    if constexpr (EK == E_STORE || EK == E_CONV) {
+    if constexpr (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) {
       bj = (cok && p.bias) ? p.bias[col] : 0.f;
     }
     if constexpr (EK == E_ROWDOT) {
@@ -522,7 +533,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
         const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
         const bool rok = row < p.M;
         float v = acc[i][j][e];
-        if constexpr (EK == E_STORE) {
+        if constexpr (EK == E_PAIRADD) {
+          if (rok && cok) {
+            const int pj = row / p.pairB;
+            const int pi = row - pj * p.pairB;
+            v += bj + p.padd1[(long)pi * p.ldp1 + col] + p.padd2[(long)pj * p.ldp2 + col];
+            p.C[(long)row * p.ldc + col] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        } else if constexpr (EK == E_STORE) {
           v = cok ? v + bj : 0.f;
           if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
           if (rok) {

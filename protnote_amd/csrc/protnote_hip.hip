@@ -177,7 +177,8 @@ static int rowdot_nparts(int n);
 #endif
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
-  if constexpr (EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) {
+  if constexpr ((EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) ||
+                (EK == E_PAIRADD && AK == A_PAIRPROD)) {
     if (PN_BIG && variant == 0 && p.N % 256 == 0 && p.M >= 65536)
       return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
   }
@@ -587,7 +588,9 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
   w.A1 = bp.take<float>((size_t)B * h);
   w.B1 = bp.take<float>((size_t)NL * h);
   w.weff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * hd->d) : nullptr;
-  const int nz = hd->nlayers >= 4 ? 2 : (hd->nlayers == 3 ? 1 : 0);
+  // stored chunk activations: layers 2..n-1 (ping-pong), plus z1 itself for concatenation_prod
+  const int nstored = hd->nlayers - 2 + (hd->fusion == 2 ? 1 : 0);
+  const int nz = nstored >= 2 ? 2 : nstored;
   w.z[0] = nz >= 1 ? bp.take<float>((size_t)crow * h) : nullptr;
   w.z[1] = nz >= 2 ? bp.take<float>((size_t)crow * h) : nullptr;
   w.nparts = rowdot_nparts(h);
@@ -617,7 +620,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h, d = hd->d;
   if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 2..%d)", hd->nlayers, PN_MAX_LAYERS);
-  if (hd->fusion != 0 && hd->fusion != 1) return fail("pairhead: fusion %d not implemented", hd->fusion);
+  if (hd->fusion < 0 || hd->fusion > 2) return fail("pairhead: fusion %d not implemented", hd->fusion);
   if (d % 4 || h % 4) return fail("pairhead: d and h must be multiples of 4");
   const int chunk = clamp_chunk(label_chunk, NL);
   if ((long)chunk * B > 0x7fffffffL) return fail("pairhead: chunk too large");
@@ -642,41 +645,60 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
     p.M = NL; p.A = L_e; p.W = w1 + d; p.C = w.B1;
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
   }
+  if (hd->fusion == 2 && hd->nlayers - 1 > 2 && w.z[1] == nullptr) return fail("pairhead: internal z buffers");
   for (int i = 0; i < hd->nlayers; ++i) {
     if (hd->bn[i].weight != nullptr && hd->bias[i] != nullptr)
       return fail("pairhead: Linear bias together with BatchNorm is not supported");
     hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[i], hd->bias[i], hd->bn_eps, h,
                        h, w.s[i], w.t[i]);
   }
-  // A' = s1*A1 + t1, B' = s1*B1  =>  h1[i,j] = relu(A'[i] + B'[j])
-  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, w.A1, (long)h, w.A1, (long)h,
-                     (long)B, h, w.s[0], w.t[0]);
-  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.B1, (long)h, w.B1, (long)h,
-                     (long)NL, h, w.s[0], (const float*)nullptr);
-  HIP_OK(hipGetLastError());
+  const bool prod = hd->fusion == 2;
+  if (!prod) {
+    // A' = s1*A1 + t1, B' = s1*B1  =>  h1[i,j] = relu(A'[i] + B'[j])
+    hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, w.A1, (long)h, w.A1, (long)h,
+                       (long)B, h, w.s[0], w.t[0]);
+    hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.B1, (long)h, w.B1, (long)h,
+                       (long)NL, h, w.s[0], (const float*)nullptr);
+    HIP_OK(hipGetLastError());
+  }
 
   for (int j0 = 0; j0 < NL; j0 += chunk) {
     const int nj = (NL - j0 < chunk) ? NL - j0 : chunk;
     const long rows = (long)nj * B;
     const float* in = nullptr;
+    int zsel = 0;
+    if (prod) {
+      // concatenation_prod: z1 = A1[i] + B1[j] + (P_e[i] (.) L_e[j]) W1c^T  (not separable: one more pair GEMM)
+      GemmParams p = gp_zero();
+      p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = d;
+      p.A = P_e; p.lda = d; p.A2 = L_e + (long)j0 * d; p.lda2 = d; p.pairB = B;
+      p.W = hd->w[0] + 2 * d; p.ldw = hd->in_dim;
+      p.padd1 = w.A1; p.ldp1 = h; p.padd2 = w.B1 + (long)j0 * h; p.ldp2 = h;
+      p.C = w.z[zsel]; p.ldc = h;
+      PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
+      in = w.z[zsel];
+      zsel ^= 1;
+    }
     for (int li = 1; li < hd->nlayers; ++li) {
       const bool last = (li + 1 == hd->nlayers);
+      const bool from_pairs = (li == 1) && !prod;
       GemmParams p = gp_zero();
       p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
       p.W = hd->w[li]; p.ldw = h;
-      if (li == 1) {
+      if (from_pairs) {
         p.A = w.A1; p.lda = h; p.A2 = w.B1 + (long)j0 * h; p.lda2 = h; p.pairB = B;
       } else {
         p.A = in; p.lda = h; p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
       }
       if (last) {
         p.e_scale = w.s[li]; p.e_shift = w.t[li]; p.e_w = hd->w_out; p.rowdot_out = w.partials;
-        if (li == 1) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_ROWDOT>(p, 0, st)));
+        if (from_pairs) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_ROWDOT>(p, 0, st)));
         else PN_OK((launch_gemm<A_AFFINE_RELU, E_ROWDOT>(p, 0, st)));
       } else {
-        float* out = w.z[(li - 1) & 1];
+        float* out = w.z[zsel];
+        zsel ^= 1;
         p.C = out; p.ldc = h;
-        if (li == 1) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+        if (from_pairs) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
         else PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
         in = out;
       }
@@ -1111,7 +1133,8 @@ extern "C" size_t pn_pairhead_train_ws_bytes(const pn_pairhead* hd, int B, int N
 
 static int pair_check(const pn_pairhead* hd, int B, int NL) {
   if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported", hd->nlayers);
-  if (hd->fusion != 0 && hd->fusion != 1) return fail("pairhead: fusion %d not implemented", hd->fusion);
+  if (hd->fusion != 0 && hd->fusion != 1)
+    return fail("pairhead train: fusion %d (concatenation_prod) is implemented for inference only", hd->fusion);
   if (hd->d % 4 || hd->h % 4) return fail("pairhead: d and h must be multiples of 4");
   if ((long)B * NL > 0x7fffffffL) return fail("pairhead: pair grid too large");
   for (int l = 0; l < hd->nlayers; ++l) {

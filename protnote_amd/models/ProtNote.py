@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 
-_FUSION_ID = {"concatenation": 0, "concatenation_diff": 1}
+_FUSION_ID = {"concatenation": 0, "concatenation_diff": 1, "concatenation_prod": 2}
 
 
 def _row_mlp(in_channels, hidden_channels, bias, dropout):

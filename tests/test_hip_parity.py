@@ -107,7 +107,7 @@ def test_encoder_full_width_vs_oracle(B, Lmax, lens):
 
 
 # ----------------------------------------------------------------------------------------------- ProtNote eval
-@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "similarity"])
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "concatenation_prod", "similarity"])
 def test_protnote_eval_golden(golden_dir, fusion):
     g = _g(golden_dir, f"protnote_small_{fusion}.npz")
     model, _ = make_protnote(g, DEV)
@@ -190,3 +190,26 @@ def test_zero_shot_bucketed_padding_and_label_swap():
     ref_ec = O.protnote_forward(osd, torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float(), lens, ec,
                                 descriptions_per_label=2)
     assert ec_out.shape == (6, 11) and (ec_out - ref_ec).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("fusion", ["concatenation_diff", "concatenation_prod"])
+def test_pairhead_eval_fusion_variants_real_width(fusion):
+    """3d-wide first layer (P, L, P-L | P.L) at d=1024 / h=3072 against the oracle's materialised joint tensor."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(15)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3, in_mult=3)
+    B, NL = 9, 50
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f,
+                             fusion=fusion)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, feature_fusion=fusion)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    model.pair_label_chunk = 16
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    err = (out.cpu() - ref).abs().max().item()
+    assert ref.abs().max().item() > 0.5 and err < 5e-4, err
