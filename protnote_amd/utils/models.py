@@ -1,0 +1,61 @@
+"""On-disk formats around the hot path, so real ProtNote artefacts drop in:
+
+  * checkpoint dict {epoch, model_state_dict, optimizer_state_dict, best_val_metric}
+    (protnote/utils/models.py:304-321 save_checkpoint, :324-374 load_model incl. the DDP 'module.' prefix rule)
+  * cached label embeddings: `<name>.pt` = f32 tensor [N_desc, d] and `<name>_index.pt` = pandas DataFrame with
+    columns id, description_type, description, token_count (bin/generate_label_embeddings.py:123-164,
+    protnote/data/datasets.py:115-127) -> rows filtered/sorted by protnote_amd.data.labels.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ..data import labels as LB
+
+
+def save_checkpoint(model, optimizer, epoch, best_val_metric, model_path):
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict() if optimizer is not None else {},
+                "best_val_metric": best_val_metric}, model_path)
+
+
+def strip_ddp_prefix(state_dict):
+    """Keys saved from a DDP-wrapped model start with 'module.' (reference load_model :352-358)."""
+    keys = list(state_dict.keys())
+    if keys and keys[0].startswith("module."):
+        return OrderedDict((k[7:], v) for k, v in state_dict.items())
+    return state_dict
+
+
+def load_checkpoint_into(model, checkpoint_path: str, map_location="cpu", strict: bool = True):
+    """Load `model_state_dict` of a reference-format checkpoint into a protnote_amd (or reference) model.
+    Returns the rest of the checkpoint (epoch, optimizer_state_dict, best_val_metric)."""
+    ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+    model.load_state_dict(strip_ddp_prefix(ckpt["model_state_dict"]), strict=strict)
+    return {k: v for k, v in ckpt.items() if k != "model_state_dict"}
+
+
+def index_path_for(embedding_path: str) -> str:
+    """`a/b/emb.pt` -> `a/b/emb_index.pt` - same split-on-first-dot rule as the reference (datasets.py:115-118;
+    any other '.' in the path breaks it there too), but done on the file name only."""
+    head, dot, ext = embedding_path.rpartition(".")
+    return f"{head}_index.{ext}" if dot else embedding_path + "_index"
+
+
+def load_label_embedding_cache(embedding_path: str, label_vocabulary, descriptions=("name", "label")):
+    """-> (embeddings [M, d] f32 in vocabulary order with each label's descriptions on consecutive rows,
+           token_counts [M] i64, descriptions_per_label) for inference-time ensembling (ProtNote.py:313-322)."""
+    emb = torch.load(embedding_path, map_location="cpu", weights_only=False)
+    index = torch.load(index_path_for(embedding_path), map_location="cpu", weights_only=False)
+    ids = index["id"].astype(str).tolist()
+    types = index["description_type"].astype(str).tolist()
+    kept, span = LB.embedding_row_index(ids, types, list(label_vocabulary), list(descriptions))
+    missing = [l for l in label_vocabulary if l not in span]
+    if missing:
+        raise KeyError(f"{len(missing)} labels have no cached embedding, e.g. {missing[:3]}")
+    rows = LB.sorted_embedding_rows(span, list(label_vocabulary))
+    counts = np.asarray(index["token_count"].values)[kept][rows]
+    per_label = {span[l][1] - span[l][0] + 1 for l in label_vocabulary}
+    return (emb[torch.from_numpy(kept[rows])].float().contiguous(), torch.from_numpy(counts.astype(np.int64)),
+            per_label.pop() if len(per_label) == 1 else None)

@@ -450,12 +450,53 @@ def golden_bookkeeping():
     print("bookkeeping.npz", [k for k in out if k.startswith("test/") and "ex" not in k])
 
 
+def golden_tf_weights():
+    """utils/proteinfer.py:7-41 transfer_tf_weights_to_torch on a synthetic TF-variable pickle (TF layouts:
+    conv kernels [k, Cin, Cout], dense [in, out]); the pickle itself is the input fixture."""
+    import pickle
+    from collections import OrderedDict
+
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.utils.proteinfer import transfer_tf_weights_to_torch
+
+    rng = np.random.RandomState(3)
+    cfg = dict(num_labels=6, input_channels=20, output_channels=12, kernel_size=9, dilation_base=3,
+               num_resnet_blocks=2, bottleneck_factor=0.5)
+    C, Cb, k = 12, 6, 9
+    tf = OrderedDict()
+    tf["inferrer/conv1d/kernel:0"] = rng.randn(k, 20, C).astype(np.float32)
+    tf["inferrer/conv1d/bias:0"] = rng.randn(C).astype(np.float32)
+    n = 0
+    for blk in range(2):
+        for width, kk, cin, cout in ((C, k, C, Cb), (Cb, 1, Cb, C)):
+            pre = f"inferrer/residual_block_{blk}/batch_normalization_{n}/"
+            tf[pre + "gamma:0"] = rng.rand(width).astype(np.float32) + 0.5
+            tf[pre + "beta:0"] = rng.randn(width).astype(np.float32)
+            tf[pre + "moving_mean:0"] = rng.randn(width).astype(np.float32)
+            tf[pre + "moving_variance:0"] = rng.rand(width).astype(np.float32) + 0.5
+            tf[f"inferrer/residual_block_{blk}/conv1d_{n}/kernel:0"] = rng.randn(kk, cin, cout).astype(np.float32)
+            tf[f"inferrer/residual_block_{blk}/conv1d_{n}/bias:0"] = rng.randn(cout).astype(np.float32)
+            n += 1
+    tf["inferrer/logits/kernel:0"] = rng.randn(C, 6).astype(np.float32)
+    tf["inferrer/logits/bias:0"] = rng.randn(6).astype(np.float32)
+    tf["inferrer/global_step:0"] = np.int64(12345)
+    path = os.path.join(OUT, "tf_weights_small.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(tf, f)
+    model = ProteInfer(activation=torch.nn.ReLU, **cfg)
+    transfer_tf_weights_to_torch(model, path)
+    out = {"cfg_" + k_: np.array(v) for k_, v in cfg.items()}
+    out.update(sd_np(model, "sd/"))
+    np.savez_compressed(os.path.join(OUT, "tf_weights_small_expected.npz"), **out)
+    print("tf_weights_small.pkl + expected", len(out))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote, "losses": golden_losses_metrics,
-            "collator": golden_collator, "bookkeeping": golden_bookkeeping}
+            "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -213,3 +213,31 @@ def test_pairhead_eval_fusion_variants_real_width(fusion):
         out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
     err = (out.cpu() - ref).abs().max().item()
     assert ref.abs().max().item() > 0.5 and err < 5e-4, err
+
+
+def test_map_parity_full_width():
+    """mAP parity (BASELINE metric: 'mAP parity vs reference'): micro / macro average precision computed from
+    the HIP logits equals the one computed from the CPU-oracle logits on the same synthetic evaluation set
+    (full-width model, 96 sequences x 300 labels, targets drawn from the oracle's own probabilities so that AP
+    is far from the prevalence floor)."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.evaluation import map_macro, map_micro
+
+    gen = torch.Generator().manual_seed(31)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 96, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    y = (torch.rand(B, NL, generator=gen) < torch.sigmoid(2 * ref - 2)).numpy()
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    out = out.cpu().numpy()
+    mi_ref, ma_ref = map_micro(ref.numpy(), y), map_macro(ref.numpy(), y)
+    mi, ma = map_micro(out, y), map_macro(out, y)
+    assert 0.2 < mi_ref < 0.99
+    assert abs(mi - mi_ref) < 1e-4 and abs(ma - ma_ref) < 1e-4, (mi, mi_ref, ma, ma_ref)
