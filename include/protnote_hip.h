@@ -91,7 +91,7 @@ int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, int rows, flo
 typedef struct pn_pairhead {
   int d;        /* latent dim: P_e [B][d], L_e [NL][d] */
   int in_dim;   /* 2d (concatenation) or 3d (concatenation_diff / _prod) */
-  int fusion;   /* 0 concatenation, 1 concatenation_diff, 2 concatenation_prod (inference only) */
+  int fusion;   /* 0 concatenation, 1 concatenation_diff, 2 concatenation_prod */
   int nlayers;  /* hidden layers (>= 2) */
   int h;        /* hidden width */
   const float* w[PN_MAX_LAYERS];    /* w[0]: [h][in_dim]; w[i>0]: [h][h] */

@@ -13,7 +13,7 @@
 namespace pn {
 
 enum { TA_PLAIN = 0, TA_DZ_ELEM = 1, TA_DZ_ROWG = 2 };
-enum { TB_PLAIN = 0, TB_AFFINE_RELU = 1, TB_PAIRSUM_RELU = 2 };
+enum { TB_PLAIN = 0, TB_AFFINE_RELU = 1, TB_PAIRSUM_RELU = 2, TB_PAIRPROD = 3 };  // 3: B[r % pairB] * B2[r / pairB]
 
 struct TnParams {
   long R;               // contraction extent (rows)
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   const int amc = a_ok ? am : 0, bnc = b_ok ? bn : 0;
   const unsigned pB = (unsigned)p.pairB;
   unsigned pi0 = 0, pj0 = 0;
-  if constexpr (TB == TB_PAIRSUM_RELU) {
+  if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) {
     const unsigned ru = (unsigned)(r_begin + rr);
     pj0 = ru / pB;
     pi0 = ru - pj0 * pB;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         const float g = p.gvec[r];
         rg[q] = make_float4(g, g, g, g);
       }
-      if constexpr (TB == TB_PAIRSUM_RELU) {
+      if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) {
         unsigned i = pi0 + 8 * q, j = pj0;
         while (i >= pB) {  // at most one iteration when B >= 24
           i -= pB;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         rb[q] = ld4(p.B + r * p.ldb + bnc);
       }
     }
-    if constexpr (TB == TB_PAIRSUM_RELU) {  // advance the carried decode by one slab
+    if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) {  // advance the carried decode by one slab
       pi0 += BK;
       while (pi0 >= pB) {
         pi0 -= pB;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
       pin4(ra[q]);
       pin4(rb[q]);
       if constexpr (TA != TA_PLAIN) pin4(rg[q]);
-      if constexpr (TB == TB_PAIRSUM_RELU) pin4(rb2[q]);
+      if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) pin4(rb2[q]);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -190,6 +190,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         b.y = relu(fmaf(b.y, bs.y, bt.y));
         b.z = relu(fmaf(b.z, bs.z, bt.z));
         b.w = relu(fmaf(b.w, bs.w, bt.w));
+      } else if constexpr (TB == TB_PAIRPROD) {
+        b.x *= rb2[q].x;
+        b.y *= rb2[q].y;
+        b.z *= rb2[q].z;
+        b.w *= rb2[q].w;
       } else if constexpr (TB == TB_PAIRSUM_RELU) {
         b.x = relu(b.x + rb2[q].x);
         b.y = relu(b.y + rb2[q].y);

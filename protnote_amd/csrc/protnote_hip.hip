@@ -1076,7 +1076,7 @@ static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& 
     s.mean[l] = bp.take<float>(h);
     s.invstd[l] = bp.take<float>(h);
   }
-  s.zbuf[0] = nullptr;
+  s.zbuf[0] = hd->fusion == 2 ? bp.take<float>((size_t)(R + S) * h) : nullptr;  // concatenation_prod stores z1 too
   for (int l = 1; l < hd->nlayers; ++l) s.zbuf[l] = bp.take<float>((size_t)(R + S) * h);
   return bp.ok;
 }
@@ -1133,8 +1133,7 @@ extern "C" size_t pn_pairhead_train_ws_bytes(const pn_pairhead* hd, int B, int N
 
 static int pair_check(const pn_pairhead* hd, int B, int NL) {
   if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported", hd->nlayers);
-  if (hd->fusion != 0 && hd->fusion != 1)
-    return fail("pairhead train: fusion %d (concatenation_prod) is implemented for inference only", hd->fusion);
+  if (hd->fusion < 0 || hd->fusion > 2) return fail("pairhead: fusion %d not implemented", hd->fusion);
   if (hd->d % 4 || hd->h % 4) return fail("pairhead: d and h must be multiples of 4");
   if ((long)B * NL > 0x7fffffffL) return fail("pairhead: pair grid too large");
   for (int l = 0; l < hd->nlayers; ++l) {
@@ -1177,6 +1176,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     w1 = w.weff;
     ldw1 = 2 * d;
   }
+  const bool prod = hd->fusion == 2;
+  if (prod) ldw1 = hd->in_dim;
   HIP_OK(hipMemsetAsync(w.sumA, 0, 4 * al256(h * sizeof(double)), st));  // sumA, sqA, sumB, sqB are contiguous
   {
     GemmParams p = gp_zero();
@@ -1187,14 +1188,32 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     p.M = NL; p.A = L_e; p.W = w1 + d; p.C = sv.B1; p.col_sum = w.sumB; p.col_sumsq = w.sqB;
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
   }
-  hipLaunchKernelGGL(k_bn_fold_pair, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.sumA,
-                     (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL,
-                     hd->bn_eps, hd->bn_momentum, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]);
-  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, (const float*)sv.A1, (long)h,
-                     sv.Ap, (long)h, (long)B, h, (const float*)sv.s[0], (const float*)sv.t[0]);
-  hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, (const float*)sv.B1, (long)h,
-                     sv.Bp, (long)h, (long)NL, h, (const float*)sv.s[0], (const float*)nullptr);
-  HIP_OK(hipGetLastError());
+  if (!prod) {
+    hipLaunchKernelGGL(k_bn_fold_pair, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.sumA,
+                       (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL,
+                       hd->bn_eps, hd->bn_momentum, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]);
+    hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, (const float*)sv.A1, (long)h,
+                       sv.Ap, (long)h, (long)B, h, (const float*)sv.s[0], (const float*)sv.t[0]);
+    hipLaunchKernelGGL(k_affine_rows, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, (const float*)sv.B1, (long)h,
+                       sv.Bp, (long)h, (long)NL, h, (const float*)sv.s[0], (const float*)nullptr);
+    HIP_OK(hipGetLastError());
+  } else {
+    // concatenation_prod: z1 = A1[i] + B1[j] + (P_e[i] (.) L_e[j]) W1c^T is not separable -> one more pair GEMM
+    // whose output is stored, with BatchNorm statistics taken directly over the grid
+    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
+    GemmParams p = gp_zero();
+    p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = d;
+    p.A = P_e; p.lda = d; p.A2 = L_e; p.lda2 = d; p.pairB = B;
+    p.W = hd->w[0] + 2 * d; p.ldw = hd->in_dim;
+    p.padd1 = sv.A1; p.ldp1 = h; p.padd2 = sv.B1; p.ldp2 = h;
+    p.C = sv.zbuf[0] + (size_t)S * h; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
+    PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
+    hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.S1,
+                       (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[0], sv.t[0],
+                       sv.mean[0], sv.invstd[0]);
+    HIP_OK(hipGetLastError());
+  }
 
   for (int l = 1; l < n; ++l) {
     float* z = sv.zbuf[l] + (size_t)S * h;
@@ -1203,7 +1222,7 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     GemmParams p = gp_zero();
     p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
     p.W = hd->w[l]; p.ldw = h; p.C = z; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
-    if (l == 1) {
+    if (l == 1 && !prod) {
       p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
       PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
     } else {
@@ -1294,7 +1313,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     TnParams tp = tn_zero();
     tp.R = R; tp.M = h; tp.N = h;
     tp.A = dz; tp.lda = h;
-    if (l == 1) {
+    if (l == 1 && hd->fusion != 2) {
       tp.B = sv.Ap; tp.ldb = h; tp.B2 = sv.Bp; tp.ldb2 = h; tp.pairB = B;
       PN_OK((launch_tn<TA_PLAIN, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
     } else {
@@ -1319,10 +1338,13 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     G = sv.zbuf[l];
   }
 
-  // ---- layer 0 (separable): z1[i,j] = A1[i] + B1[j], upstream gradient G = dh_0 over the pair grid ----
+  // ---- layer 0: upstream gradient G = dh_0 over the pair grid ----
   HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
   HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
-  {
+  const bool prod = hd->fusion == 2;
+  float* dQ = nullptr;  // concatenation_prod: gradient wrt the P (.) L block, [R][d]
+  if (!prod) {
+    // separable: z1[i,j] = A1[i] + B1[j] is regenerated, never stored
     StatsParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.R = R; sp.C = h; sp.rows_per_block = stats_rows;
@@ -1344,6 +1366,44 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     rp.out = w.dA1;
     hipLaunchKernelGGL((k_pair_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
     HIP_OK(hipGetLastError());
+  } else {
+    // concatenation_prod: z1 is stored; dz1 is materialised over G, then summed / contracted
+    float* z0 = sv.zbuf[0] + (size_t)S * h;
+    StatsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.R = R; sp.C = h; sp.rows_per_block = stats_rows; sp.pairB = 1;
+    sp.Z = z0; sp.ldz = h; sp.G = G; sp.ldg = h;
+    sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
+    sp.S1 = w.S1; sp.S2 = w.S2;
+    hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
+                       (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
+                       (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
+                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr);
+    DzParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.R = R; dp.C = h; dp.rows_per_block = 512;
+    dp.Z = z0; dp.ldz = h; dp.G = G; dp.ldg = h; dp.s = sv.s[0]; dp.t = sv.t[0]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q;
+    float* dz0 = const_cast<float*>(G);
+    dp.out = dz0; dp.ldo = h;
+    hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(h, 1024), nblk(R, 512)), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL((k_pair_sum<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, (const float*)dz0, (long)h, B, NL, h,
+                       (const float*)nullptr, 0L, w.dB1, (long)h, 0);
+    hipLaunchKernelGGL((k_pair_sum<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, (const float*)dz0, (long)h, B, NL, h,
+                       (const float*)nullptr, 0L, w.dA1, (long)h, 0);
+    HIP_OK(hipGetLastError());
+    // dW1c[n][k] = sum_r dz1[r][n] * P_e[i][k] * L_e[j][k]
+    TnParams tp = tn_zero();
+    tp.R = R; tp.M = h; tp.N = d; tp.A = dz0; tp.lda = h;
+    tp.B = P_e; tp.ldb = d; tp.B2 = L_e; tp.ldb2 = d; tp.pairB = B;
+    PN_OK((launch_tn<TA_PLAIN, TB_PAIRPROD>(tp, gr->dw[0] + 2 * d, hd->in_dim, w.part, w.part_floats, st)));
+    // dQ = dz1 W1c  ([R][d], over the dead z1 buffer)
+    dQ = sv.zbuf[0];
+    PN_OK(transpose_into(hd->w[0] + 2 * d, hd->in_dim, h, d, w.WT, h, st));  // WT[d][h]
+    GemmParams p = gp_zero();
+    p.M = (int)R; p.N = d; p.Nstore = d; p.Kseg = h;
+    p.A = dz0; p.lda = h; p.W = w.WT; p.ldw = h; p.C = dQ; p.ldc = d;
+    PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
   }
   // dW_0: [h][in_dim];  concatenation: [dA1^T P_e | dB1^T L_e]
   float* dwa = hd->fusion == 1 ? w.dweff : gr->dw[0];
@@ -1374,6 +1434,14 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     p.M = side == 0 ? B : NL; p.N = d; p.Nstore = d; p.Kseg = h;
     p.A = side == 0 ? w.dA1 : w.dB1; p.lda = h; p.W = w.WT; p.ldw = h; p.C = out; p.ldc = d;
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+  }
+  if (prod) {
+    // dP_e[i] += sum_j dQ[i,j] (.) L_e[j],   dL_e[j] += sum_i dQ[i,j] (.) P_e[i]
+    if (dP_e) hipLaunchKernelGGL((k_pair_sum<1>), dim3(nblk(d, 1024), B), dim3(256), 0, st, (const float*)dQ, (long)d,
+                                 B, NL, d, L_e, (long)d, dP_e, (long)d, 1);
+    if (dL_e) hipLaunchKernelGGL((k_pair_sum<0>), dim3(nblk(d, 1024), NL), dim3(256), 0, st, (const float*)dQ, (long)d,
+                                 B, NL, d, P_e, (long)d, dL_e, (long)d, 1);
+    HIP_OK(hipGetLastError());
   }
   return 0;
 }

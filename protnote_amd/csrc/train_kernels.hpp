@@ -242,6 +242,46 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const PairRedParams P) {
       make_float4((float)d0, (float)d1, (float)d2, (float)d3);
 }
 
+// plain reductions of a stored pair-grid matrix X[r = j*B + i][c] (concatenation_prod backward):
+//   MODE 0: out[j][c] (+)= sum_i X[r][c] * (mul ? mul[i][c] : 1)     grid (C/1024, NL)
+//   MODE 1: out[i][c] (+)= sum_j X[r][c] * (mul ? mul[j][c] : 1)     grid (C/1024, B)
+// `accumulate` adds to what out already holds (the dense-GEMM part of the same gradient).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ X, long ldx, int B, int NL, int C,
+                                                   const float* __restrict__ mul, long ldm, float* __restrict__ out,
+                                                   long ldo, int accumulate) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int fixed = blockIdx.y;
+  const int n = MODE == 0 ? B : NL;
+  double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int cnt = 0;
+#pragma unroll 4
+  for (int k = 0; k < n; ++k) {
+    const long r = MODE == 0 ? (long)fixed * B + k : (long)k * B + fixed;
+    float4 x = ld4(X + r * ldx + c);
+    if (mul) {
+      const float4 m = ld4(mul + (long)k * ldm + c);
+      x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+    }
+    a0 += x.x; a1 += x.y; a2 += x.z; a3 += x.w;
+    if (++cnt == 256) {
+      d0 += a0; d1 += a1; d2 += a2; d3 += a3;
+      a0 = a1 = a2 = a3 = 0.f;
+      cnt = 0;
+    }
+  }
+  d0 += a0; d1 += a1; d2 += a2; d3 += a3;
+  float4* o = reinterpret_cast<float4*>(out + (long)fixed * ldo + c);
+  float4 v = make_float4((float)d0, (float)d1, (float)d2, (float)d3);
+  if (accumulate) {
+    const float4 old = *o;
+    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+  }
+  *o = v;
+}
+
 // logits of the pair grid from the stored last pre-activation: out[r] = b + sum_c relu(s*z[r][c]+t) * w[c];
 // one wave per row.
 __global__ __launch_bounds__(256) void k_rowdot_rows(const float* __restrict__ Z, long ldz, long R, int C,

@@ -82,7 +82,7 @@ def _freeze_encoder(model):
             p.requires_grad = False
 
 
-@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "similarity"])
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "concatenation_prod", "similarity"])
 @pytest.mark.parametrize("loss", ["BCE", "FocalLoss"])
 def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
     from protnote_amd.utils.losses import get_loss
