@@ -110,6 +110,17 @@ size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label
 int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
                          float* logits_pairs, int label_chunk, void* ws, size_t ws_bytes, void* stream);
 
+/* save_embeddings path (ProtNote.py:294-302): also returns the penultimate activations relu(bn(z_last)) of the
+ * output MLP, hidden_pairs [NL*B][h] on the label-major pair grid (small evaluation subsets only). */
+size_t pn_pairhead_hidden_ws_bytes(const pn_pairhead* hd, int B, int NL);
+int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                                float* logits_pairs, float* hidden_pairs, void* ws, size_t ws_bytes, void* stream);
+
+/* ProtNote.additive_attention (ProtNote.py:154-166), inference: hidden [N][T][d] token embeddings,
+ * attention_mask [N][T] i64, raw_attn_scorer weight [d] / bias [1] -> out [N][d]. */
+int pn_additive_attention(const float* hidden, const int64_t* attention_mask, const float* w, const float* b, int N,
+                          int T, int d, float* out, void* stream);
+
 /* ProtNote.py:308-322: pair logits for NL = n_out*ndesc description rows (consecutive rows = one label)
  * -> out[B][n_out];  ndesc == 1: plain re-layout;  else logit(mean_d sigmoid(x), eps=1e-7).
  * protein_major = 0: input is the label-major pair grid x[j*B + i]; 1: input is x[i*NL + j]. */

@@ -69,6 +69,11 @@ _SIGS = {
     "pn_pairhead_eval_ws_bytes": (C.c_size_t, [C.POINTER(pn_pairhead), C.c_int, C.c_int, C.c_int]),
     "pn_pairhead_fwd_eval": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_pairhead_hidden_ws_bytes": (C.c_size_t, [C.POINTER(pn_pairhead), C.c_int, C.c_int]),
+    "pn_pairhead_fwd_eval_hidden": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_additive_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
     "pn_ensemble_logit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_label_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),

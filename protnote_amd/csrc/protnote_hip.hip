@@ -1606,3 +1606,99 @@ extern "C" int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int 
   HIP_OK(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// save_embeddings path (ProtNote.py:294-302): logits AND the penultimate activations of the output MLP
+// ------------------------------------------------------------------------------------------------
+__global__ void k_affine_relu_rows(const float* __restrict__ z, long ldz, float* __restrict__ out, long ldo, long rows,
+                                   int cols, const float* __restrict__ s, const float* __restrict__ t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i - r * cols);
+  out[r * ldo + c] = fmaxf(fmaf(z[r * ldz + c], s[c], t[c]), 0.f);
+}
+
+extern "C" size_t pn_pairhead_hidden_ws_bytes(const pn_pairhead* hd, int B, int NL) {
+  const size_t rh = (size_t)B * NL * hd->h * sizeof(float);
+  return pn_pairhead_eval_ws_bytes(hd, B, NL, NL) + 2 * al256(rh) + 4096;
+}
+
+// hidden_pairs[r][h] (r = j*B + i) = relu(bn(z_last)), logits_pairs[r] = hidden . w_out + b_out; eval-mode BN.
+// Meant for the small subsets the reference saves embeddings for (the full [B*NL, h] tensor is materialised).
+extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
+                                           float* logits_pairs, float* hidden_pairs, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int h = hd->h;
+  const long R = (long)B * NL;
+  if (hd->nlayers < 2) return fail("pairhead hidden: nlayers < 2 unsupported");
+  // Run the eval head with one layer fewer and a unit "output neuron" trick is not possible (the row-dot epilogue
+  // never stores), so: layers 1..n-2 through the normal path into a scratch z, the last hidden layer stored too.
+  const size_t base = pn_pairhead_eval_ws_bytes(hd, B, NL, NL);
+  if (ws_bytes < base + 2 * al256((size_t)R * h * sizeof(float))) return fail("pairhead hidden: workspace too small");
+  float* zlast = (float*)((char*)ws + al256(base));
+  // 1) logits (also prepares A', B', the folded BN vectors and, for n >= 3, z_{n-2} of the single chunk in ws)
+  PN_OK(pn_pairhead_fwd_eval(hd, P_e, L_e, B, NL, logits_pairs, NL, ws, base, stream));
+  // 2) recompute the last hidden pre-activation with a storing epilogue
+  Bump bp(ws, base);
+  PairWs w;
+  if (!pair_carve(hd, B, NL, NL, bp, w)) return fail("pairhead hidden: workspace carve failed");
+  const int li = hd->nlayers - 1;
+  const bool prod = hd->fusion == 2;
+  GemmParams p = gp_zero();
+  p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
+  p.W = hd->w[li]; p.ldw = h; p.C = zlast; p.ldc = h;
+  if (li == 1 && !prod) {
+    p.A = w.A1; p.lda = h; p.A2 = w.B1; p.lda2 = h; p.pairB = B;
+    PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+  } else {
+    // the stored input of the last layer: ping-pong position after (li - 1) [+1 for prod] stores
+    const int nstores = (li - 1) + (prod ? 1 : 0);
+    p.A = w.z[(nstores - 1) & 1]; p.lda = h; p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
+    PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+  }
+  hipLaunchKernelGGL(k_affine_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)zlast, (long)h,
+                     hidden_pairs, (long)h, R, h, (const float*)w.s[li], (const float*)w.t[li]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// additive attention pooling over label tokens (ProtNote.py:154-166), inference:
+//   out[n][:] = sum_t softmax_t(mask ? w.h[n][t] + b : -inf) * h[n][t][:]
+// one workgroup per label
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_additive_attention(const float* __restrict__ hid, const int64_t* __restrict__ mask,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            int T, int d, float* __restrict__ out) {
+  extern __shared__ float sc[];  // [T] scores
+  const int n = blockIdx.x;
+  const float* hn = hid + (long)n * T * d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < T; t += 4) {
+    float a = 0.f;
+    for (int c = lane; c < d; c += 64) a = fmaf(hn[(long)t * d + c], w[c], a);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) sc[t] = mask[(long)n * T + t] != 0 ? a + b[0] : -INFINITY;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+  float den = 0.f;
+  for (int t = 0; t < T; ++t) den += expf(sc[t] - mx);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = fmaf(expf(sc[t] - mx) / den, hn[(long)t * d + c], acc);
+    out[(long)n * d + c] = acc;
+  }
+}
+
+extern "C" int pn_additive_attention(const float* hidden, const int64_t* attention_mask, const float* w,
+                                     const float* b, int N, int T, int d, float* out, void* stream) {
+  if (T <= 0 || T > 8192) return fail("additive_attention: unsupported token count %d", T);
+  hipLaunchKernelGGL(k_additive_attention, dim3(N), dim3(256), T * sizeof(float), (hipStream_t)stream, hidden,
+                     attention_mask, w, b, T, d, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

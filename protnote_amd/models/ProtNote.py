@@ -211,6 +211,43 @@ class ProtNote(nn.Module):
         del keep
         return pairs  # label-major pair grid: pairs[j*B + i]
 
+    def _pairhead_eval_with_embeddings(self, P_e, L_e):
+        """save_embeddings=True (reference ProtNote.py:294-302,326-332): besides the logits, return the joint
+        embeddings and the penultimate output-MLP activations as CPU tensors in the reference's protein-major
+        row order (row = i * N_L + j).  Small evaluation subsets only: [B*N_L, 3072] is materialised."""
+        hd, keep = self._pair_desc()
+        B, NL = P_e.shape[0], L_e.shape[0]
+        lib = L.lib()
+        ws = L.workspace(lib.pn_pairhead_hidden_ws_bytes(C.byref(hd), B, NL), P_e.device, "pair")
+        pairs = torch.empty(NL * B, dtype=torch.float32, device=P_e.device)
+        hidden = torch.empty(NL, B, hd.h, dtype=torch.float32, device=P_e.device)
+        L.check(lib.pn_pairhead_fwd_eval_hidden(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), L.ptr(hidden),
+                                                L.ptr(ws), ws.numel(), L.stream_ptr()))
+        del keep
+        pe, le = P_e.cpu(), L_e.cpu()
+        joint = torch.cat([pe[:, None, :].expand(B, NL, -1), le[None, :, :].expand(B, NL, -1)], dim=2)
+        joint = joint.reshape(B * NL, -1)
+        d = pe.shape[1]
+        if self.feature_fusion == "concatenation_diff":
+            joint = torch.cat([joint, joint[:, :d] - joint[:, d:]], dim=-1)
+        if self.feature_fusion == "concatenation_prod":
+            joint = torch.cat([joint, joint[:, :d] * joint[:, d:]], dim=-1)
+        out_emb = hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu()
+        return pairs, {"output_layer_embeddings": out_emb, "joint_embeddings": joint}
+
+    def additive_attention(self, hidden_states, attention_mask):
+        """Reference ProtNote.additive_attention (ProtNote.py:154-166), inference: masked-softmax attention pooling of
+        token embeddings [N, T, d] with the raw_attn_scorer Linear(d, 1)."""
+        L.require_hip(hidden_states, attention_mask)
+        hs = hidden_states.detach().float().contiguous()
+        mask = attention_mask.to(device=hs.device, dtype=torch.int64).contiguous()
+        N, T, d = hs.shape
+        out = torch.empty(N, d, dtype=torch.float32, device=hs.device)
+        L.check(L.lib().pn_additive_attention(L.ptr(hs), L.ptr(mask), L.ptr(self.raw_attn_scorer.weight.detach()),
+                                              L.ptr(self.raw_attn_scorer.bias.detach()), N, T, d, L.ptr(out),
+                                              L.stream_ptr()))
+        return out
+
     def _similarity(self, P_e, L_e):
         B, NL, d = P_e.shape[0], L_e.shape[0], P_e.shape[1]
         lib = L.lib()
@@ -249,10 +286,12 @@ class ProtNote(nn.Module):
             raise ValueError("Incompatible label parameters passed to forward method.")
         L.require_hip(L_f)
         if self.label_embedding_pooling_method == "all":
-            raise NotImplementedError("LABEL_EMBEDDING_POOLING_METHOD='all' (additive attention) is not implemented")
-        if save_embeddings:
-            raise NotImplementedError("save_embeddings=True would materialise the [B*N_L, 2d] joint tensor, "
-                                      "which protnote_amd never builds")
+            if self.training:
+                raise NotImplementedError("training raw_attn_scorer (LABEL_EMBEDDING_POOLING_METHOD='all') is not "
+                                          "implemented; inference is")
+            L_f = self.additive_attention(L_f, tokenized_labels["attention_mask"])
+        if save_embeddings and (self.training or not self.feature_fusion.startswith("concatenation")):
+            raise NotImplementedError("save_embeddings=True is implemented for inference with the concatenation heads")
 
         with torch.autocast(device_type="cuda", enabled=False):  # kernels are f32; ignore AMP (ProtNoteTrainer.py:728)
             if self.training and torch.is_grad_enabled():
@@ -285,6 +324,9 @@ class ProtNote(nn.Module):
                     if ndesc != 1:
                         logits = self._ensemble(logits, B, NL, ndesc, protein_major=True)
                 elif self.feature_fusion.startswith("concatenation"):
+                    if save_embeddings:
+                        pairs, embeddings = self._pairhead_eval_with_embeddings(P_e, L_e)
+                        return self._ensemble(pairs, B, NL, ndesc), embeddings
                     pairs = self._pairhead_eval(P_e, L_e)
                     logits = self._ensemble(pairs, B, NL, ndesc)
                 else:

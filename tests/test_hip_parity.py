@@ -241,3 +241,47 @@ def test_map_parity_full_width():
     mi, ma = map_micro(out, y), map_macro(out, y)
     assert 0.2 < mi_ref < 0.99
     assert abs(mi - mi_ref) < 1e-4 and abs(ma - ma_ref) < 1e-4, (mi, mi_ref, ma, ma_ref)
+
+
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_prod"])
+def test_save_embeddings_and_attention_pooling(golden_dir, fusion):
+    """save_embeddings=True returns the reference's joint / penultimate tensors (protein-major rows) and
+    LABEL_EMBEDDING_POOLING_METHOD='all' pools token embeddings with the additive attention of ProtNote.py:154-166."""
+    import torch.nn.functional as F
+
+    g = _g(golden_dir, f"protnote_small_{fusion}.npz")
+    model, sd = make_protnote(g, DEV)
+    model.eval()
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])
+    with torch.no_grad():
+        logits, emb = model(sequence_onehots=x.to(DEV), sequence_lengths=lens.to(DEV), label_embeddings=lab.to(DEV),
+                            save_embeddings=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["eval/logits_raw"], atol=5e-4, rtol=1e-4)
+    # oracle: penultimate activations of the output MLP on the materialised joint tensor
+    P_e, L_e = torch.from_numpy(g["eval/P_e"]), torch.from_numpy(g["eval/L_e"])
+    joint = O.joint_embeddings(P_e, L_e, fusion)
+    np.testing.assert_allclose(emb["joint_embeddings"].numpy(), joint.numpy(), atol=1e-4, rtol=1e-4)
+    hsd = {k: v.clone() for k, v in sd.items()}
+    hid = joint
+    lin = O._linear_indices(hsd, "output_layer.")
+    for i in lin[:-1]:
+        hid = F.relu(O._bn(F.linear(hid, hsd[f"output_layer.{i}.weight"]), hsd, f"output_layer.{i + 1}.", False, 1e-5, 0.1))
+    assert emb["output_layer_embeddings"].shape == hid.shape
+    np.testing.assert_allclose(emb["output_layer_embeddings"].numpy(), hid.numpy(), atol=5e-4, rtol=1e-3)
+
+    # additive attention pooling
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(4)
+    m2 = ProtNote(protein_embedding_dim=8, label_embedding_dim=24, latent_dim=8, label_embedding_pooling_method="all",
+                  output_mlp_hidden_dim_scale_factor=2, output_mlp_num_layers=2, projection_head_num_layers=2,
+                  projection_head_hidden_dim_scale_factor=2).to(DEV).eval()
+    hs = torch.randn(7, 11, 24, generator=gen)
+    mask = (torch.rand(7, 11, generator=gen) < 0.7).long()
+    mask[:, 0] = 1
+    w, b = m2.raw_attn_scorer.weight.detach().cpu(), m2.raw_attn_scorer.bias.detach().cpu()
+    scores = (hs @ w.T).squeeze(-1) + b
+    ref = torch.bmm(torch.softmax(scores.masked_fill(mask == 0, float("-inf")), -1).unsqueeze(1), hs).squeeze(1)
+    out = m2.additive_attention(hs.to(DEV), mask.to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
