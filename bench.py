@@ -37,7 +37,7 @@ KIND_NAMES = {
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 
 
-def build_model(device, seed=42):
+def build_model(device, seed=42, unit_scale_weights=False):
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.protein_encoders import ProteInfer
 
@@ -57,6 +57,10 @@ def build_model(device, seed=42):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
                 m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
                 m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.5)
+        if unit_scale_weights:  # N(0, (1.6/sqrt(fan_in))^2) weights: O(1) logits instead of the ~1e-2 of default init
+            for m in model.modules():
+                if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d)):
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.6 / m.weight[0].numel() ** 0.5))
     for n, p in model.named_parameters():
         if n.startswith("sequence_encoder"):
             p.requires_grad = False  # TRAIN_SEQUENCE_ENCODER: False

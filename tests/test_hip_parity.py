@@ -285,3 +285,53 @@ def test_save_embeddings_and_attention_pooling(golden_dir, fusion):
     ref = torch.bmm(torch.softmax(scores.masked_fill(mask == 0, float("-inf")), -1).unsqueeze(1), hs).squeeze(1)
     out = m2.additive_attention(hs.to(DEV), mask.to(DEV))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_full_size_eval_properties():
+    """BASELINE configs[1] size (B=256, L=512, N_L=32102, full-width model) through size-independent properties
+    (the oracle cannot run this size): in eval mode a pair's logit depends only on that protein and that label, so
+    (i) a re-ordered sub-batch against a label subset reproduces the corresponding entries of the full logits,
+    (ii) duplicating every label row and ensembling (logit(mean(sigmoid))) returns the same logits,
+    (iii) all 8.2 M logits are finite and not constant."""
+    from bench import build_model, synthetic_batch
+
+    model = build_model(torch.device(DEV), unit_scale_weights=True).eval()
+    B, L, NL = 256, 512, 32102
+    batch = synthetic_batch(B, L, NL, torch.device(DEV), seed=123)
+    # ragged lengths inside the fixed L=512 padding
+    gen = torch.Generator().manual_seed(1)
+    lens = torch.randint(64, L + 1, (B,), generator=gen).to(DEV)
+    x = batch["sequence_onehots"]
+    lab = batch["label_embeddings"]
+    with torch.no_grad():
+        full, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+        assert full.shape == (B, NL) and bool(torch.isfinite(full).all()) and float(full.std()) > 0.1
+        rows = torch.tensor([255, 3, 128, 17, 64, 200, 1, 99], device=DEV)
+        cols = torch.arange(31000, 31500, device=DEV)
+        sub, _ = model(sequence_onehots=x[rows].contiguous(), sequence_lengths=lens[rows],
+                       label_embeddings=lab[cols].contiguous())
+        assert (sub - full[rows][:, cols]).abs().max().item() < 2e-5
+        model.inference_descriptions_per_label = 2
+        dup = lab[cols].repeat_interleave(2, dim=0).contiguous()
+        ens, _ = model(sequence_onehots=x[rows].contiguous(), sequence_lengths=lens[rows], label_embeddings=dup)
+        inside = sub.abs() < 12  # torch.special.logit(eps=1e-7) clamps |logit| at 16.1 (reference :313-322)
+        assert int(inside.sum()) > 100 and (ens - sub)[inside].abs().max().item() < 2e-3
+        assert (ens - sub.clamp(-16.1181, 16.1181)).abs().max().item() < 0.5
+        model.inference_descriptions_per_label = 1
+
+
+def test_encoder_long_sequence_vs_oracle(golden_dir):
+    """MAX_SEQUENCE_LENGTH-sized input (L = 10000, base_config.yaml:79) next to a length-1 sequence: every dilation's
+    halo, the position-index arithmetic and the masked mean at the largest supported length."""
+    g = _g(golden_dir, "encoder_small.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    enc = make_encoder(sd, "", npz_cfg(g, "cfg_"), DEV).eval()
+    for p in enc.parameters():
+        p.requires_grad = False
+    gen = torch.Generator().manual_seed(2)
+    lens = torch.tensor([10000, 1, 4097])
+    ids = torch.randint(0, 20, (3, 10000), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    ref = O.proteinfer_get_embeddings(sd, x, lens)
+    out = enc.get_embeddings(x.to(DEV), lens.to(DEV)).cpu()
+    assert (out - ref).abs().max().item() < 2e-4
