@@ -14,20 +14,11 @@
 
 #include <type_traits>
 
-#ifndef PN_OVL
-#define PN_OVL 1
-#endif
 #ifndef PN_MINW
 #define PN_MINW 2
 #endif
 #ifndef PN_BK
 #define PN_BK 32
-#endif
-#ifndef PN_WS
-#define PN_WS 0
-#endif
-#ifndef PN_PRIO
-#define PN_PRIO 0
 #endif
 #ifndef PN_XCD
 #define PN_XCD 1
@@ -96,19 +87,6 @@ struct GemmParams {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
-// Two workgroups share a CU (one wave of each per SIMD).  Left alone they phase-lock: both run their MFMA
-// blocks together (sharing the matrix pipe) and then both stream/transform operands together, leaving the
-// pipe idle ~15 % of the time.  Giving the co-resident waves of a SIMD DIFFERENT static priorities (from
-// the hardware wave slot) makes the higher one own the pipe during its MFMA block and the lower one fill
-// exactly the gaps - the anti-phased schedule - so the pipe stays busy.
-__device__ __forceinline__ void stagger_priority() {
-#if PN_PRIO
-  const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;  // HW_REG_HW_ID.wave_id[1:0]
-  if (slot == 1) __builtin_amdgcn_s_setprio(1);
-  else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-  else if (slot == 3) __builtin_amdgcn_s_setprio(3);
-#endif
-}
 // Make a fetched register quad opaque at this point of the program: the transform math that consumes it
 // cannot be hoisted above (DAG linearisation otherwise floats it in front of the MFMA block, dragging the
 // s_waitcnt vmcnt with it and exposing the global-load latency).
@@ -117,15 +95,7 @@ __device__ __forceinline__ void pin4(float4& v) {
 }
 
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) void gemm_nt_kernel(const GemmParams p) {
-  // WS (wave specialisation): the workgroup has 2 x WAVES_M*WAVES_N waves.  Waves [0, NW) are CONSUMERS - they
-  // only read MFMA fragments from LDS and issue matrix ops, so the matrix pipe never waits on HBM/L2 latency,
-  // address arithmetic or operand transforms.  Waves [NW, 2NW) are PRODUCERS - they stream the next slab
-  // global -> registers -> (BN/ReLU/mask/dz transform) -> LDS while the consumers compute the current one.
-  // One s_barrier per slab hands the double-buffered LDS stage over.
-  constexpr bool WS = PN_WS != 0;
-  constexpr bool OVL = PN_OVL != 0 && !WS;  // non-WS only: weave commit() into the second half of the MFMA block
-  constexpr int VPM = (AK == A_DZ_ELEM || AK == A_DZ_ROWG) ? 5 : 3;  // VALU ops scheduled per MFMA
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;
   constexpr int BN = WAVES_N * WN * 32;
@@ -138,18 +108,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
   constexpr int STAGE = (BM + BN) * LDK;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  stagger_priority();
 
-  constexpr int NTB = NT * (WS ? 2 : 1);  // threads in the workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_producer = WS ? (wave >= WAVES_M * WAVES_N) : true;
-  const bool is_consumer = WS ? (wave < WAVES_M * WAVES_N) : true;
-  const int cw = WS ? (wave % (WAVES_M * WAVES_N)) : wave;  // consumer wave index (tile position)
-  const int wm = cw / WAVES_N;
-  const int wn = cw % WAVES_N;
-  const int ltid = WS ? (tid & (NT - 1)) : tid;  // loader thread index (producer waves when WS)
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
 
   const int ntn = (p.Nstore + BN - 1) / BN;
   int tile_m, tile_n;
@@ -176,8 +140,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
   const int row0 = tile_m * BM;
   const int col0 = tile_n * BN;
 
-  const int kv = ltid % KV;
-  const int r_in = ltid / KV;
+  const int kv = tid % KV;
+  const int r_in = tid / KV;
 
   // ---------------- per-thread operand row state ----------------
   const float* arow[NQA];
@@ -370,63 +334,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
 
   // ---------------- main loop: register-prefetch double buffering, one barrier per slab ----------------
   using std::integral_constant;
-  constexpr int KH = BK / 16;  // half of the BK/8 fragment steps
 
-  // consumer-side slab product with register double-buffered fragments: the ds_read_b128s of fragment step
-  // kk+1 are issued before the 4*WM*WN MFMAs of step kk, so LDS latency sits under the matrix pipe even
-  // with a single consumer wave per SIMD.
-  auto compute_ws = [&](int buf) {
-    const float* As = smem + buf * STAGE + (wm * WM * 32 + frag_row) * LDK + frag_k;
-    const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + frag_k;
-    float4 a[2][WM], b[2][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) a[0][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK);
-#pragma unroll
-    for (int j = 0; j < WN; ++j) b[0][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDK);
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      const int c = kk & 1;
-      if (kk + 1 < BK / 8) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-          a[c ^ 1][i] = *reinterpret_cast<const float4*>(As + i * 32 * LDK + (kk + 1) * 8);
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          b[c ^ 1][j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].x, b[c][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].y, b[c][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].z, b[c][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i].w, b[c][j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-  };
-
-  if constexpr (WS) {
-    if (is_producer) {
-      fetch(0);
-      pin_fetched();
-      commit(0);
-      if (nslab > 1) fetch(1);
-    }
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-      if (is_producer) {
-        if (s + 1 < nslab) {
-          pin_fetched();
-          commit((s + 1) & 1);            // waits for the loads of slab s+1 (issued one slab ago)
-          if (s + 2 < nslab) fetch(s + 2);  // and immediately puts slab s+2 in flight
-        }
-      } else {
-        compute_ws(s & 1);
-      }
-      __syncthreads();
-    }
-  } else {
   fetch(0);
   pin_fetched();
   commit(0);
@@ -468,26 +376,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
     const int cur = s & 1;
     fetch(s + 1);  // global loads of the next slab are issued first ...
     __builtin_amdgcn_sched_barrier(0);
-    // ... and stay in flight under the first half of this slab's MFMAs ...
-    compute(cur, integral_constant<int, 0>{}, integral_constant<int, KH>{});
+    // ... stay in flight under the first half of this slab's MFMAs ...
+    compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 16>{});
     __builtin_amdgcn_sched_barrier(0);
-    pin_fetched();  // (keeps hipcc from floating the consumer math, and its vmcnt wait, above this point)
-    // ... then the operand transform + LDS stores of slab s+1 are woven between the second half's MFMAs
-    // (one matrix op, then a few VALU / one ds_write while the matrix pipe is busy), so the only
-    // non-overlapped part of the slab is the barrier itself.
-    compute(cur, integral_constant<int, KH>{}, integral_constant<int, BK / 8>{});
+    pin_fetched();  // ... are waited for here (the pin keeps hipcc from floating the consumer math and its
+                    // s_waitcnt vmcnt above this point) ...
+    // ... and the operand transform + LDS stores share one scheduling region with the second half's MFMAs
+    compute(cur, integral_constant<int, BK / 16>{}, integral_constant<int, BK / 8>{});
     commit(cur ^ 1);
-    if constexpr (OVL) {
-      constexpr int NM = (BK / 8 - KH) * 4 * WM * WN;  // MFMAs in the second half
-      constexpr int NRD = WM + WN;                      // ds_read_b128 per fragment step
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        if (i % (4 * WM * WN) == 0) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-        if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-    }
 #if !defined(PN_ABL) || PN_ABL != 3
     __syncthreads();
 #endif
@@ -496,19 +392,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
   compute((nslab - 1) & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
   __syncthreads();
 
-  }
-
   // ---------------- epilogue ----------------
   const int hl = lane >> 5;  // which 4-row group of each 8
   const int cl = lane & 31;
   const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_sum != nullptr);
   float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
   if (want_stats) {
-    for (int i = tid; i < 2 * BN; i += NTB) red[i] = 0.f;
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
     __syncthreads();
   }
 
-  if (is_consumer) {
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = col0 + (wn * WN + j) * 32 + cl;
@@ -580,10 +473,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
       }
     }
   }
-  }  // is_consumer
   if (want_stats) {
     __syncthreads();
-    for (int i = tid; i < BN; i += NTB) {
+    for (int i = tid; i < BN; i += NT) {
       const int col = col0 + i;
       if (col < p.N) {
         atomicAdd(&p.col_sum[col], (double)red[i]);
@@ -592,7 +484,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
     }
   }
   if constexpr (EK == E_ROWDOT) {
-    if (is_consumer) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -609,7 +500,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 * (PN_WS ? 2 : 1), PN_MINW) v
         if (cl == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
       }
     }
-    }
   }
 }
 
@@ -617,7 +507,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, int BK>
 struct GemmCfg {
   static constexpr int BM = WAVES_M * WM * 32;
   static constexpr int BN = WAVES_N * WN * 32;
-  static constexpr int NT = WAVES_M * WAVES_N * 64 * (PN_WS ? 2 : 1);
+  static constexpr int NT = WAVES_M * WAVES_N * 64;
   static constexpr int LDS_BYTES = 2 * (BM + BN) * (BK + 4) * (int)sizeof(float);
 };
 

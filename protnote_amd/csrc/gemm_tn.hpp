@@ -55,7 +55,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   constexpr int NQ = 4;  // (BK rows * C4 float4 per row) / threads
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  stagger_priority();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
