@@ -6,3 +6,11 @@ under `protnote_amd.`.  All arithmetic runs in hand-written
 through the C ABI in include/protnote_hip.h; PyTorch only owns device memory, streams and
 torch.distributed."""
 __version__ = "0.1.0"
+
+
+def free_workspaces():
+    """Drop the cached device scratch buffers (grow-only per-device workspaces of the C-ABI calls).  The
+    training-time activation store of a model lives on the model (`model._pn_train_save`) and goes with it."""
+    from . import _lib
+
+    _lib._ws_cache.clear()

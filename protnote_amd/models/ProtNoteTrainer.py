@@ -41,6 +41,8 @@ def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, t
 
     if world_size > 1:
         broadcast_buffers(model)
+    if counts is not None and hasattr(loss_fn, "metric_counts"):
+        loss_fn.metric_counts, loss_fn.decision_threshold = counts, threshold  # counted inside the loss pass
     logits, _ = model(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
                       label_embeddings=batch["label_embeddings"],
                       label_token_counts=batch.get("label_token_counts"))
@@ -50,10 +52,9 @@ def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, t
         allreduce_gradients(optimizer)
     optimizer.step()
     optimizer.zero_grad()
-    if counts is not None:
+    if counts is not None and not hasattr(loss_fn, "metric_counts"):  # foreign loss module: separate pass
         with torch.no_grad():
-            probs = torch.sigmoid(logits.detach())
-            tp, fn, fp = calculate_tp_fn_fp(probs, batch["label_multihots"], threshold)
+            tp, fn, fp = calculate_tp_fn_fp(torch.sigmoid(logits.detach()), batch["label_multihots"], threshold)
             counts[0] += tp
             counts[1] += fn
             counts[2] += fp

@@ -14,7 +14,7 @@ _BCE, _FOCAL = 0, 1
 
 class _FusedLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, kind, pos_weight, gamma, alpha, smoothing):
+    def forward(ctx, logits, target, kind, pos_weight, gamma, alpha, smoothing, counts=None, threshold=0.5):
         L.require_hip(logits, target)
         if logits.dim() != 2 or target.shape != logits.shape:
             raise ValueError("expected logits and targets of the same [B, N] shape")
@@ -28,9 +28,14 @@ class _FusedLossFn(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
         ws = L.workspace(256, x.device, "loss")
+        tp = fn = fp = None
+        if counts is not None:  # [3, N] f32 accumulators of per-label TP / FN / FP (ProtNoteTrainer.py:61-83)
+            if counts.shape != (3, N) or counts.dtype != torch.float32 or not counts.is_contiguous():
+                raise ValueError("metric counts must be a contiguous float32 [3, N_labels] tensor")
+            tp, fn, fp = counts[0], counts[1], counts[2]
         L.check(L.lib().pn_loss_fwd_bwd(L.ptr(x), L.ptr(tf), L.ptr(ti), B, N, kind, float(pos_weight), float(gamma),
-                                        float(alpha), float(smoothing), 0.5, L.ptr(loss), L.ptr(dlog), None, None,
-                                        None, L.ptr(ws), ws.numel(), L.stream_ptr()))
+                                        float(alpha), float(smoothing), float(threshold), L.ptr(loss), L.ptr(dlog),
+                                        L.ptr(tp), L.ptr(fn), L.ptr(fp), L.ptr(ws), ws.numel(), L.stream_ptr()))
         ctx.dlog = dlog
         return loss.reshape(())
 
@@ -38,10 +43,17 @@ class _FusedLossFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         g = ctx.dlog * grad_out
         ctx.dlog = None
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None, None
 
 
-class BCEWithLogitsLoss(torch.nn.Module):
+class _CountsMixin:
+    """Optional K13+K14 fusion: set `metric_counts` to a [3, N_labels] f32 tensor and the same pass over the logits
+    that computes the loss and its gradient also accumulates per-label TP / FN / FP at `decision_threshold`."""
+    metric_counts = None
+    decision_threshold = 0.5
+
+
+class BCEWithLogitsLoss(_CountsMixin, torch.nn.Module):
     def __init__(self, pos_weight=None):
         super().__init__()
         if pos_weight is not None and torch.is_tensor(pos_weight) and pos_weight.numel() != 1:
@@ -49,10 +61,11 @@ class BCEWithLogitsLoss(torch.nn.Module):
         self.pos_weight = 1.0 if pos_weight is None else float(pos_weight)
 
     def forward(self, input, target):
-        return _FusedLossFn.apply(input, target, _BCE, self.pos_weight, 0.0, -1.0, 0.0)
+        return _FusedLossFn.apply(input, target, _BCE, self.pos_weight, 0.0, -1.0, 0.0, self.metric_counts,
+                                  self.decision_threshold)
 
 
-class FocalLoss(torch.nn.Module):
+class FocalLoss(_CountsMixin, torch.nn.Module):
     def __init__(self, alpha: float, gamma: float, reduction="mean", label_smoothing=0.0):
         super().__init__()
         assert (alpha is not None) & (gamma is not None), \
@@ -62,7 +75,8 @@ class FocalLoss(torch.nn.Module):
         self.alpha, self.gamma, self.reduction, self.label_smoothing = alpha, gamma, reduction, label_smoothing
 
     def forward(self, input, target):
-        return _FusedLossFn.apply(input, target, _FOCAL, 1.0, self.gamma, self.alpha, self.label_smoothing)
+        return _FusedLossFn.apply(input, target, _FOCAL, 1.0, self.gamma, self.alpha, self.label_smoothing,
+                                  self.metric_counts, self.decision_threshold)
 
 
 def get_loss(config: dict, label_weights: torch.Tensor = None, bce_pos_weight: torch.Tensor = None):

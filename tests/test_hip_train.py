@@ -55,6 +55,14 @@ def test_fused_loss_and_metrics_golden(golden_dir):
             np.testing.assert_allclose(l.item(), float(g[name + "/loss"]), rtol=2e-6, err_msg=name)
             np.testing.assert_allclose(lg.grad.cpu().numpy(), g[name + "/dlogits"], atol=2e-10, rtol=2e-5,
                                        err_msg=name)
+    # K13 + K14 fused: the loss pass itself accumulates the per-label counts
+    fused = BCEWithLogitsLoss()
+    fused.metric_counts = torch.zeros(3, logits.shape[1], device=DEV)
+    fused.decision_threshold = 0.3
+    fused(logits, y.float())
+    fused(logits, y.float())
+    for k, name in enumerate(("tp", "fn", "fp")):
+        assert np.array_equal(fused.metric_counts[k].cpu().numpy(), 2 * g["th0.3/" + name]), name
     for th in (0.5, 0.3):
         tp, fn_, fp = calculate_tp_fn_fp(torch.sigmoid(logits), y, threshold=th)
         assert np.array_equal(tp.cpu().numpy(), g[f"th{th}/tp"])  # integer counts: bit-exact
