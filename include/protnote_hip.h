@@ -207,6 +207,12 @@ int pn_transpose(const float* src, long ld_src, int rows, int cols, float* dst, 
 int pn_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, long R, int M, int N,
                void* ws, size_t ws_bytes, void* stream);
 
+/* Device-side batch assembly (input layout of collate_variable_sequence_length, collators.py:123-133):
+ * ids = the batch's residue indices back to back (uint8), offsets [B+1] i64 -> onehots [B][A][Lmax] f32
+ * (zero-padded) and lengths [B] i64. */
+int pn_onehot_batch(const uint8_t* ids, const int64_t* offsets, int B, int A, int Lmax, float* onehots,
+                    int64_t* lengths, void* stream);
+
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
  * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller

@@ -108,6 +108,8 @@ _SIGS = {
     "pn_transpose": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     "pn_gemm_tn": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int,
                              C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_onehot_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),

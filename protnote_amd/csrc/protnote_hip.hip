@@ -1702,3 +1702,30 @@ extern "C" int pn_additive_attention(const float* hidden, const int64_t* attenti
   HIP_OK(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// device-side batch assembly: ragged uint8 residue ids -> padded f32 one-hots [B][A][Lmax] + lengths.
+// The host ships B*L bytes instead of B*A*L*4 (80x less PCIe traffic than the reference's collated one-hots).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_onehot_batch(const uint8_t* __restrict__ ids, const int64_t* __restrict__ offsets, int B, int A,
+                               int Lmax, float* __restrict__ out, int64_t* __restrict__ lengths) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * A * Lmax;
+  if (i >= total) return;
+  const int t = (int)(i % Lmax);
+  const int a = (int)((i / Lmax) % A);
+  const int b = (int)(i / ((long)Lmax * A));
+  const int64_t off = offsets[b];
+  const int len = (int)(offsets[b + 1] - off);
+  out[i] = (t < len && ids[off + t] == a) ? 1.f : 0.f;
+  if (t == 0 && a == 0) lengths[b] = len;
+}
+
+extern "C" int pn_onehot_batch(const uint8_t* ids, const int64_t* offsets, int B, int A, int Lmax, float* onehots,
+                               int64_t* lengths, void* stream) {
+  if (B <= 0 || A <= 0 || Lmax <= 0) return fail("onehot_batch: empty batch");
+  hipLaunchKernelGGL(k_onehot_batch, dim3(nblk((long)B * A * Lmax, 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                     offsets, B, A, Lmax, onehots, lengths);
+  HIP_OK(hipGetLastError());
+  return 0;
+}

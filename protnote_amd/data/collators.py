@@ -58,3 +58,39 @@ def collate_variable_sequence_length(batch: List[Dict], label_sample_size=None, 
         out["label_multihots"] = torch.stack(
             [row["label_multihots"] if idx is None else row["label_multihots"][idx] for row in batch])
     return out
+
+
+def collate_to_device(batch: List[Dict], device, label_sample_size=None, distribute_labels=False, shuffle_labels=False,
+                      in_batch_sampling=False, grid_sampler=False, return_label_multihots=True, world_size=1, rank=0):
+    """Same batch dict as collate_variable_sequence_length, assembled ON THE DEVICE: the host ships the ragged
+    residue indices as uint8 (B*L bytes, one copy) plus offsets, and pn_onehot_batch writes the zero-padded f32
+    one-hots [B, A, Lmax] and the lengths in HBM.  Examples may carry `sequence_ints` (residue indices) or the
+    reference's `sequence_onehots` [A, L] (argmax'ed here)."""
+    import numpy as np
+
+    from .. import _lib as L
+
+    idx = sample_label_indices(batch, label_sample_size, distribute_labels, shuffle_labels, in_batch_sampling,
+                               grid_sampler, world_size, rank)
+    first = batch[0]
+    A = int(first["sequence_onehots"].shape[0]) if "sequence_onehots" in first else int(first["alphabet_size"])
+    ints = [np.asarray(r["sequence_ints"], dtype=np.uint8) if "sequence_ints" in r
+            else r["sequence_onehots"].argmax(0).to(torch.uint8).numpy() for r in batch]
+    lens = [len(v) for v in ints]
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
+    flat = torch.from_numpy(np.concatenate(ints))
+    B, Lmax = len(batch), int(max(lens))
+    flat_d = flat.to(device, non_blocking=True)
+    off_d = offsets.to(device, non_blocking=True)
+    onehots = torch.empty(B, A, Lmax, dtype=torch.float32, device=device)
+    lengths = torch.empty(B, dtype=torch.int64, device=device)
+    L.check(L.lib().pn_onehot_batch(L.ptr(flat_d), L.ptr(off_d), B, A, Lmax, L.ptr(onehots), L.ptr(lengths),
+                                    L.stream_ptr()))
+    emb = first["label_embeddings"] if idx is None else first["label_embeddings"][idx]
+    out = {"sequence_onehots": onehots, "sequence_ids": [r["sequence_id"] for r in batch],
+           "sequence_lengths": lengths, "label_embeddings": emb.to(device, non_blocking=True),
+           "label_token_counts": first["label_token_counts"].to(device, non_blocking=True)}
+    if return_label_multihots:
+        mh = torch.stack([r["label_multihots"] if idx is None else r["label_multihots"][idx] for r in batch])
+        out["label_multihots"] = mh.to(device, non_blocking=True)
+    return out

@@ -64,3 +64,18 @@ def test_label_bookkeeping_bit_exact(golden_dir):
             assert np.array_equal(LB.label_multihot(labs, l2i).numpy(), g[p + f"ex{i}/multihots"])
             assert np.array_equal(LB.sequence_onehot(seq, a2i).numpy(), g[p + f"ex{i}/onehots"])
             assert int(g[p + f"ex{i}/length"]) == len(seq)
+
+
+def test_length_bucket_sampler():
+    from protnote_amd.data.samplers import LengthBucketBatchSampler
+
+    lens = [5, 130, 2000, 128, 129, 3000, 256, 257, 1, 700]
+    s = LengthBucketBatchSampler(lens, batch_size=2)
+    batches = list(s)
+    assert sorted(i for b in batches for i in b) == list(range(len(lens)))  # a partition
+    for b in batches:
+        assert len({s.bucket_of(lens[i]) for i in b}) == 1 and len(b) <= 2
+    assert s.bucket_of(128) == 0 and s.bucket_of(129) == 1 and s.bucket_of(3000) == 4
+    a = list(LengthBucketBatchSampler(lens, 2, shuffle=True, seed=3, rank=0, world_size=2))
+    b = list(LengthBucketBatchSampler(lens, 2, shuffle=True, seed=3, rank=1, world_size=2))
+    assert sorted(i for x in a + b for i in x) == list(range(len(lens)))  # ranks partition the epoch

@@ -335,3 +335,26 @@ def test_encoder_long_sequence_vs_oracle(golden_dir):
     ref = O.proteinfer_get_embeddings(sd, x, lens)
     out = enc.get_embeddings(x.to(DEV), lens.to(DEV)).cpu()
     assert (out - ref).abs().max().item() < 2e-4
+
+
+def test_device_batch_assembly_matches_cpu_collator(golden_dir):
+    """collate_to_device (uint8 ids + offsets -> one-hots built in HBM) == the reference-layout CPU collator, bit-exact."""
+    from protnote_amd.data.collators import collate_to_device, collate_variable_sequence_length
+
+    gen = torch.Generator().manual_seed(8)
+    lab = torch.randn(9, 16, generator=gen)
+    cnt = torch.randint(1, 9, (9,), generator=gen)
+    batch = []
+    for i, n in enumerate([33, 1, 700, 128, 64]):
+        ids = torch.randint(0, 20, (n,), generator=gen)
+        batch.append({"sequence_onehots": torch.nn.functional.one_hot(ids, 20).T.float(), "sequence_id": f"S{i}",
+                      "sequence_length": torch.tensor(n), "label_multihots": (torch.rand(9, generator=gen) < 0.3).long(),
+                      "label_embeddings": lab, "label_token_counts": cnt})
+    for kw in ({}, {"label_sample_size": 4}, {"in_batch_sampling": True}):
+        ref = collate_variable_sequence_length(batch, **kw)
+        dev = collate_to_device(batch, DEV, **kw)
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                assert dev[k].dtype == v.dtype and dev[k].shape == v.shape and torch.equal(dev[k].cpu(), v), k
+            else:
+                assert dev[k] == v
