@@ -62,3 +62,30 @@ def test_struct_sizes_match_c(built_lib, tmp_path):
     want = [ctypes.sizeof(t) for t in (_lib.pn_bn, _lib.pn_res_block, _lib.pn_encoder, _lib.pn_mlp,
                                        _lib.pn_pairhead)]
     assert got == want
+
+
+def test_error_convention(built_lib):
+    """Entry points return non-zero and leave a message in pn_last_error() on invalid arguments (checked before any
+    launch, so this runs without a GPU)."""
+    from protnote_amd import _lib
+
+    lib = _lib.lib()
+    rc = lib.pn_gemm_nt(None, 6, None, 6, None, 8, 4, 8, 6, None, None, None, None, None, 0, None)  # K % 4 != 0
+    assert rc != 0 and b"multiples of 4" in lib.pn_last_error()
+    rc = lib.pn_ensemble_logit(None, 4, 10, 3, 0, None, None)  # NL not divisible by ndesc
+    assert rc != 0 and b"divisible" in lib.pn_last_error()
+    with pytest.raises(RuntimeError, match="libprotnote_hip"):
+        _lib.check(rc)
+
+
+def test_grad_struct_sizes_match_c(built_lib, tmp_path):
+    import subprocess
+    from protnote_amd import _lib
+
+    src = tmp_path / "sz2.c"
+    src.write_text('#include <stdio.h>\n#include "protnote_hip.h"\nint main(){printf("%zu %zu\\n",'
+                   "sizeof(pn_mlp_grads),sizeof(pn_pairhead_grads));}")
+    exe = tmp_path / "sz2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(_lib.pn_mlp_grads), ctypes.sizeof(_lib.pn_pairhead_grads)]
