@@ -128,9 +128,14 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -m protnote_amd.build` "
-                "(protnote_amd has no CPU/eager fallback)")
+            try:  # in-tree build with hipcc when the toolchain is there; never a CPU/eager fallback
+                from .build import build_lib
+
+                build_lib(verbose=False)
+            except Exception as exc:  # noqa: BLE001
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing and could not be built ({exc}); build it with "
+                    "`python -m protnote_amd.build` (protnote_amd has no CPU/eager fallback)") from exc
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
