@@ -44,3 +44,37 @@ class LengthBucketBatchSampler:
 
     def __len__(self) -> int:
         return len(self._batches())
+
+
+class DistributedWeightedSampler:
+    """Index stream of the reference's DistributedWeightedSampler (protnote/data/samplers.py:66-124): every epoch
+    draws floor(N / world) * world indices from torch.multinomial(weights) on a CPU generator seeded with the
+    epoch, keeps the rank-strided slice and shuffles it with the same generator - bit-identical streams."""
+
+    def __init__(self, weights, world_size: int = 1, rank: int = 0, replacement: bool = True):
+        import math
+
+        import torch
+
+        self.weights = weights if isinstance(weights, torch.Tensor) else torch.tensor(weights, dtype=torch.double)
+        self.world_size, self.rank, self.replacement, self.epoch = world_size, rank, replacement, 0
+        self.num_samples = int(math.floor(len(self.weights) * 1.0 / world_size))
+        self.total_size = self.num_samples * world_size
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def __iter__(self):
+        import torch
+
+        g = torch.Generator()
+        g.manual_seed(self.epoch)
+        if not self.replacement:
+            assert len(self.weights) > self.total_size, \
+                "When sampling without replacement, number of samples to draw must be less than the dataset size"
+        idx = torch.multinomial(self.weights, self.total_size, replacement=self.replacement, generator=g)
+        mine = idx[self.rank:self.total_size:self.world_size]
+        return iter(mine[torch.randperm(len(mine), generator=g)].tolist())

@@ -491,12 +491,37 @@ def golden_tf_weights():
     print("tf_weights_small.pkl + expected", len(out))
 
 
+def golden_samplers():
+    """Index streams of protnote/data/samplers.py::DistributedWeightedSampler (torch.multinomial + randperm on a
+    generator seeded with the epoch, rank-strided) for 2 ranks x 2 epochs, with and without replacement."""
+    from protnote.data.samplers import DistributedWeightedSampler
+
+    g = torch.Generator().manual_seed(11)
+    weights = torch.rand(37, generator=g).double() + 0.05
+    out = {"weights": weights.numpy()}
+    for repl in (True, False):
+        for world in (1, 2):
+            for rank in range(world):
+                n = 37 if repl else 30  # without replacement the reference needs len(weights) > total_size
+                w = weights if repl else torch.cat([weights, weights[:8]])
+                s = DistributedWeightedSampler(w, world_size=world, rank=rank, replacement=repl)
+                if not repl:
+                    s.num_samples = n // world
+                    s.total_size = s.num_samples * world
+                for epoch in (0, 1):
+                    s.set_epoch(epoch)
+                    out[f"repl{int(repl)}/w{world}/r{rank}/e{epoch}"] = np.array(list(iter(s)))
+    np.savez_compressed(os.path.join(OUT, "samplers.npz"), **out)
+    print("samplers.npz", len(out))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote, "losses": golden_losses_metrics,
-            "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights}
+            "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
+            "samplers": golden_samplers}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

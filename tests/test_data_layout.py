@@ -79,3 +79,22 @@ def test_length_bucket_sampler():
     a = list(LengthBucketBatchSampler(lens, 2, shuffle=True, seed=3, rank=0, world_size=2))
     b = list(LengthBucketBatchSampler(lens, 2, shuffle=True, seed=3, rank=1, world_size=2))
     assert sorted(i for x in a + b for i in x) == list(range(len(lens)))  # ranks partition the epoch
+
+
+def test_distributed_weighted_sampler_streams(golden_dir):
+    """Bit-identical index streams vs the reference sampler (2 ranks x 2 epochs, with / without replacement)."""
+    from protnote_amd.data.samplers import DistributedWeightedSampler
+
+    g = np.load(os.path.join(golden_dir, "samplers.npz"))
+    weights = torch.from_numpy(g["weights"])
+    for repl in (True, False):
+        for world in (1, 2):
+            for rank in range(world):
+                w = weights if repl else torch.cat([weights, weights[:8]])
+                s = DistributedWeightedSampler(w, world_size=world, rank=rank, replacement=repl)
+                if not repl:
+                    s.num_samples = 30 // world
+                    s.total_size = s.num_samples * world
+                for epoch in (0, 1):
+                    s.set_epoch(epoch)
+                    assert list(iter(s)) == g[f"repl{int(repl)}/w{world}/r{rank}/e{epoch}"].tolist()
