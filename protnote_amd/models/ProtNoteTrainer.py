@@ -59,3 +59,60 @@ def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, t
             counts[1] += fn
             counts[2] += fp
     return loss.detach()
+
+
+class Trainer:
+    """Minimal epoch driver around the fused step (reference ProtNoteTrainer.train_one_epoch :675-825 and
+    evaluate :449-673, without W&B / checkpoint cadence / threshold search): per-batch train_step with the loss pass
+    counting TP/FN/FP, ONE fused [3, N_L] all-reduce per epoch (the reference does three dist.reduce calls,
+    :637-639/:795-797), F1 macro/micro from the counts, and - for evaluation - mAP from the collected logits."""
+
+    def __init__(self, model, loss_fn, optimizer=None, world_size=1, threshold=0.5):
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        self.world_size, self.threshold = world_size, threshold
+
+    def _metrics(self, counts, loss_sum, n_batches):
+        from ..utils.distributed import allreduce_counts
+
+        counts = allreduce_counts(counts)
+        tp, fn, fp = counts[0], counts[1], counts[2]
+        return {"loss": loss_sum / max(n_batches, 1), "f1_macro": float(calculate_f1(tp, fn, fp).mean()),
+                "f1_micro": float(calculate_f1_micro(tp, fn, fp))}
+
+    def train_one_epoch(self, loader):
+        self.model.train()
+        counts, loss_sum, n = None, 0.0, 0
+        for batch in loader:
+            if counts is None:
+                counts = torch.zeros(3, batch["label_multihots"].shape[1], dtype=torch.float32,
+                                     device=batch["label_multihots"].device)
+            loss_sum += float(train_step(self.model, self.loss_fn, self.optimizer, batch, world_size=self.world_size,
+                                         counts=counts, threshold=self.threshold))
+            n += 1
+        return self._metrics(counts, loss_sum, n)
+
+    @torch.no_grad()
+    def evaluate(self, loader, with_map=True):
+        from ..utils.evaluation import map_macro, map_micro
+
+        self.model.eval()
+        counts, loss_sum, n, all_logits, all_labels = None, 0.0, 0, [], []
+        for batch in loader:
+            y = batch["label_multihots"]
+            if counts is None:
+                counts = torch.zeros(3, y.shape[1], dtype=torch.float32, device=y.device)
+            logits, _ = self.model(sequence_onehots=batch["sequence_onehots"],
+                                   sequence_lengths=batch["sequence_lengths"],
+                                   label_embeddings=batch["label_embeddings"])
+            if hasattr(self.loss_fn, "metric_counts"):
+                self.loss_fn.metric_counts, self.loss_fn.decision_threshold = counts, self.threshold
+            loss_sum += float(self.loss_fn(logits, y))
+            n += 1
+            if with_map:
+                all_logits.append(logits.cpu())
+                all_labels.append(y.cpu())
+        out = self._metrics(counts, loss_sum, n)
+        if with_map and all_logits:
+            s, t = torch.cat(all_logits).numpy(), torch.cat(all_labels).numpy()
+            out.update(map_micro=map_micro(s, t), map_macro=map_macro(s, t))
+        return out
