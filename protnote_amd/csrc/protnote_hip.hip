@@ -182,6 +182,9 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
     if (PN_BIG && variant == 0 && p.N % 256 == 0 && p.M >= 65536)
       return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
   }
+  if constexpr (EK == E_CONV) {  // variant 3: 256x192 tile (4x2 waves of 64x96): 550 -> 3 x 192 = 576, 1100 -> 6 x 192
+    if (PN_BIG && variant == 3) return launch_gemm_cfg<AK, EK, 4, 2, 2, 3, 32>(p, st);
+  }
   if constexpr (EK == E_ROWDOT) {  // partial-slab count depends on the tile: decided by N alone (rowdot_nparts)
     if (PN_BIG && p.N % 256 == 0) return launch_gemm_cfg<AK, EK, 4, 2, 2, 4, 32>(p, st);
   }
@@ -462,7 +465,8 @@ extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const i
     p.col_sum = csum;
     p.col_sumsq = csq;
     (void)Cin_;
-    return launch_gemm<A_CONV, E_CONV>(p, pick_variant(ld_out), st);
+    const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
+    return launch_gemm<A_CONV, E_CONV>(p, big ? 3 : pick_variant(ld_out), st);
   };
 
   // conv1: MaskedConv1D(Cin -> C, k, dil 1), no BN/ReLU in front (protein_encoders.py:84-91,110)

@@ -87,7 +87,8 @@ def test_encoder_golden_eval_and_train(golden_dir):
         np.testing.assert_allclose(got[k].numpy(), v.numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
 
 
-@pytest.mark.parametrize("B,Lmax,lens", [(3, 96, [96, 1, 40]), (2, 400, [400, 333])])
+@pytest.mark.parametrize("B,Lmax,lens", [(3, 96, [96, 1, 40]), (2, 400, [400, 333]),
+                                          (10, 512, [512, 1, 333, 512, 77, 500, 40, 511, 256, 129])])  # 256x192 conv tiles
 def test_encoder_full_width_vs_oracle(B, Lmax, lens):
     """Real channel counts (1100 / 550, k=9, dilations 1..81) against the oracle on the same seeded inputs."""
     cfg = dict(num_labels=11, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
