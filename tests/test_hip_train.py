@@ -387,3 +387,46 @@ def test_trainer_learns_synthetic_task():
     assert last["loss"] < 0.7 * first["loss"], (first, last)
     ev = tr.evaluate(batches)
     assert ev["map_micro"] > 0.5 and ev["f1_micro"] > 0.3, ev
+
+
+def test_torch_ddp_wrapper_compat(golden_dir):
+    """The reference wraps the model in torch DDP (bin/main.py:452, find_unused_parameters=True) and runs
+    scaler.scale(loss).backward() under autocast (ProtNoteTrainer.py:728-738).  With a 1-rank process group the
+    same wrapper + GradScaler + autocast around protnote_amd's modules must give the plain gradients."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from protnote_amd.utils.losses import get_loss
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = _g(golden_dir, "protnote_small_concatenation.npz")
+        model, _ = make_protnote(g, DEV)
+        _freeze_encoder(model)
+        model.label_embedding_noising_alpha = 0.0
+        model.train()
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=True)
+        x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+        lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+        y = torch.from_numpy(g["multihots"]).to(DEV)
+        loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+        scaler = torch.amp.GradScaler("cuda")
+        with torch.autocast("cuda"):
+            logits, _ = ddp(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+            loss = loss_fn(logits, y.float())
+        scaler.scale(loss).backward()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4)
+        scaler.unscale_(opt)
+        # reference gradient of the same (noise-free) step from the oracle
+        sd = O.as_torch_sd(g, "sd/")
+        _, ref_loss, ref_grads, _ = O.train_step(sd, torch.from_numpy(g["x"]), torch.from_numpy(g["lens"]), lab.cpu(),
+                                                 y.cpu(), loss="BCE", apply_update=False)
+        np.testing.assert_allclose(loss.item(), float(ref_loss), rtol=1e-4)
+        named = dict(model.named_parameters())
+        for k, ref in ref_grads.items():
+            got = named[k].grad.cpu()
+            assert (got - ref).abs().max().item() <= 2e-5 + 2e-4 * ref.abs().max().item(), k
+    finally:
+        dist.destroy_process_group()
