@@ -152,6 +152,24 @@ typedef struct pn_pairhead_grads {
   float* db_out; /* [1] */
 } pn_pairhead_grads;
 
+/* ProteInfer encoder with TRAIN_SEQUENCE_ENCODER: True (ProtNote.py:248-256): training forward that keeps the
+ * block inputs / conv outputs / BN batch statistics in `save`, and the backward from d(embeddings) to every encoder
+ * parameter (gradient tensors in torch layout: conv weights [Cout][Cin][k]). */
+typedef struct pn_res_block_grads {
+  float *bn1_w, *bn1_b, *conv_a_w, *conv_a_b, *bn2_w, *bn2_b, *conv_b_w, *conv_b_b;
+} pn_res_block_grads;
+typedef struct pn_encoder_grads {
+  float* conv1_w;
+  float* conv1_b;
+  pn_res_block_grads blk[PN_MAX_BLOCKS];
+} pn_encoder_grads;
+size_t pn_encoder_train_save_bytes(const pn_encoder* enc, int B, int L);
+size_t pn_encoder_bwd_ws_bytes(const pn_encoder* enc, int B, int L);
+int pn_encoder_fwd_train(const pn_encoder* enc, const float* onehots, const int64_t* lens, int B, int L, float* emb,
+                         int ld_emb, void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+int pn_encoder_bwd(const pn_encoder* enc, int B, int L, const float* demb, int ld_demb, const pn_encoder_grads* gr,
+                   void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+
 /* W_p / W_l with train-mode BatchNorm1d (batch statistics over `rows`, running-stat update) - the
  * training-time self.W_p(P_f) / self.W_l(L_f) of ProtNote.py:270-271 - and its backward.  `save` carries
  * the pre-activations and BN statistics from forward to backward (size: *_train_save_bytes). */

@@ -146,13 +146,16 @@ def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], 
                      descriptions_per_label: int = 1, noise_alpha: float = 0.0,
                      noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
                      dilation_base: int = 3, sequence_embeddings: Optional[Tensor] = None,
-                     aux: Optional[dict] = None) -> Tensor:
-    """ProtNote.forward (ProtNote.py:168-334), cached-label-embedding path; encoder frozen (no_grad)."""
+                     aux: Optional[dict] = None, train_sequence_encoder: bool = False) -> Tensor:
+    """ProtNote.forward (ProtNote.py:168-334), cached-label-embedding path; the encoder runs under no_grad unless
+    train_sequence_encoder and training (ProtNote.py:248-260)."""
     L_f = label_embeddings
     if training and label_token_counts is not None and noise_alpha > 0:
         L_f = noised_label_embeddings(L_f, noise_alpha, noise_u)
     if sequence_embeddings is not None:
         P_f = sequence_embeddings
+    elif train_sequence_encoder and training:
+        P_f = proteinfer_get_embeddings(sd, onehots, lens, training, dilation_base, "sequence_encoder.")
     else:
         with torch.no_grad():
             P_f = proteinfer_get_embeddings(sd, onehots, lens, training, dilation_base, "sequence_encoder.")
@@ -212,11 +215,19 @@ def f1_micro(tp, fn, fp):
     return f1_per_label(tp.sum(), fn.sum(), fp.sum())
 
 
-def trainable_names(sd: SD):
-    """ProtNoteTrainer.py:199-226 with the default config: encoder frozen, heads trainable."""
+def trainable_names(sd: SD, train_sequence_encoder: bool = False):
+    """ProtNoteTrainer.py:199-226: heads trainable; the encoder only with TRAIN_SEQUENCE_ENCODER (its classifier
+    `sequence_encoder.output_layer` is never reached by get_embeddings, so it gets no gradient either way)."""
     skip = ("running_mean", "running_var", "num_batches_tracked")
-    return [k for k in sd if not k.startswith("sequence_encoder.") and not k.startswith("label_encoder.")
-            and not k.endswith(skip)]
+    out = []
+    for k in sd:
+        if k.startswith("label_encoder.") or k.endswith(skip):
+            continue
+        if k.startswith("sequence_encoder."):
+            if not train_sequence_encoder or k.startswith("sequence_encoder.output_layer."):
+                continue
+        out.append(k)
+    return out
 
 
 def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, multihots: Tensor, *,
@@ -224,18 +235,19 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
                clip: Optional[float] = 1.0, lr: float = 3e-4, dilation_base: int = 3,
                adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
-               **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+               train_sequence_encoder: bool = False, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
     """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU).
 
     Updates `sd` in place (params by Adam, BN buffers by the train-mode forward).
     Returns (logits, loss, grads, total_grad_norm)."""
-    names = trainable_names(sd)
+    names = trainable_names(sd, train_sequence_encoder)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
     work = dict(sd)
     work.update(leaves)
     logits = protnote_forward(work, onehots, lens, label_embeddings, fusion=fusion, training=True,
                               noise_alpha=noise_alpha, noise_u=noise_u, temperature=temperature,
-                              label_token_counts=label_token_counts, dilation_base=dilation_base)
+                              label_token_counts=label_token_counts, dilation_base=dilation_base,
+                              train_sequence_encoder=train_sequence_encoder)
     y = multihots.float()
     l = bce_loss(logits, y, **loss_kw) if loss == "BCE" else focal_loss(logits, y, **loss_kw)
     grads_t = torch.autograd.grad(l, [leaves[k] for k in names], allow_unused=True)

@@ -44,6 +44,15 @@ class pn_pairhead(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
 
 
+class pn_res_block_grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("bn1_w", "bn1_b", "conv_a_w", "conv_a_b", "bn2_w", "bn2_b", "conv_b_w",
+                                          "conv_b_b")]
+
+
+class pn_encoder_grads(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("blk", pn_res_block_grads * PN_MAX_BLOCKS)]
+
+
 class pn_mlp_grads(C.Structure):
     _fields_ = [("dw", C.c_void_p * PN_MAX_LAYERS), ("dgamma", C.c_void_p * PN_MAX_LAYERS),
                 ("dbeta", C.c_void_p * PN_MAX_LAYERS)]
@@ -79,6 +88,13 @@ _SIGS = {
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pn_similarity_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_encoder_train_save_bytes": (C.c_size_t, [C.POINTER(pn_encoder), C.c_int, C.c_int]),
+    "pn_encoder_bwd_ws_bytes": (C.c_size_t, [C.POINTER(pn_encoder), C.c_int, C.c_int]),
+    "pn_encoder_fwd_train": (C.c_int, [C.POINTER(pn_encoder), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_encoder_bwd": (C.c_int, [C.POINTER(pn_encoder), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                 C.POINTER(pn_encoder_grads), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
     "pn_mlp_rows_train_save_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
     "pn_mlp_rows_train_ws_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
     "pn_mlp_rows_fwd_train": (C.c_int, [C.POINTER(pn_mlp), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -13,7 +13,9 @@
 namespace pn {
 
 enum { TA_PLAIN = 0, TA_DZ_ELEM = 1, TA_DZ_ROWG = 2 };
-enum { TB_PLAIN = 0, TB_AFFINE_RELU = 1, TB_PAIRSUM_RELU = 2, TB_PAIRPROD = 3 };  // 3: B[r % pairB] * B2[r / pairB]
+enum { TB_PLAIN = 0, TB_AFFINE_RELU = 1, TB_PAIRSUM_RELU = 2, TB_PAIRPROD = 3, TB_CONVTAP = 4 };
+// 3: B[r % pairB] * B2[r / pairB];  4: one tap of the masked dilated-conv input (weight gradient of MaskedConv1D):
+//    row p = (b, t) reads B[p + shift] when 0 <= t + shift < len[b] (else 0), then relu(b_s*x + b_t) if b_s != null
 
 struct TnParams {
   long R;               // contraction extent (rows)
@@ -38,6 +40,9 @@ struct TnParams {
   const float* B2;
   long ldb2;
   int pairB;
+  const int* lens;  // TB_CONVTAP: int32 sequence lengths
+  int L;            //             positions per sequence
+  int shift;        //             (tap - k/2) * dilation
   // ---- output ----
   float* Cpart;  // [nsplit][M][ldc]
   long ldc;
@@ -100,15 +105,15 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
       mq = ld4(p.m_q + am);
     }
   }
-  if constexpr (TB == TB_AFFINE_RELU) {
-    if (b_ok) {
+  if constexpr (TB == TB_AFFINE_RELU || TB == TB_CONVTAP) {
+    if (b_ok && p.b_s != nullptr) {
       bs = ld4(p.b_s + bn);
       bt = ld4(p.b_t + bn);
     }
   }
 
   float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
-  unsigned rowok = 0;
+  unsigned rowok = 0, tapok = 0;
 
   // branch-free fetch: rows past the split end are clamped to the split's first row and zeroed by selects in
   // commit().  The pair-grid decode (i = r % B, j = r / B) of the thread's first row is carried incrementally
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   }
   auto fetch = [&](long k0) {
     rowok = 0;
+    tapok = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       long r = k0 + rr + 8 * q;
@@ -145,6 +151,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         j = ok ? j : 0;
         rb[q] = ld4(p.B + (long)i * p.ldb + bnc);
         rb2[q] = ld4(p.B2 + (long)j * p.ldb2 + bnc);
+      } else if constexpr (TB == TB_CONVTAP) {
+        const int b = (int)(r / p.L);
+        const int t = (int)(r - (long)b * p.L) + p.shift;
+        const bool tap_ok = ok && t >= 0 && t < p.lens[b];
+        tapok |= (tap_ok ? 1u : 0u) << q;
+        rb[q] = ld4(p.B + (tap_ok ? r + p.shift : r_begin) * p.ldb + bnc);
       } else {
         rb[q] = ld4(p.B + r * p.ldb + bnc);
       }
@@ -184,6 +196,16 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         a.w = (fmaf(a.w, ms.w, mt.w) > 0.f ? g.w * mcs.w : 0.f) + fmaf(mq.w, a.w, mp.w);
       }
       float4 b = rb[q];
+      bool bok = ok && b_ok;
+      if constexpr (TB == TB_CONVTAP) {
+        bok = b_ok && ((tapok >> q) & 1u);
+        if (p.b_s != nullptr) {
+          b.x = relu(fmaf(b.x, bs.x, bt.x));
+          b.y = relu(fmaf(b.y, bs.y, bt.y));
+          b.z = relu(fmaf(b.z, bs.z, bt.z));
+          b.w = relu(fmaf(b.w, bs.w, bt.w));
+        }
+      }
       if constexpr (TB == TB_AFFINE_RELU) {
         b.x = relu(fmaf(b.x, bs.x, bt.x));
         b.y = relu(fmaf(b.y, bs.y, bt.y));
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         b.w = relu(b.w + rb2[q].w);
       }
       *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = sel4(ok && a_ok, a);
-      *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = sel4(ok && b_ok, b);
+      *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = sel4(bok, b);
     }
   };
 

@@ -281,6 +281,9 @@ __global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq
     bn.running_var[c] = (1.f - momentum) * bn.running_var[c] + momentum * (float)unb;
     if (mean_out) mean_out[c] = (float)mean;
     if (invstd_out) invstd_out[c] = invstd;
+  } else {  // pad lane: keep every saved vector finite
+    if (mean_out) mean_out[c] = 0.f;
+    if (invstd_out) invstd_out[c] = 0.f;
   }
   s[c] = sc;
   t[c] = sh;
@@ -421,94 +424,142 @@ extern "C" size_t pn_encoder_ws_bytes(const pn_encoder* enc, int B, int L) {
   return bp.off;
 }
 
-extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
-                              float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
-  if (B <= 0 || L <= 0) return fail("encoder: empty batch");
-  Bump bp(ws, ws_bytes);
-  EncWs w;
-  if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
+// activations and BN statistics kept from a training forward for the encoder backward (TRAIN_SEQUENCE_ENCODER)
+struct EncSave {
+  int* lens32;
+  float* x0;                         // [P][ld4(Cin)] masked channels-last input
+  float* X[PN_MAX_BLOCKS + 1];       // X[0] = conv1 output, X[i+1] = block i output, each [P][ld4(C)]
+  float* Z[PN_MAX_BLOCKS];           // conv_a outputs [P][ld4(Cb)]
+  float *s1[PN_MAX_BLOCKS], *t1[PN_MAX_BLOCKS], *m1[PN_MAX_BLOCKS], *i1[PN_MAX_BLOCKS];
+  float *s2[PN_MAX_BLOCKS], *t2[PN_MAX_BLOCKS], *m2[PN_MAX_BLOCKS], *i2[PN_MAX_BLOCKS];
+};
+
+static bool enc_save_carve(const pn_encoder* e, int B, int L, Bump& bp, EncSave& sv) {
+  const long P = (long)B * L;
+  const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
+  sv.lens32 = bp.take<int>(B);
+  sv.x0 = bp.take<float>(P * ldi);
+  for (int i = 0; i <= e->nblocks; ++i) sv.X[i] = bp.take<float>(P * ldc);
+  for (int i = 0; i < e->nblocks; ++i) {
+    sv.Z[i] = bp.take<float>(P * ldb);
+    sv.s1[i] = bp.take<float>(ldc); sv.t1[i] = bp.take<float>(ldc);
+    sv.m1[i] = bp.take<float>(ldc); sv.i1[i] = bp.take<float>(ldc);
+    sv.s2[i] = bp.take<float>(ldb); sv.t2[i] = bp.take<float>(ldb);
+    sv.m2[i] = bp.take<float>(ldb); sv.i2[i] = bp.take<float>(ldb);
+  }
+  return bp.ok;
+}
+
+extern "C" size_t pn_encoder_train_save_bytes(const pn_encoder* enc, int B, int L) {
+  Bump bp(nullptr, (size_t)-1);
+  EncSave sv;
+  enc_save_carve(enc, B, L, bp, sv);
+  return bp.off + 256;
+}
+
+static int encoder_forward(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L, float* emb,
+                           int ld_emb, int training, EncWs& w, EncSave* sv, hipStream_t st) {
   const long P = (long)B * L;
   if (P > 0x7fffffffL) return fail("encoder: B*L too large");
   const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
   const float bn_eps = 1e-3f, bn_mom = 0.01f;  // protein_encoders.py:36,48
+  int* lens32 = sv ? sv->lens32 : w.lens32;
+  float* x0 = sv ? sv->x0 : w.x0;
 
-  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, w.lens32, B);
-  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, w.lens32, w.x0, B, e->Cin, L,
-                     ldi);
+  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, lens32, B);
+  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
+                     L, ldi);
   HIP_OK(hipGetLastError());
 
-  auto conv = [&](const float* in, int ld_in, int Cin_, const float* wpk, const float* bias, int Cout, int ld_out,
-                  float* out, int ntap, int dil, const float* s, const float* t, const float* resid,
-                  double* csum, double* csq) -> int {
+  auto conv = [&](const float* in, int ld_in, const float* wpk, const float* bias, int Cout, int ld_out, float* out,
+                  int ntap, int dil, const float* s, const float* t, const float* resid, double* csum,
+                  double* csq) -> int {
     GemmParams p = gp_zero();
-    p.M = (int)P;
-    p.N = Cout;
-    p.Nstore = ld_out;
-    p.nseg = ntap;
-    p.Kseg = ld_in;
-    p.A = in;
-    p.lda = ld_in;
-    p.a_scale = s;
-    p.a_shift = t;
-    p.lens = w.lens32;
-    p.L = L;
-    p.dil = dil;
-    p.W = wpk;
-    p.ldw = (long)ntap * ld_in;
-    p.C = out;
-    p.ldc = ld_out;
-    p.bias = bias;
-    p.resid = resid;
-    p.ldr = ld_out;
-    p.col_sum = csum;
-    p.col_sumsq = csq;
-    (void)Cin_;
+    p.M = (int)P; p.N = Cout; p.Nstore = ld_out; p.nseg = ntap; p.Kseg = ld_in;
+    p.A = in; p.lda = ld_in; p.a_scale = s; p.a_shift = t; p.lens = lens32; p.L = L; p.dil = dil;
+    p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.bias = bias; p.resid = resid; p.ldr = ld_out;
+    p.col_sum = csum; p.col_sumsq = csq;
     const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
     return launch_gemm<A_CONV, E_CONV>(p, big ? 3 : pick_variant(ld_out), st);
   };
 
   // conv1: MaskedConv1D(Cin -> C, k, dil 1), no BN/ReLU in front (protein_encoders.py:84-91,110)
-  float* x = w.xa;
+  float* x = sv ? sv->X[0] : w.xa;
   float* xn = w.xb;
   if (training) HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
-  PN_OK(conv(w.x0, ldi, e->Cin, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
+  PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
              training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
 
   int dil = 1;
   for (int i = 0; i < e->nblocks; ++i) {
     const pn_res_block& bk = e->blk[i];
+    float* s1 = sv ? sv->s1[i] : w.s1;
+    float* t1 = sv ? sv->t1[i] : w.t1;
+    float* s2 = sv ? sv->s2[i] : w.s2;
+    float* t2 = sv ? sv->t2[i] : w.t2;
+    float* z = sv ? sv->Z[i] : w.z;
+    if (sv) xn = sv->X[i + 1];
     // bn_activation_1 folded into conv_a's operand load
     if (training) {
-      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, w.sum_x, w.sq_x,
-                         (double)P, bn_eps, bn_mom, e->C, ldc, w.s1, w.t1, (float*)nullptr, (float*)nullptr);
+      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const double*)w.sum_x,
+                         (const double*)w.sq_x, (double)P, bn_eps, bn_mom, e->C, ldc, s1, t1,
+                         sv ? sv->m1[i] : (float*)nullptr, sv ? sv->i1[i] : (float*)nullptr);
       HIP_OK(hipMemsetAsync(w.sum_z, 0, 2 * (size_t)ldb * sizeof(double), st));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const float*)nullptr,
-                         bn_eps, e->C, ldc, w.s1, w.t1);
+                         bn_eps, e->C, ldc, s1, t1);
     }
-    PN_OK(conv(x, ldc, e->C, bk.conv_a_w, bk.conv_a_b, e->Cb, ldb, w.z, e->ksize, dil, w.s1, w.t1, nullptr,
+    PN_OK(conv(x, ldc, bk.conv_a_w, bk.conv_a_b, e->Cb, ldb, z, e->ksize, dil, s1, t1, nullptr,
                training ? w.sum_z : nullptr, training ? w.sq_z : nullptr));
     if (training) {
-      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, w.sum_z, w.sq_z,
-                         (double)P, bn_eps, bn_mom, e->Cb, ldb, w.s2, w.t2, (float*)nullptr, (float*)nullptr);
+      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const double*)w.sum_z,
+                         (const double*)w.sq_z, (double)P, bn_eps, bn_mom, e->Cb, ldb, s2, t2,
+                         sv ? sv->m2[i] : (float*)nullptr, sv ? sv->i2[i] : (float*)nullptr);
       HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const float*)nullptr,
-                         bn_eps, e->Cb, ldb, w.s2, w.t2);
+                         bn_eps, e->Cb, ldb, s2, t2);
     }
     const bool need_stats = training && (i + 1 < e->nblocks);
-    PN_OK(conv(w.z, ldb, e->Cb, bk.conv_b_w, bk.conv_b_b, e->C, ldc, xn, 1, 1, w.s2, w.t2, x,
-               need_stats ? w.sum_x : nullptr, need_stats ? w.sq_x : nullptr));
-    float* tmp = x;
-    x = xn;
-    xn = tmp;
+    PN_OK(conv(z, ldb, bk.conv_b_w, bk.conv_b_b, e->C, ldc, xn, 1, 1, s2, t2, x, need_stats ? w.sum_x : nullptr,
+               need_stats ? w.sq_x : nullptr));
+    if (sv) {
+      x = xn;
+    } else {
+      float* tmp = x;
+      x = xn;
+      xn = tmp;
+    }
     dil *= e->dil_base;
   }
-  hipLaunchKernelGGL(k_pool, dim3(nblk(e->C, 256), B), dim3(256), 0, st, x, w.lens32, emb, L, e->C, ldc, ld_emb);
+  hipLaunchKernelGGL(k_pool, dim3(nblk(e->C, 256), B), dim3(256), 0, st, (const float*)x, (const int*)lens32, emb, L,
+                     e->C, ldc, ld_emb);
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
+                              float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream) {
+  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
+  if (B <= 0 || L <= 0) return fail("encoder: empty batch");
+  Bump bp(ws, ws_bytes);
+  EncWs w;
+  if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
+  return encoder_forward(e, onehots, lens, B, L, emb, ld_emb, training, w, nullptr, (hipStream_t)stream);
+}
+
+// training forward that keeps what the backward needs (block inputs, conv_a outputs, BN batch statistics)
+extern "C" int pn_encoder_fwd_train(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
+                                    float* emb, int ld_emb, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
+  if (B <= 0 || L <= 0) return fail("encoder: empty batch");
+  Bump bp(ws, ws_bytes), bs(save, save_bytes);
+  EncWs w;
+  EncSave sv;
+  if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
+  if (!enc_save_carve(e, B, L, bs, sv)) return fail("encoder: save buffer too small (%zu given)", save_bytes);
+  return encoder_forward(e, onehots, lens, B, L, emb, ld_emb, 1, w, &sv, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1731,5 +1782,157 @@ extern "C" int pn_onehot_batch(const uint8_t* ids, const int64_t* offsets, int B
   hipLaunchKernelGGL(k_onehot_batch, dim3(nblk((long)B * A * Lmax, 256)), dim3(256), 0, (hipStream_t)stream, ids,
                      offsets, B, A, Lmax, onehots, lengths);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder backward (TRAIN_SEQUENCE_ENCODER: True; reference ProtNote.py:248-256 + autograd through
+// protein_encoders.py:8-118).  Gradients live on valid positions only: every conv input and output is masked, so a
+// padded position's gradient can reach neither a parameter nor a valid position (BN statistics see du = 0 there).
+// ------------------------------------------------------------------------------------------------
+struct EncBwdWs {
+  float *g, *T1, *T2, *cs, *p, *q, *WbT, *WtA, *dWpk, *part;
+  double *S1, *S2, *col;
+  size_t part_floats;
+};
+
+static bool enc_bwd_carve(const pn_encoder* e, int B, int L, Bump& bp, EncBwdWs& w) {
+  const long P = (long)B * L;
+  const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
+  w.g = bp.take<float>(P * ldc);
+  w.T1 = bp.take<float>(P * ldb);
+  w.T2 = bp.take<float>(P * ldc);
+  w.cs = bp.take<float>(ldc);
+  w.p = bp.take<float>(ldc);
+  w.q = bp.take<float>(ldc);
+  w.WbT = bp.take<float>((size_t)ldb * ldc);
+  w.WtA = bp.take<float>((size_t)e->C * e->ksize * ldb);
+  const size_t pk_a = (size_t)ldb * e->ksize * ldc, pk_1 = (size_t)ldc * e->ksize * ldi, pk_b = (size_t)ldc * ldb;
+  size_t pk = pk_a > pk_1 ? pk_a : pk_1;
+  if (pk_b > pk) pk = pk_b;
+  w.dWpk = bp.take<float>(pk);
+  w.part_floats = (size_t)8 * ldc * ldc;
+  w.part = bp.take<float>(w.part_floats);
+  w.S1 = bp.take<double>(ldc);
+  w.S2 = bp.take<double>(ldc);
+  w.col = bp.take<double>(ldc);
+  return bp.ok;
+}
+
+extern "C" size_t pn_encoder_bwd_ws_bytes(const pn_encoder* enc, int B, int L) {
+  Bump bp(nullptr, (size_t)-1);
+  EncBwdWs w;
+  enc_bwd_carve(enc, B, L, bp, w);
+  return bp.off + 256;
+}
+
+extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* demb, int ld_demb,
+                              const pn_encoder_grads* gr, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder bwd: too many blocks");
+  Bump bs(save, save_bytes), bw(ws, ws_bytes);
+  EncSave sv;
+  EncBwdWs w;
+  if (!enc_save_carve(e, B, L, bs, sv)) return fail("encoder bwd: save buffer too small");
+  if (!enc_bwd_carve(e, B, L, bw, w)) return fail("encoder bwd: workspace too small");
+  const long P = (long)B * L;
+  const int C = e->C, Cb = e->Cb, k = e->ksize;
+  const int ldc = ld4(C), ldb = ld4(Cb), ldi = ld4(e->Cin);
+
+  auto colsum_to = [&](const float* X, int ld, int cols, float* dst) -> int {  // bias gradient
+    HIP_OK(hipMemsetAsync(w.col, 0, (size_t)ldc * sizeof(double), st));
+    hipLaunchKernelGGL(k_colsum, dim3(nblk(cols, 256), nblk(P, 2048)), dim3(256), 0, st, X, (long)ld, P, cols, 2048L,
+                       w.col);
+    hipLaunchKernelGGL(k_d2f, dim3(nblk(cols, 256)), dim3(256), 0, st, (const double*)w.col, dst, cols, 1.f);
+    HIP_OK(hipGetLastError());
+    return 0;
+  };
+  // BN + ReLU backward of `G` (gradient wrt mask * relu(bn(Zin))) -> out = [addto +] mask_pad * dz
+  auto bn_relu_bwd = [&](const float* Zin, int ld, int cols, const pn_bn& bn, const float* s, const float* t,
+                         const float* mean, const float* invstd, const float* G, float* dgamma, float* dbeta,
+                         float* out, const float* addto) -> int {
+    HIP_OK(hipMemsetAsync(w.S1, 0, (size_t)ldc * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.S2, 0, (size_t)ldc * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(w.cs, 0, (size_t)ldc * sizeof(float), st));
+    HIP_OK(hipMemsetAsync(w.p, 0, (size_t)ldc * sizeof(float), st));
+    HIP_OK(hipMemsetAsync(w.q, 0, (size_t)ldc * sizeof(float), st));
+    StatsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.R = P; sp.C = ld; sp.rows_per_block = 1024; sp.pairB = 1;
+    sp.Z = Zin; sp.ldz = ld; sp.G = G; sp.ldg = ld; sp.s = s; sp.t = t; sp.mean = mean; sp.invstd = invstd;
+    sp.S1 = w.S1; sp.S2 = w.S2;
+    hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(ld, 1024), nblk(P, 1024)), dim3(256), 0, st, sp);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(cols, 256)), dim3(256), 0, st, (const double*)w.S1,
+                       (const double*)w.S2, (const double*)nullptr, (double)P, cols, bn.weight, s, mean, invstd,
+                       (const float*)nullptr, w.cs, w.p, w.q, dgamma, dbeta, (float*)nullptr);
+    DzParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.R = P; dp.C = ld; dp.rows_per_block = 512;
+    dp.Z = Zin; dp.ldz = ld; dp.G = G; dp.ldg = ld; dp.s = s; dp.t = t; dp.cs = w.cs; dp.p = w.p; dp.q = w.q;
+    dp.out = out; dp.ldo = ld; dp.lens = sv.lens32; dp.L = L; dp.addto = addto;
+    hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(ld, 1024), nblk(P, 512)), dim3(256), 0, st, dp);
+    HIP_OK(hipGetLastError());
+    return 0;
+  };
+  // weight gradient of one MaskedConv1D: dW[co][tap][ci] = sum_p dY[p][co] * in_act[p + shift(tap)][ci]
+  auto conv_wgrad = [&](const float* dY, int ld_y, int Cout, const float* in, int ld_in, int Cin, int ntap, int dil,
+                        const float* s, const float* t, float* dst_torch) -> int {
+    for (int tap = 0; tap < ntap; ++tap) {
+      TnParams tp = tn_zero();
+      tp.R = P; tp.M = ld_y; tp.N = ld_in; tp.A = dY; tp.lda = ld_y;
+      tp.B = in; tp.ldb = ld_in; tp.b_s = s; tp.b_t = t; tp.lens = sv.lens32; tp.L = L;
+      tp.shift = (tap - ntap / 2) * dil;
+      PN_OK((launch_tn<TA_PLAIN, TB_CONVTAP>(tp, w.dWpk + (size_t)tap * ld_in, (long)ntap * ld_in, w.part,
+                                              w.part_floats, st)));
+    }
+    hipLaunchKernelGGL(k_unpack_conv_grad, dim3(nblk((long)Cout * Cin * ntap, 256)), dim3(256), 0, st,
+                       (const float*)w.dWpk, Cout, Cin, ntap, ld_in, dst_torch);
+    HIP_OK(hipGetLastError());
+    return 0;
+  };
+  auto conv_nt = [&](const float* in, int ld_in, const float* wpk, int Cout, int ld_out, float* out, int ntap,
+                     int dil) -> int {  // masked conv without bias / affine (data gradients)
+    GemmParams p = gp_zero();
+    p.M = (int)P; p.N = Cout; p.Nstore = ld_out; p.nseg = ntap; p.Kseg = ld_in;
+    p.A = in; p.lda = ld_in; p.lens = sv.lens32; p.L = L; p.dil = dil;
+    p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.ldr = ld_out;
+    return launch_gemm<A_CONV, E_CONV>(p, pick_variant(ld_out), st);
+  };
+
+  // d(pool): gradient wrt the last block output
+  hipLaunchKernelGGL(k_pool_bwd, dim3(nblk(P * ldc, 256)), dim3(256), 0, st, demb, ld_demb, (const int*)sv.lens32, L,
+                     C, ldc, P, w.g);
+  HIP_OK(hipGetLastError());
+
+  int dil = 1;
+  for (int i = 1; i < e->nblocks; ++i) dil *= e->dil_base;
+  for (int i = e->nblocks - 1; i >= 0; --i) {
+    const pn_res_block& bk = e->blk[i];
+    const pn_res_block_grads& gb = gr->blk[i];
+    // ---- masked_conv2 (1x1, Cb -> C): y = conv(b_act) + bias, X[i+1] = mask*y + X[i]; dy = g
+    PN_OK(colsum_to(w.g, ldc, C, gb.conv_b_b));
+    PN_OK(conv_wgrad(w.g, ldc, C, sv.Z[i], ldb, Cb, 1, 1, sv.s2[i], sv.t2[i], gb.conv_b_w));
+    HIP_OK(hipMemsetAsync(w.WbT, 0, (size_t)ldb * ldc * sizeof(float), st));
+    PN_OK(transpose_into(bk.conv_b_w, ldb, C, ldb, w.WbT, ldc, st));  // [Cb(pad)][ldc]
+    PN_OK(conv_nt(w.g, ldc, w.WbT, Cb, ldb, w.T1, 1, 1));               // d b_act  [P][ldb]
+    // ---- bn_activation_2 -> dz (masked conv_a output gradient), in place over T1
+    PN_OK(bn_relu_bwd(sv.Z[i], ldb, Cb, bk.bn2, sv.s2[i], sv.t2[i], sv.m2[i], sv.i2[i], w.T1, gb.bn2_w, gb.bn2_b,
+                      w.T1, nullptr));
+    // ---- masked_conv1 (k taps, dilated, C -> Cb)
+    PN_OK(colsum_to(w.T1, ldb, Cb, gb.conv_a_b));
+    PN_OK(conv_wgrad(w.T1, ldb, Cb, sv.X[i], ldc, C, k, dil, sv.s1[i], sv.t1[i], gb.conv_a_w));
+    hipLaunchKernelGGL(k_conv_w_dgrad, dim3(nblk((long)C * k * ldb, 256)), dim3(256), 0, st, bk.conv_a_w, Cb, C, k,
+                       ldc, ldb, w.WtA);
+    HIP_OK(hipGetLastError());
+    PN_OK(conv_nt(w.T1, ldb, w.WtA, C, ldc, w.T2, k, dil));           // d a_act  [P][ldc]
+    // ---- bn_activation_1 + residual: g <- g + mask * dz1
+    PN_OK(bn_relu_bwd(sv.X[i], ldc, C, bk.bn1, sv.s1[i], sv.t1[i], sv.m1[i], sv.i1[i], w.T2, gb.bn1_w, gb.bn1_b, w.g,
+                      w.g));
+    dil /= e->dil_base;
+  }
+  // ---- conv1 (Cin -> C, no BN in front): dy = g
+  PN_OK(colsum_to(w.g, ldc, C, gr->conv1_b));
+  PN_OK(conv_wgrad(w.g, ldc, C, sv.x0, ldi, e->Cin, k, 1, nullptr, nullptr, gr->conv1_w));
   return 0;
 }

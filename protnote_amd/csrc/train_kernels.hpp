@@ -112,6 +112,9 @@ struct DzParams {
   const float *s, *t, *cs, *p, *q;
   float* out;
   long ldo;
+  const int* lens;     // optional: rows are positions (b, t); dz is zeroed for t >= lens[b] (MaskedConv1D output mask)
+  int L;
+  const float* addto;  // optional: out = addto + dz (residual branch of the encoder blocks), ld = ldo
 };
 
 template <int ROWG>
@@ -137,8 +140,66 @@ __global__ __launch_bounds__(256) void k_dz_apply(const DzParams P) {
     o.y = (fmaf(z.y, s.y, t.y) > 0.f ? g.y * cs.y : 0.f) + fmaf(q.y, z.y, pp.y);
     o.z = (fmaf(z.z, s.z, t.z) > 0.f ? g.z * cs.z : 0.f) + fmaf(q.z, z.z, pp.z);
     o.w = (fmaf(z.w, s.w, t.w) > 0.f ? g.w * cs.w : 0.f) + fmaf(q.w, z.w, pp.w);
+    if (P.lens != nullptr) {
+      const long b = r / P.L;
+      if ((int)(r - b * P.L) >= P.lens[b]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (P.addto != nullptr) {
+      const float4 a = ld4(P.addto + r * P.ldo + c);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
     *reinterpret_cast<float4*>(P.out + r * P.ldo + c) = o;
   }
+}
+
+// ---------------- encoder backward helpers (TRAIN_SEQUENCE_ENCODER) ----------------
+// gradient of the masked mean-pool (protein_encoders.py:114-117): g[p][c] = t < len ? demb[b][c] / len : 0
+__global__ void k_pool_bwd(const float* __restrict__ demb, int ld_emb, const int* __restrict__ lens, int L, int C,
+                           int ld, long P, float* __restrict__ g) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * ld) return;
+  const long p = i / ld;
+  const int c = (int)(i - p * ld);
+  const int b = (int)(p / L), t = (int)(p - (long)b * L);
+  const int len = lens[b];
+  g[i] = (c < C && t < len) ? demb[(long)b * ld_emb + c] / (float)len : 0.f;
+}
+
+// column sums of X[P][ld] (bias gradients): out[c] += sum_p X[p][c]; grid (ld/256 cols, row chunks)
+__global__ void k_colsum(const float* __restrict__ X, long ld, long P, int C, long rows_per_block, double* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  double a = 0;
+  for (long r = r0; r < r1; ++r) a += X[r * ld + c];
+  atomicAdd(&out[c], a);
+}
+
+// forward-packed conv weight [Cout][k][ld4(Cin)] -> data-gradient weight [Cin][k][ld4(Cout)] with the taps reversed:
+// dX[p][ci] = sum_seg sum_co dY[p + (seg - k/2) dil][co] * W[co][ci][k-1-seg]
+__global__ void k_conv_w_dgrad(const float* __restrict__ packed, int Cout, int Cin, int k, int ldci, int ldco,
+                               float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)Cin * k * ldco;
+  if (i >= total) return;
+  const int co = (int)(i % ldco);
+  const int seg = (int)((i / ldco) % k);
+  const int ci = (int)(i / ((long)ldco * k));
+  out[i] = (co < Cout) ? packed[((long)co * k + (k - 1 - seg)) * ldci + ci] : 0.f;
+}
+
+// packed weight gradient [Mpad][k][ldci] -> torch Conv1d layout [Cout][Cin][k]
+__global__ void k_unpack_conv_grad(const float* __restrict__ packed, int Cout, int Cin, int k, int ldci,
+                                   float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)Cout * Cin * k;
+  if (i >= total) return;
+  const int tap = (int)(i % k);
+  const int ci = (int)((i / k) % Cin);
+  const int co = (int)(i / ((long)k * Cin));
+  out[i] = packed[((long)co * k + tap) * ldci + ci];
 }
 
 // From S1,S2: dgamma = S2, dbeta = S1 and the per-column vectors of the dz generator

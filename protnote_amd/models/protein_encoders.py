@@ -69,7 +69,8 @@ class ProteInfer(torch.nn.Module):
         w = conv.weight
         key = (w._version, w.data_ptr(), w.device)
         hit = self._packed.get(name)
-        if hit is not None and hit[0] == key:
+        # a trainable weight may be updated through raw pointers (FusedClipAdam) without a version bump: repack
+        if hit is not None and hit[0] == key and not w.requires_grad:
             return hit[1]
         cout, cin, k = w.shape
         packed = torch.empty(cout, k, _ld4(cin), dtype=torch.float32, device=w.device)
@@ -103,14 +104,25 @@ class ProteInfer(torch.nn.Module):
             b.conv_b_b = blk.masked_conv2.bias.data_ptr()
         return enc, keep
 
+    def trunk_parameters(self):
+        """Parameters reached by get_embeddings, in the order _EncoderTrainFn returns their gradients."""
+        ps = [self.conv1.weight, self.conv1.bias]
+        for blk in self.resnet_blocks:
+            bn1, bn2 = blk.bn_activation_1[0], blk.bn_activation_2[0]
+            ps += [bn1.weight, bn1.bias, blk.masked_conv1.weight, blk.masked_conv1.bias, bn2.weight, bn2.bias,
+                   blk.masked_conv2.weight, blk.masked_conv2.bias]
+        return ps
+
     def get_embeddings(self, x, sequence_lengths):
         """[B, Cin, L] f32 one-hots + [B] lengths -> [B, C] masked mean-pooled features
         (reference protein_encoders.py:109-118).  In train mode BatchNorm uses batch statistics and
-        updates its running buffers exactly like the reference's "frozen" encoder does."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "TRAIN_SEQUENCE_ENCODER=True (encoder backward) is not implemented; freeze the encoder "
-                "(reference default, base_config.yaml:71) or call under torch.no_grad()")
+        updates its running buffers exactly like the reference's "frozen" encoder does.
+        With gradients enabled and trainable parameters (TRAIN_SEQUENCE_ENCODER: True) the call is differentiable:
+        pn_encoder_fwd_train keeps the activations, pn_encoder_bwd returns every parameter gradient."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.trunk_parameters()):
+            if not self.training:
+                raise NotImplementedError("differentiating the encoder in eval mode is not implemented")
+            return _EncoderTrainFn.apply(self, x, sequence_lengths, *self.trunk_parameters())
         L.require_hip(x, sequence_lengths)
         if x.dim() != 3 or x.shape[1] != self._dims["Cin"]:
             raise ValueError(f"expected [B, {self._dims['Cin']}, L] input, got {tuple(x.shape)}")
@@ -126,11 +138,14 @@ class ProteInfer(torch.nn.Module):
         L.check(lib.pn_encoder_fwd(C.byref(enc), L.ptr(x), L.ptr(lens), B, Lmax, L.ptr(emb), emb.shape[1],
                                    training, L.ptr(ws), ws.numel(), L.stream_ptr()))
         if training:
-            for blk in self.resnet_blocks:
-                blk.bn_activation_1[0].num_batches_tracked += 1
-                blk.bn_activation_2[0].num_batches_tracked += 1
+            self._bump_batches_tracked()
         del keep
         return emb
+
+    def _bump_batches_tracked(self):
+        for blk in self.resnet_blocks:
+            blk.bn_activation_1[0].num_batches_tracked += 1
+            blk.bn_activation_2[0].num_batches_tracked += 1
 
     def forward(self, x, sequence_lengths):
         """Reference protein_encoders.py:120-123: Linear(C -> num_labels) on the pooled features."""
@@ -155,3 +170,46 @@ class ProteInfer(torch.nn.Module):
                     num_resnet_blocks, bottleneck_factor)
         transfer_tf_weights_to_torch(model, weights_path)
         return model
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    """Differentiable ProteInfer.get_embeddings (TRAIN_SEQUENCE_ENCODER: True, reference ProtNote.py:248-256)."""
+
+    @staticmethod
+    def forward(ctx, enc_mod, x, lens, *params):
+        L.require_hip(x, lens)
+        x = x.detach().contiguous().float()
+        lens = lens.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        B, _, Lmax = x.shape
+        enc, keep = enc_mod._descriptor()
+        lib = L.lib()
+        save = torch.empty(lib.pn_encoder_train_save_bytes(C.byref(enc), B, Lmax), dtype=torch.uint8, device=x.device)
+        ws = L.workspace(lib.pn_encoder_ws_bytes(C.byref(enc), B, Lmax), x.device, "enc")
+        emb = torch.empty(B, enc_mod._dims["C"], dtype=torch.float32, device=x.device)
+        L.check(lib.pn_encoder_fwd_train(C.byref(enc), L.ptr(x), L.ptr(lens), B, Lmax, L.ptr(emb), emb.shape[1],
+                                         L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        enc_mod._bump_batches_tracked()
+        ctx.enc_mod, ctx.save, ctx.shape, ctx.params = enc_mod, save, (B, Lmax), params
+        del keep
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        enc_mod, (B, Lmax) = ctx.enc_mod, ctx.shape
+        enc, keep = enc_mod._descriptor()
+        lib = L.lib()
+        demb = demb.contiguous().float()
+        grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in ctx.params]
+        gr = L.pn_encoder_grads()
+        gr.conv1_w, gr.conv1_b = grads[0].data_ptr(), grads[1].data_ptr()
+        names = ("bn1_w", "bn1_b", "conv_a_w", "conv_a_b", "bn2_w", "bn2_b", "conv_b_w", "conv_b_b")
+        for i in range(enc_mod._dims["nblocks"]):
+            for j, n in enumerate(names):
+                setattr(gr.blk[i], n, grads[2 + 8 * i + j].data_ptr())
+        ws = L.workspace(lib.pn_encoder_bwd_ws_bytes(C.byref(enc), B, Lmax), demb.device, "encbwd")
+        L.check(lib.pn_encoder_bwd(C.byref(enc), B, Lmax, L.ptr(demb), demb.shape[1], C.byref(gr), L.ptr(ctx.save),
+                                   ctx.save.numel(), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        del keep
+        ctx.save = None
+        outs = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:])]
+        return (None, None, None, *outs)

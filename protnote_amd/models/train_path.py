@@ -149,7 +149,7 @@ class _HeadsTrainFn(torch.autograd.Function):
     @staticmethod
     def _finish(ctx, model, lib, st, dev, P_f, L_f, dP_e, dL_e, grads, gbuf):
         # ---- projection heads ----
-        def mlp_bwd(seq, x, dy, tag):
+        def mlp_bwd(seq, x, dy, tag, dx=None):
             m, layers = model._mlp_desc(seq)
             g = L.pn_mlp_grads()
             for i, (lin, bn) in enumerate(layers):
@@ -160,17 +160,18 @@ class _HeadsTrainFn(torch.autograd.Function):
             rows = x.shape[0]
             sv = _save_buf(model, tag, 0, dev)
             w = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
-            L.check(lib.pn_mlp_rows_bwd(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(dy), C.byref(g), None, L.ptr(sv),
-                                        sv.numel(), L.ptr(w), w.numel(), st))
+            L.check(lib.pn_mlp_rows_bwd(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(dy), C.byref(g), L.ptr(dx),
+                                        L.ptr(sv), sv.numel(), L.ptr(w), w.numel(), st))
 
-        mlp_bwd(model.W_p, P_f, dP_e, "W_p")
+        dP_f = torch.empty_like(P_f) if ctx.needs_input_grad[1] else None  # TRAIN_SEQUENCE_ENCODER: True
+        mlp_bwd(model.W_p, P_f, dP_e, "W_p", dP_f)
         mlp_bwd(model.W_l, L_f, dL_e, "W_l")
 
         outs = []
         for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]):
             outs.append(grads.get(id(p)) if need else None)
         ctx.model = None
-        return (None, None, None, *outs)
+        return (None, dP_f, None, *outs)
 
 
 def head_parameters(model):
@@ -188,13 +189,18 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
         L_f = L_f.detach().float().contiguous()
         if label_token_counts is not None and model.label_embedding_noising_alpha > 0:
             L_f = model._noised(L_f, torch.rand_like(L_f))
-        if sequence_embeddings is not None and not model.train_sequence_encoder:
-            P_f = sequence_embeddings.detach().float().contiguous()
-        elif sequence_onehots is not None and sequence_lengths is not None:
-            if model.train_sequence_encoder:
-                raise NotImplementedError("TRAIN_SEQUENCE_ENCODER=True is not implemented in protnote_amd")
+    P_f = None
+    if sequence_embeddings is not None and not model.train_sequence_encoder:
+        P_f = sequence_embeddings.detach().float().contiguous()
+    elif sequence_onehots is not None and sequence_lengths is not None:
+        if model.train_sequence_encoder:
+            # reference ProtNote.py:248-256: encoder inside the autograd graph (differentiable when its
+            # parameters require grad: _EncoderTrainFn)
             P_f = model.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
         else:
-            raise ValueError("Incompatible sequence parameters passed to forward method.")
+            with torch.no_grad():
+                P_f = model.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
+    else:
+        raise ValueError("Incompatible sequence parameters passed to forward method.")
     L.require_hip(P_f, L_f)
     return _HeadsTrainFn.apply(model, P_f, L_f, *head_parameters(model))

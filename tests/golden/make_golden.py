@@ -278,6 +278,24 @@ def golden_protnote():
                 for k, v in grads.items():
                     out[p + "grad/" + k] = v
                 out.update(sd_np(m2, p + "sd_after/"))
+            if fusion == "concatenation":
+                # TRAIN_SEQUENCE_ENCODER: True - gradients reach every encoder parameter (ProtNote.py:248-256)
+                m3 = type(model)(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg), label_encoder=None,
+                                 feature_fusion=fusion, inference_descriptions_per_label=2,
+                                 train_sequence_encoder=True, **head_cfg)
+                m3.load_state_dict(model.state_dict())
+                m3.train()
+                loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+                inputs = dict(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab1,
+                              label_token_counts=cnt1)
+                logits3, _ = m3(**inputs)
+                loss3 = loss_fn(logits3, y.float())
+                loss3.backward()
+                out["train_enc_BCE/loss"] = np.array(float(loss3.detach()), dtype=np.float32)
+                out["train_enc_BCE/logits"] = logits3.detach().numpy().copy()
+                for n3, p3 in m3.named_parameters():
+                    if p3.grad is not None:
+                        out["train_enc_BCE/grad/" + n3] = p3.grad.numpy().copy()
         finally:
             PN.torch.rand_like = real_rand_like
         fn = os.path.join(OUT, f"protnote_small_{fusion}.npz")

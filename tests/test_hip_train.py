@@ -430,3 +430,83 @@ def test_torch_ddp_wrapper_compat(golden_dir):
             assert (got - ref).abs().max().item() <= 2e-5 + 2e-4 * ref.abs().max().item(), k
     finally:
         dist.destroy_process_group()
+
+
+def test_train_sequence_encoder_golden(golden_dir, monkeypatch):
+    """TRAIN_SEQUENCE_ENCODER: True (reference ProtNote.py:248-256): gradients of every encoder parameter (conv
+    weights/biases, BN affine) and of the heads vs the reference's autograd on the golden batch."""
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    g = _g(golden_dir, "protnote_small_concatenation.npz")
+    model, _ = make_protnote(g, DEV, train_sequence_encoder=True)
+    model.train()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
+    u = torch.from_numpy(g["train/noise_u"]).to(DEV)
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, label_token_counts=cnt)
+    loss = BCEWithLogitsLoss()(logits, torch.from_numpy(g["multihots"]).to(DEV).float())
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g["train_enc_BCE/loss"]), rtol=1e-4)
+    named = dict(model.named_parameters())
+    n_enc = 0
+    for k in g.files:
+        if k.startswith("train_enc_BCE/grad/"):
+            name = k[len("train_enc_BCE/grad/"):]
+            ref = g[k]
+            got = named[name].grad.cpu().numpy()
+            np.testing.assert_allclose(got, ref, atol=2e-5 + 3e-4 * np.abs(ref).max(), err_msg=name)
+            n_enc += name.startswith("sequence_encoder.")
+    assert n_enc == 18
+    assert named["sequence_encoder.output_layer.weight"].grad is None  # never reached by get_embeddings
+
+
+@pytest.mark.parametrize("C,lens,tol", [(52, [300, 37, 1, 222, 300, 150], 2e-4), (1100, [100, 37, 64, 100], 1e-2),
+                                        (1100, [300, 37, 1, 222, 300, 150], 1e-2)])
+def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
+    """k=9, 5 blocks, dilations 1..81, ragged lengths: encoder gradients vs the oracle's autograd in f64.
+    With 52 channels every gradient agrees to ~4e-6 (tight bound: the position/dilation geometry is exact).  With the
+    reference's 1100/550 channels each of the 10 BatchNorm+ReLU layers has 3e5 .. 2e6 pre-activations; one that sits
+    within f32 rounding of zero flips its ReLU mask, which alone is a ~1/sqrt(N) ~ 1e-3 relative change of that
+    layer's gradient and of everything upstream.  tools/relu_flip_probe.py reproduces exactly this with the f64
+    oracle plus 1e-6 relative noise on the conv outputs (steps of 1e-3 .. 5e-3 from the last block towards conv1), and
+    tools/debug_enc.py shows the same staircase for the HIP path (1e-5 at the last block).  Hence a norm-wise 1e-2
+    bound at full width.  (B >= 4: with B = 2 the batch-statistics BatchNorm in W_p is singular.)"""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.protein_encoders import ProteInfer
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(41)
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=C, kernel_size=9, dilation_base=3,
+                num_resnet_blocks=5, bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, C, 1024, 64, 128, 2, 128, 2))
+    lens = torch.tensor(lens)
+    B, Lmax, NL = len(lens), int(lens.max()), 24
+    ids = torch.randint(0, 20, (B, Lmax), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.3).float()
+    osd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    _, l64, g64, _ = O.train_step(osd, x.double(), lens, lab.double(), y.double(), loss="BCE", apply_update=False,
+                                  train_sequence_encoder=True)
+    enc = ProteInfer(activation=torch.nn.ReLU, **ecfg)
+    model = ProtNote(protein_embedding_dim=C, sequence_encoder=enc, latent_dim=64,
+                     output_mlp_hidden_dim_scale_factor=2, output_mlp_num_layers=2, projection_head_num_layers=2,
+                     projection_head_hidden_dim_scale_factor=2, train_sequence_encoder=True)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    logits, _ = model(sequence_onehots=x.to(DEV), sequence_lengths=lens.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(l64), rtol=1e-4)
+    gmax = max(g.abs().max().item() for n, g in g64.items() if n.startswith("sequence_encoder."))
+    for name, p in model.named_parameters():
+        if name.startswith("sequence_encoder.output_layer"):
+            continue
+        ref = g64[name]
+        # absolute floor: the last conv bias only shifts every P_f row equally, which W_p's BatchNorm removes - its
+        # true gradient is exactly 0 and the f32 result is rounding noise
+        err = (p.grad.cpu().double() - ref).norm().item()
+        assert err <= tol * ref.norm().item() + 1e-6 * gmax * ref.numel() ** 0.5, (name, err, ref.norm().item())

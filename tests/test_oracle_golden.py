@@ -114,3 +114,23 @@ def test_losses_and_metrics(golden_dir):
         assert np.array_equal(fp.numpy(), g[f"th{th}/fp"])
         np.testing.assert_array_equal(O.f1_per_label(tp, fn, fp).numpy(), g[f"th{th}/f1"])
         np.testing.assert_array_equal(O.f1_micro(tp, fn, fp).numpy(), g[f"th{th}/f1_micro"])
+
+
+def test_protnote_train_encoder_grads(golden_dir):
+    """TRAIN_SEQUENCE_ENCODER: True - the oracle's encoder gradients equal the reference's."""
+    g = _load(golden_dir, "protnote_small_concatenation.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous()
+    logits, l, grads, _ = O.train_step(
+        sd, x, lens, lab, torch.from_numpy(g["multihots"]), loss="BCE", noise_alpha=20.0,
+        noise_u=torch.from_numpy(g["train/noise_u"]), label_token_counts=cnt, apply_update=False,
+        train_sequence_encoder=True)
+    np.testing.assert_allclose(float(l), float(g["train_enc_BCE/loss"]), rtol=1e-5)
+    keys = [k for k in g.files if k.startswith("train_enc_BCE/grad/")]
+    assert sum(k.startswith("train_enc_BCE/grad/sequence_encoder.") for k in keys) == 18
+    for k in keys:
+        name = k[len("train_enc_BCE/grad/"):]
+        ref = g[k]
+        np.testing.assert_allclose(grads[name].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=name)
