@@ -231,6 +231,38 @@ int pn_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, lo
 int pn_onehot_batch(const uint8_t* ids, const int64_t* offsets, int B, int A, int Lmax, float* onehots,
                     int64_t* lengths, void* stream);
 
+/* ---- evaluation metrics on the device -----------------------------------------------------
+ * Replaces the per-batch D2H + CPU torcheval BinaryAUPRC / MultilabelAUPRC of ProtNoteTrainer.py:477-485,540-543
+ * (ESTIMATE_MAP False: exact) and the on-device Binary/MultilabelBinnedAUPRC(threshold=50) (ESTIMATE_MAP True),
+ * and torchmetrics AveragePrecision of utils/evaluation.py:148-169.  Label element types: */
+#define PN_LABEL_F32 0
+#define PN_LABEL_I64 1
+#define PN_LABEL_U8 2
+
+/* Exact AP.  The accumulator is label-major and stays in HBM for the whole evaluation: keys [N_L][cap] u32
+ * (order-preserving image of the f32 score), hits [N_L][cap] u8.  pn_ap_append transposes one batch
+ * (scores [B][ld_s] f32, labels [B][ld_y] of label_kind) into columns [n0, n0+B). */
+int pn_ap_append(const float* scores, int ld_s, const void* labels, int label_kind, int ld_y, int B, int N_L,
+                 uint32_t* keys, uint8_t* hits, long long cap, long long n0, void* stream);
+/* AP over the first n columns: per label -> ap [N_L] f64 (NaN where a label has no positive), npos [N_L] i64
+ * (optional); if micro_ap != NULL also the AP over all N_L*n pairs -> micro_ap [1], micro_npos [1] (optional).
+ * AP = sum over distinct score thresholds (ties share one) of (recall step) x precision, f64, deterministic.
+ * The accumulator is not modified. */
+size_t pn_ap_ws_bytes(int N_L, long long n, long long cap, int micro);
+int pn_ap_compute(const uint32_t* keys, const uint8_t* hits, int N_L, long long n, long long cap, double* ap,
+                  long long* npos, double* micro_ap, long long* micro_npos, void* ws, size_t ws_bytes, void* stream);
+
+/* Binned AUPRC.  Streaming state: pos_hist / all_hist [(N_L+1)][T+1] u64 (zero-initialised by the caller; row N_L
+ * = all labels pooled, written by pn_binned_auprc when with_micro), bin(p) = #{k : p >= thresholds[k]},
+ * thresholds [T] ascending f32 on the device (T <= 120).
+ * pn_binned_auprc: out [N_L (+1 if with_micro)] f64, area = sum_k (recall_k - recall_{k+1}) precision_k with
+ * precision = 1 where nothing is predicted and a final (1, 0) point; NaN where a label has no positive. */
+int pn_binned_hist_update(const float* scores, int ld_s, const void* labels, int label_kind, int ld_y, int B, int N_L,
+                          const float* thresholds, int T, unsigned long long* pos_hist, unsigned long long* all_hist,
+                          void* stream);
+int pn_binned_auprc(unsigned long long* pos_hist, unsigned long long* all_hist, int N_L, int T, double* out,
+                    long long* npos, int with_micro, void* stream);
+
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
  * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller

@@ -126,6 +126,15 @@ _SIGS = {
                              C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_onehot_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "pn_ap_append": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "pn_ap_ws_bytes": (C.c_size_t, [C.c_int, C.c_longlong, C.c_longlong, C.c_int]),
+    "pn_ap_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_binned_hist_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pn_binned_auprc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),

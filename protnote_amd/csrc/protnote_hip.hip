@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../include/protnote_hip.h"
+#include "common.hpp"
 #include "gemm_engine.hpp"
 
 using namespace pn;
@@ -33,6 +34,14 @@ static int fail(const char* fmt, ...) {
     int _r = (expr);        \
     if (_r != 0) return _r; \
   } while (0)
+
+int pn::fail_msg(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
 
 extern "C" const char* pn_last_error(void) { return g_err; }
 extern "C" int pn_version(void) { return 1; }

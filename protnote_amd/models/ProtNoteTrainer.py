@@ -92,11 +92,14 @@ class Trainer:
         return self._metrics(counts, loss_sum, n)
 
     @torch.no_grad()
-    def evaluate(self, loader, with_map=True):
-        from ..utils.evaluation import map_macro, map_micro
+    def evaluate(self, loader, with_map=True, estimate_map=False, map_thresholds=50):
+        """`estimate_map` follows ESTIMATE_MAP (ProtNoteTrainer.py:477-489): False -> exact AUPRC, True -> binned
+        AUPRC with `map_thresholds` thresholds; `with_map=False` is ESTIMATE_MAP: None.  Either way the scores never
+        leave the device (the reference moves every batch to the CPU, :540-543)."""
+        from ..utils.evaluation import DeviceAveragePrecision, DeviceBinnedAUPRC
 
         self.model.eval()
-        counts, loss_sum, n, all_logits, all_labels = None, 0.0, 0, [], []
+        counts, loss_sum, n, ap = None, 0.0, 0, None
         for batch in loader:
             y = batch["label_multihots"]
             if counts is None:
@@ -109,10 +112,15 @@ class Trainer:
             loss_sum += float(self.loss_fn(logits, y))
             n += 1
             if with_map:
-                all_logits.append(logits.cpu())
-                all_labels.append(y.cpu())
+                if ap is None:
+                    if estimate_map:
+                        ap = DeviceBinnedAUPRC(y.shape[1], y.device, threshold=map_thresholds)
+                    else:
+                        total = len(loader.dataset) if hasattr(loader, "dataset") else 0
+                        ap = DeviceAveragePrecision(y.shape[1], max(total, y.shape[0]), y.device, growable=True)
+                ap.update(torch.sigmoid(logits), y)   # the reference scores probabilities (:521-523)
         out = self._metrics(counts, loss_sum, n)
-        if with_map and all_logits:
-            s, t = torch.cat(all_logits).numpy(), torch.cat(all_labels).numpy()
-            out.update(map_micro=map_micro(s, t), map_macro=map_macro(s, t))
+        if ap is not None:
+            m = ap.compute()
+            out.update(map_micro=m["map_micro"], map_macro=m["map_macro"])
         return out

@@ -221,8 +221,9 @@ def test_map_parity_full_width():
     the HIP logits equals the one computed from the CPU-oracle logits on the same synthetic evaluation set
     (full-width model, 96 sequences x 300 labels, targets drawn from the oracle's own probabilities so that AP
     is far from the prevalence floor)."""
+    from oracle import metrics_oracle as MO
     from protnote_amd.models.ProtNote import ProtNote
-    from protnote_amd.utils.evaluation import map_macro, map_micro
+    from protnote_amd.utils.evaluation import DeviceAveragePrecision
 
     gen = torch.Generator().manual_seed(31)
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
@@ -237,9 +238,15 @@ def test_map_parity_full_width():
     model = model.to(DEV).eval()
     with torch.no_grad():
         out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
-    out = out.cpu().numpy()
-    mi_ref, ma_ref = map_micro(ref.numpy(), y), map_macro(ref.numpy(), y)
-    mi, ma = map_micro(out, y), map_macro(out, y)
+    # device end to end: HIP logits -> sigmoid -> resident accumulator -> HIP AP kernels; reference: oracle logits ->
+    # CPU metric oracle
+    acc = DeviceAveragePrecision(NL, B, DEV)
+    acc.update(torch.sigmoid(out), torch.from_numpy(y).to(DEV))
+    m = acc.compute()
+    mi, ma = m["map_micro"], m["map_macro"]
+    pr = torch.sigmoid(ref).numpy()
+    mi_ref = MO.average_precision_fast(pr.ravel(), y.ravel())
+    ma_ref = float(np.nanmean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)]))
     assert 0.2 < mi_ref < 0.99
     assert abs(mi - mi_ref) < 1e-4 and abs(ma - ma_ref) < 1e-4, (mi, mi_ref, ma, ma_ref)
 
