@@ -34,7 +34,12 @@ KIND_NAMES = {
     100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
 }
+KIND_NAMES.update({1000: "nt:plain [bf16x3]", 1010: "nt:bn_relu(z) [bf16x3]", 1020: "nt:pairsum_relu [bf16x3]",
+                   1012: "nt:bn_relu(z)->rowdot [bf16x3]", 1022: "nt:pairsum_relu->rowdot [bf16x3]",
+                   1100: "tn:plain x plain [bf16x3]", 1101: "tn:plain x bn_relu [bf16x3]",
+                   1102: "tn:plain x pairsum [bf16x3]"})
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: Peak BF16 MFMA, dense
 
 
 def build_model(device, seed=42, unit_scale_weights=False):
@@ -119,6 +124,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--labels", type=int, default=32102)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", choices=["f32", "bf16x3"], default=os.environ.get("PN_MATH_MODE", "f32"),
+                    help="arithmetic of the pair-grid GEMMs: exact f32 MFMA (default) or split-bf16 products")
     args = ap.parse_args()
 
     from protnote_amd import _lib
@@ -134,6 +141,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", torch.cuda.current_device())  # set by init_from_env (LOCAL_RANK)
 
+    _lib.set_math_mode(args.math)
     model = build_model(dev)
     model.train()
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
@@ -185,19 +193,26 @@ def main():
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        # f32 mode: algorithmic flops against the f32-MFMA peak.  bf16x3 mode: the same algorithmic flops (each costs
+        # three bf16 MFMA flops) against the dense bf16 peak - the ceiling of that ratio is 1/3.
+        peak = F32_MFMA_PEAK_TFLOPS if args.math == "f32" else BF16_MFMA_PEAK_TFLOPS
         out = {
             "metric": "protein-label pairs/sec (fwd+bwd)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.math == "f32" else "bf16x3 (f32 split into bf16 hi+lo, 3 MFMAs, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3]: train step fwd+bwd+clip+Adam, BCE loss, per-GPU batch "
                                    f"{B} x L={L}, {NL} GO-sized label set, random-init ProteInfer(1100ch,5 blocks)+"
                                    "ProtNote(concatenation head 3x3072, 4-layer projections), frozen encoder",
                        "global_batch": world * B, "seq_len": L, "n_labels": NL,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": loss_val},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "pair-grid 3072x3072 f32-MFMA GEMM family (gemm_nt_kernel / gemm_tn_kernel)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if args.math == "f32" else None,
+                         "kernel": ("pair-grid 3072x3072 f32-MFMA GEMM family (gemm_nt_kernel / gemm_tn_kernel)"
+                                    if args.math == "f32" else
+                                    "pair-grid 3072x3072 bf16x3 GEMM family (gemm_nt_bf16x3_kernel / "
+                                    "gemm_tn_bf16x3_kernel); achieved = algorithmic (f32-equivalent) flops"),
                          "launches": n_launch, "avg_ms_per_launch": tot_ms / max(n_launch, 1),
                          "flops_per_launch": tot_fl / max(n_launch, 1)},
             "kernels": kernels,

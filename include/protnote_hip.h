@@ -263,6 +263,13 @@ int pn_binned_hist_update(const float* scores, int ld_s, const void* labels, int
 int pn_binned_auprc(unsigned long long* pos_hist, unsigned long long* all_hist, int N_L, int T, double* out,
                     long long* npos, int with_micro, void* stream);
 
+/* Arithmetic of the pair-grid GEMMs (process-wide): 0 = exact f32 MFMA (default; results are a k-ordered fmaf
+ * chain), 1 = "bf16x3": operands split into bf16 hi + lo on the fly, a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16
+ * matrix pipe with f32 accumulation - ~1e-5 relative error per product instead of 6e-8, several times faster.
+ * The encoder, the row MLPs (W_p, W_l) and all reductions stay f32 in either mode. */
+int pn_set_math_mode(int mode);
+int pn_get_math_mode(void);
+
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
  * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller

@@ -14,3 +14,16 @@ def free_workspaces():
     from . import _lib
 
     _lib._ws_cache.clear()
+
+
+def set_math_mode(mode) -> None:
+    """"f32" (default) or "bf16x3" for the pair-grid GEMMs; see include/protnote_hip.h pn_set_math_mode."""
+    from . import _lib
+
+    _lib.set_math_mode(mode)
+
+
+def get_math_mode() -> str:
+    from . import _lib
+
+    return _lib.get_math_mode()

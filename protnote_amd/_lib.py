@@ -135,6 +135,8 @@ _SIGS = {
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pn_binned_auprc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_void_p]),
+    "pn_set_math_mode": (C.c_int, [C.c_int]),
+    "pn_get_math_mode": (C.c_int, []),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
@@ -167,7 +169,26 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        mode = os.environ.get("PN_MATH_MODE")
+        if mode:
+            set_math_mode(mode)
     return _lib
+
+
+_MATH_MODES = {"f32": 0, "0": 0, "bf16x3": 1, "1": 1}
+
+
+def set_math_mode(mode) -> None:
+    """Arithmetic of the pair-grid GEMMs: "f32" (default, exact f32 MFMA) or "bf16x3" (split-bf16 products with f32
+    accumulation: ~1e-5 relative error per product, several times faster).  Also settable with PN_MATH_MODE."""
+    key = str(mode).lower()
+    if key not in _MATH_MODES:
+        raise ValueError(f"math mode must be 'f32' or 'bf16x3', got {mode!r}")
+    check(lib().pn_set_math_mode(_MATH_MODES[key]))
+
+
+def get_math_mode() -> str:
+    return "bf16x3" if lib().pn_get_math_mode() == 1 else "f32"
 
 
 def check(rc: int):

@@ -94,6 +94,154 @@ __device__ __forceinline__ void pin4(float4& v) {
   asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
+// Output-tile coordinates of this workgroup; false = padding workgroup of the XCD-ordered grid (returns at once).
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
+// has its own 4 MB L2.  Give every XCD whole br x bc blocks of output tiles, one block (= the workgroups resident
+// on its 32 CUs) at a time: inside a block each A row-panel is shared by bc and each W column-panel by br
+// workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
+template <int BM, int BN>
+__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n) {
+  const int ntn = (p.Nstore + BN - 1) / BN;
+  if (PN_XCD && p.xcd_bc > 0) {
+    const int ntm = (p.M + BM - 1) / BM;
+    const int br = p.xcd_br, bc = p.xcd_bc, bsz = br * bc;
+    const int nbn = ntn / bc;
+    const int nbm = (ntm + br - 1) / br;
+    const int xw = blockIdx.x >> 3;
+    const int gb = (xw / bsz) * 8 + (blockIdx.x & 7);
+    if (gb >= nbm * nbn) return false;
+    const int r = xw % bsz;
+    tile_m = (gb / nbn) * br + r / bc;
+    tile_n = (gb % nbn) * bc + r % bc;
+    return tile_m < ntm && tile_n < ntn;
+  }
+  tile_n = blockIdx.x % ntn;
+  tile_m = blockIdx.x / ntn;
+  return true;
+}
+
+// Epilogue shared by the f32 and the bf16x3 kernels: acc[i][j] is the 32x32 MFMA accumulator of wave tile (i, j)
+// (lane l: column l % 32, rows (e & 3) + 8 * (e >> 2) + 4 * (l / 32)).  LDS must be free (barrier passed).
+template <int EK, int WAVES_M, int WAVES_N, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[WM][WN], int row0, int col0, int tile_n,
+                                              float* smem) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BN = WAVES_N * WN * 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int hl = lane >> 5;  // which 4-row group of each 8
+  const int cl = lane & 31;
+  const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_sum != nullptr);
+  float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
+  if (want_stats) {
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = col0 + (wn * WN + j) * 32 + cl;
+    const bool cok = col < p.N;
+    float s1 = 0.f, s2 = 0.f;
+    float bj = 0.f, es = 0.f, et = 0.f, ew = 0.f, cs = 0.f;
+    if constexpr (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) {
+      bj = (cok && p.bias) ? p.bias[col] : 0.f;
+    }
+    if constexpr (EK == E_ROWDOT) {
+      if (cok) {
+        es = p.e_scale[col];
+        et = p.e_shift[col];
+        ew = p.e_w[col];
+      }
+    }
+    if constexpr (EK == E_SCALE_RC) cs = cok ? p.col_scale[col] * p.alpha : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const bool rok = row < p.M;
+        float v = acc[i][j][e];
+        if constexpr (EK == E_PAIRADD) {
+          if (rok && cok) {
+            const int pj = row / p.pairB;
+            const int pi = row - pj * p.pairB;
+            v += bj + p.padd1[(long)pi * p.ldp1 + col] + p.padd2[(long)pj * p.ldp2 + col];
+            p.C[(long)row * p.ldc + col] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        } else if constexpr (EK == E_STORE) {
+          v = cok ? v + bj : 0.f;
+          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
+          if (rok) {
+            s1 += v;
+            s2 += v * v;
+          }
+        } else if constexpr (EK == E_CONV) {
+          bool live = false;
+          if (rok) {
+            const int b = row / p.L;
+            live = (row - b * p.L) < p.lens[b];
+          }
+          if (live && cok) {
+            v += bj;
+            if (p.resid) v += p.resid[(long)row * p.ldr + col];
+          } else {
+            v = 0.f;
+          }
+          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
+          s1 += v;
+          s2 += v * v;
+        } else if constexpr (EK == E_SCALE_RC) {
+          if (rok && cok) p.C[(long)row * p.ldc + col] = v * p.row_scale[row] * cs;
+        } else if constexpr (EK == E_ROWDOT) {
+          acc[i][j][e] = cok ? relu(fmaf(v, es, et)) * ew : 0.f;
+        }
+      }
+    }
+    if (want_stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (hl == 0) {
+        atomicAdd(&red[(wn * WN + j) * 32 + cl], s1);
+        atomicAdd(&red[BN + (wn * WN + j) * 32 + cl], s2);
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int i = tid; i < BN; i += NT) {
+      const int col = col0 + i;
+      if (col < p.N) {
+        atomicAdd(&p.col_sum[col], (double)red[i]);
+        atomicAdd(&p.col_sumsq[col], (double)red[BN + i]);
+      }
+    }
+  }
+  if constexpr (EK == E_ROWDOT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) v += acc[i][j][e];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        if (cl == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
+      }
+    }
+  }
+}
+
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel(const GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -115,28 +263,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
 
-  const int ntn = (p.Nstore + BN - 1) / BN;
   int tile_m, tile_n;
-  if (PN_XCD && p.xcd_bc > 0) {
-  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), and
-  // each XCD has its own 4 MB L2.  Give every XCD whole br x bc blocks of output tiles, one block (= the
-  // workgroups resident on its 32 CUs) at a time: inside a block each A row-panel is shared by bc and each W
-  // column-panel by br workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
-  const int ntm = (p.M + BM - 1) / BM;
-  const int br = p.xcd_br, bc = p.xcd_bc, bsz = br * bc;
-  const int nbn = ntn / bc;
-  const int nbm = (ntm + br - 1) / br;
-  const int xw = blockIdx.x >> 3;
-  const int gb = (xw / bsz) * 8 + (blockIdx.x & 7);
-  if (gb >= nbm * nbn) return;
-  const int r = xw % bsz;
-  tile_m = (gb / nbn) * br + r / bc;
-  tile_n = (gb % nbn) * bc + r % bc;
-  if (tile_m >= ntm || tile_n >= ntn) return;
-  } else {
-  tile_n = blockIdx.x % ntn;
-  tile_m = blockIdx.x / ntn;
-  }
+  if (!tile_coords<BM, BN>(p, tile_m, tile_n)) return;
   const int row0 = tile_m * BM;
   const int col0 = tile_n * BN;
 
@@ -393,114 +521,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   __syncthreads();
 
   // ---------------- epilogue ----------------
-  const int hl = lane >> 5;  // which 4-row group of each 8
-  const int cl = lane & 31;
-  const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_sum != nullptr);
-  float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
-  if (want_stats) {
-    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int col = col0 + (wn * WN + j) * 32 + cl;
-    const bool cok = col < p.N;
-    float s1 = 0.f, s2 = 0.f;
-    float bj = 0.f, es = 0.f, et = 0.f, ew = 0.f, cs = 0.f;
-    if constexpr (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) {
-      bj = (cok && p.bias) ? p.bias[col] : 0.f;
-    }
-    if constexpr (EK == E_ROWDOT) {
-      if (cok) {
-        es = p.e_scale[col];
-        et = p.e_shift[col];
-        ew = p.e_w[col];
-      }
-    }
-    if constexpr (EK == E_SCALE_RC) cs = cok ? p.col_scale[col] * p.alpha : 0.f;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        const bool rok = row < p.M;
-        float v = acc[i][j][e];
-        if constexpr (EK == E_PAIRADD) {
-          if (rok && cok) {
-            const int pj = row / p.pairB;
-            const int pi = row - pj * p.pairB;
-            v += bj + p.padd1[(long)pi * p.ldp1 + col] + p.padd2[(long)pj * p.ldp2 + col];
-            p.C[(long)row * p.ldc + col] = v;
-            s1 += v;
-            s2 += v * v;
-          }
-        } else if constexpr (EK == E_STORE) {
-          v = cok ? v + bj : 0.f;
-          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
-          if (rok) {
-            s1 += v;
-            s2 += v * v;
-          }
-        } else if constexpr (EK == E_CONV) {
-          bool live = false;
-          if (rok) {
-            const int b = row / p.L;
-            live = (row - b * p.L) < p.lens[b];
-          }
-          if (live && cok) {
-            v += bj;
-            if (p.resid) v += p.resid[(long)row * p.ldr + col];
-          } else {
-            v = 0.f;
-          }
-          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
-          s1 += v;
-          s2 += v * v;
-        } else if constexpr (EK == E_SCALE_RC) {
-          if (rok && cok) p.C[(long)row * p.ldc + col] = v * p.row_scale[row] * cs;
-        } else if constexpr (EK == E_ROWDOT) {
-          acc[i][j][e] = cok ? relu(fmaf(v, es, et)) * ew : 0.f;
-        }
-      }
-    }
-    if (want_stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (hl == 0) {
-        atomicAdd(&red[(wn * WN + j) * 32 + cl], s1);
-        atomicAdd(&red[BN + (wn * WN + j) * 32 + cl], s2);
-      }
-    }
-  }
-  if (want_stats) {
-    __syncthreads();
-    for (int i = tid; i < BN; i += NT) {
-      const int col = col0 + i;
-      if (col < p.N) {
-        atomicAdd(&p.col_sum[col], (double)red[i]);
-        atomicAdd(&p.col_sumsq[col], (double)red[BN + i]);
-      }
-    }
-  }
-  if constexpr (EK == E_ROWDOT) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) v += acc[i][j][e];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        if (cl == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
-      }
-    }
-  }
+  gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK>

@@ -7,6 +7,7 @@
 #include "../../include/protnote_hip.h"
 #include "common.hpp"
 #include "gemm_engine.hpp"
+#include "gemm_bf16x3.hpp"
 
 using namespace pn;
 
@@ -178,6 +179,45 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   return 0;
 }
 
+// Arithmetic of the pair-grid GEMMs: 0 = exact f32 MFMA (default), 1 = bf16x3 split (gemm_bf16x3.hpp).
+static int g_math_mode = 0;
+extern "C" int pn_set_math_mode(int mode) {
+  if (mode != 0 && mode != 1) return fail("pn_set_math_mode: 0 (f32) or 1 (bf16x3)");
+  g_math_mode = mode;
+  return 0;
+}
+extern "C" int pn_get_math_mode(void) { return g_math_mode; }
+
+template <int AK, int EK>
+static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
+  using Cfg = GemmCfg<4, 2, 2, 4, 32>;
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, 2, 2, 4>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  const long tm = (p.M + Cfg::BM - 1) / Cfg::BM;
+  const long tn = p.Nstore / Cfg::BN;
+  GemmParams pp = p;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
+  long grid = tm * tn;
+  if (pp.xcd_bc) {
+    const long nblk = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  {
+    ProfScope ps(1000 + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 static int rowdot_nparts(int n);
 // variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64);
 // variant 2: 256x256 tile (4x2 waves of 64x128, one workgroup per CU) - half the operand traffic per flop
@@ -186,6 +226,11 @@ static int rowdot_nparts(int n);
 #endif
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
+  if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
+    if (g_math_mode == 1 && PN_BIG && variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 &&
+        p.N % 256 == 0 && p.Nstore == p.N)
+      return launch_gemm_bf16x3<AK, EK>(p, st);
+  }
   if constexpr ((EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) ||
                 (EK == E_PAIRADD && AK == A_PAIRPROD)) {
     if (PN_BIG && variant == 0 && p.N % 256 == 0 && p.M >= 65536)
@@ -907,10 +952,53 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
   return 0;
 }
 
+template <int TB>
+static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
+  auto kern = gemm_tn_bf16x3_kernel<TB>;
+  constexpr int LDS = 2 * 512 * 36 * (int)sizeof(float);
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done[dev] = true;
+  }
+  int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats, 256, 1);
+  if (ns == 1) {
+    p.Cpart = dst;
+    p.ldc = ldd;
+    p.rows_per_split = (p.R + 31) / 32 * 32;
+  } else {
+    if (part == nullptr) return fail("gemm_tn: no partial buffer");
+    p.Cpart = part;
+    p.ldc = p.N;
+    long rps = (p.R + ns - 1) / ns;
+    p.rows_per_split = (rps + 31) / 32 * 32;
+    ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
+  }
+  const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
+  {
+    ProfScope ps(1100 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
+    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(512), LDS, st, p);
+  }
+  HIP_OK(hipGetLastError());
+  if (ns > 1) {
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nblk((long)p.M * p.N, 256)), dim3(256), 0, st, (const float*)part, ns,
+                       p.M, p.N, (long)p.N, dst, ldd);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
 template <int TA, int TB>
 static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   if (p.M % 4 || p.N % 4) return fail("gemm_tn: M and N must be multiples of 4");
   if (p.R <= 0) return fail("gemm_tn: empty contraction");
+  if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
+    if (g_math_mode == 1 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
+        (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0))
+      return launch_tn_bf16x3<TB>(p, dst, ldd, part, part_cap_floats, st);
+  }
   // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction)
   if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536)
     return launch_tn_cfg<TA, TB, true>(p, dst, ldd, part, part_cap_floats, st);

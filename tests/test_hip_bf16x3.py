@@ -1,0 +1,141 @@
+"""Opt-in bf16x3 arithmetic of the pair-grid GEMMs (pn_set_math_mode(1)): accuracy class against f64 and the 1e-3
+logit bound of the north star; the default f32 mode is restored after every test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def bf16x3():
+    import protnote_amd
+
+    protnote_amd.set_math_mode("bf16x3")
+    yield
+    protnote_amd.set_math_mode("f32")
+
+
+def _gemm_nt(A, W, scale=None, shift=None):
+    from protnote_amd import _lib
+
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, device=DEV)
+    _lib.check(_lib.lib().pn_gemm_nt(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(out), N, M, N, K, None,
+                                     _lib.ptr(scale), _lib.ptr(shift), None, None, 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_bf16x3_gemm_error_class(bf16x3):
+    """C = relu(A*s+t) W^T on the split-bf16 path: error relative to sum |a||w| is ~1e-5 / sqrt(K)-ish, far below
+    bf16 (4e-3) and above f32 (6e-8); ragged M exercises the row clamp."""
+    import protnote_amd
+
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 65536 + 37, 512, 160
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    s = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    t = (torch.randn(K, generator=g) * 0.1).to(DEV)
+    got = _gemm_nt(A, W, s, t).double()
+    act = torch.relu(A.double() * s.double() + t.double())
+    ref = act @ W.double().T
+    scale = (act.abs() @ W.double().abs().T)
+    rel = ((got - ref).abs() / scale).max().item()
+    assert rel < 2e-5, rel
+    protnote_amd.set_math_mode("f32")
+    exact = _gemm_nt(A, W, s, t).double()
+    rel32 = ((exact - ref).abs() / scale).max().item()
+    assert rel32 < 1e-6 and rel > 2 * rel32, (rel, rel32)   # i.e. the bf16x3 kernel really ran above
+
+
+def test_bf16x3_logits_within_north_star(bf16x3):
+    """Full-width eval forward (d=1024, h=3072, 3-layer head) on 96 x 700 pairs: logits within 1e-3 of the fp32 CPU
+    oracle (north-star bound), measured error is ~1e-4."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(31)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 96, 700
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    err = (out.cpu() - ref).abs().max().item()
+    assert ref.abs().max().item() > 0.5 and err < 1e-3, err
+    print("bf16x3 max logit error", err)
+
+
+def test_bf16x3_gemm_tn_error_class(bf16x3):
+    """C = A^T B over a long, ragged row range (split-K, masked last slab) on the split-bf16 TN kernel."""
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(1)
+    for R, M, N in ((65536 + 40, 256, 512), (131072 + 7, 512, 256)):
+        A = torch.randn(R, M, generator=g)
+        Bm = torch.randn(R, N, generator=g) + torch.arange(N) * 0.01
+        Ad, Bd = A.to(DEV), Bm.to(DEV)
+        ref = (Ad.double().T @ Bd.double()).cpu()
+        scale = (Ad.double().abs().T @ Bd.double().abs()).cpu()
+        Cd = torch.full((M, N), float("nan"), device=DEV)
+        ws = torch.empty(16 * M * N * 4 + 1024, dtype=torch.uint8, device=DEV)
+        L.check(L.lib().pn_gemm_tn(L.ptr(Ad), M, L.ptr(Bd), N, L.ptr(Cd), N, R, M, N, L.ptr(ws), ws.numel(),
+                                   L.stream_ptr()))
+        torch.cuda.synchronize()
+        rel = ((Cd.cpu().double() - ref).abs() / scale).max().item()
+        assert 1e-8 < rel < 2e-5, (R, M, N, rel)    # > f32 class: the bf16x3 kernel really ran
+
+
+@pytest.mark.parametrize("B,NL,chunk", [(64, 1100, None), (72, 920, 300)])
+def test_bf16x3_train_step_vs_oracle(bf16x3, B, NL, chunk):
+    """Full-width train step (d=1024, h=3072, 3 hidden layers) with every pair-grid GEMM (forward, dh, dW) on the
+    split-bf16 path: logits within the 1e-3 north-star bound of the f64 oracle, loss to 1e-4, every gradient within
+    1e-2 (Frobenius) - the f32 CPU path itself is 5e-4..2e-3 away at this grid size (ReLU-mask flips)."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(21)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    ref_sd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    names = O.trainable_names(ref_sd)
+    leaves = {k: ref_sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(ref_sd)
+    work.update(leaves)
+    lg = O.protnote_forward(work, None, None, lab.double(), training=True, sequence_embeddings=P_f.double())
+    ls = O.bce_loss(lg, y.double())
+    ref_grads = dict(zip(names, torch.autograd.grad(ls, [leaves[k] for k in names])))
+
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    model.pair_label_chunk = chunk
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    l = BCEWithLogitsLoss()(logits, y.to(DEV))
+    l.backward()
+    err = (logits.detach().cpu().double() - lg.detach()).abs().max().item()
+    assert err < 1e-3, err
+    np.testing.assert_allclose(l.item(), ls.item(), rtol=1e-4)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = ref_grads[name]
+        rel = (p.grad.cpu().double() - ref).norm().item() / max(ref.norm().item(), 1e-30)
+        worst = max(worst, rel)
+        assert rel < 1e-2, (name, rel)
+    print(f"bf16x3 train: logit err {err:.2e}, worst grad rel {worst:.2e}")
