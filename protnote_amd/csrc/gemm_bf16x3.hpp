@@ -13,6 +13,10 @@
 #include "gemm_engine.hpp"
 #include "gemm_tn.hpp"
 
+#ifndef PN_B3_VALU
+#define PN_B3_VALU 4
+#endif
+
 namespace pn {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -23,11 +27,28 @@ struct HiLo {
   bf16x4 hi, lo;
 };
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> packed bf16 hi pair and lo pair: 6 VALU ops (cvt_pk, shift, and, 2 subs, cvt_pk)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const f32x2 x = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(x, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float r0 = x0 - __uint_as_float(hi << 16);          // exact in f32
+  const float r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  const f32x2 r = {r0, r1};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
 __device__ __forceinline__ HiLo split4(float4 v) {
-  const f32x4 x = {v.x, v.y, v.z, v.w};
+  uint32_t h0, l0, h1, l1;
+  split2(v.x, v.y, h0, l0);
+  split2(v.z, v.w, h1, l1);
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   HiLo r;
-  r.hi = __builtin_convertvector(x, bf16x4);                                  // round to nearest even
-  r.lo = __builtin_convertvector(x - __builtin_convertvector(r.hi, f32x4), bf16x4);  // x - hi is exact in f32
+  r.hi = __builtin_bit_cast(bf16x4, (u32x2){h0, h1});
+  r.lo = __builtin_bit_cast(bf16x4, (u32x2){l0, l1});
   return r;
 }
 
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
   float4 ra[NQA][2], ra2[NQA][2], rb[NQB][2];
   float4 rsc[2], rsh[2];
 
-  auto fetch = [&](int s) {
+  auto fetch_a = [&](int s) {
     const int c = s * BK;
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
@@ -103,13 +124,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
         rsh[h] = ld4(p.a_shift + c + 8 * kv + 4 * h);
       }
     }
+  };
+  auto fetch_b = [&](int s) {
+    const int c = s * BK;
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
 #pragma unroll
       for (int h = 0; h < 2; ++h) rb[q][h] = ld4(brow[q] + c + 4 * h);
   };
-
-  auto pin_fetched = [&]() {
+  auto pin_a = [&]() {
 #pragma unroll
     for (int q = 0; q < NQA; ++q)
 #pragma unroll
@@ -117,6 +140,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
         pin4(ra[q][h]);
         if constexpr (AK == A_PAIRSUM_RELU) pin4(ra2[q][h]);
       }
+  };
+  auto pin_b = [&]() {
 #pragma unroll
     for (int q = 0; q < NQB; ++q)
 #pragma unroll
@@ -137,9 +162,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
     *reinterpret_cast<bf16x8*>(dst + 4) = lo;
   };
 
-  auto commit = [&](int buf) {
+  auto commit_a = [&](int buf) {
     float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       float4 v[2];
@@ -160,6 +184,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
       }
       store8(As + (r_in + q * RPP) * LDK + 8 * kv, v[0], v[1]);
     }
+  };
+  auto commit_b = [&](int buf) {
+    float* Bs = smem + buf * STAGE + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQB; ++q) store8(Bs + (r_in + q * RPP) * LDK + 8 * kv, rb[q][0], rb[q][1]);
   };
@@ -200,23 +227,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3
       }
   };
 
+  // Main loop.  A 32x32x16 bf16 MFMA occupies the matrix pipe for 32 cycles, in which the SIMD can issue ~5 other
+  // instructions of the same wave; PMC on the first version (MFMA block, then staging block): matrix pipe busy 57 %
+  // + VALU issue 37 % of the time = ~never both.  So the staging work is woven between the MFMAs at instruction level
+  // (sched_group_barrier): per slab s
+  //   region 1: wait A(s+1) | 24 MFMAs of k-step 0  x  generator + bf16 split + LDS writes of A(s+1) | issue A(s+2)
+  //   region 2: wait B(s+1) | 24 MFMAs of k-step 1  x  split + LDS writes of B(s+1)               | issue B(s+2)
+  // every global load has a full slab to land.
   using std::integral_constant;
-  fetch(0);
-  pin_fetched();
-  commit(0);
+  auto weave = [&](auto nvalu_c) {
+#if !defined(PN_B3_NOWEAVE)
+    constexpr int NV = decltype(nvalu_c)::value;
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);  // all fragment reads of the k-step first
+#pragma unroll
+    for (int i = 0; i < WM * WN * 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU of the staging path
+      if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS writes: 8 per region
+    }
+#endif
+  };
+  fetch_a(0);
+  fetch_b(0);
+  pin_a();
+  pin_b();
+  commit_a(0);
+  commit_b(0);
+  fetch_a(nslab > 1 ? 1 : 0);
+  fetch_b(nslab > 1 ? 1 : 0);
   __syncthreads();
   for (int s = 0; s + 1 < nslab; ++s) {
     const int cur = s & 1;
-    fetch(s + 1);
+    const int nxt = s + 2 < nslab ? s + 2 : s + 1;  // (the last one is a harmless re-read)
     __builtin_amdgcn_sched_barrier(0);
+    pin_a();
     compute(cur, integral_constant<int, 0>{});
+    commit_a(cur ^ 1);
+    weave(integral_constant<int, (AK == A_PLAIN ? PN_B3_VALU : PN_B3_VALU + 1)>{});
     __builtin_amdgcn_sched_barrier(0);
-    pin_fetched();
+    fetch_a(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    pin_b();
     compute(cur, integral_constant<int, 1>{});
-    commit(cur ^ 1);
+    commit_b(cur ^ 1);
+    weave(integral_constant<int, PN_B3_VALU>{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_b(nxt);
     __syncthreads();
   }
   compute((nslab - 1) & 1, integral_constant<int, 0>{});
+  __builtin_amdgcn_sched_barrier(0);
   compute((nslab - 1) & 1, integral_constant<int, 1>{});
   __syncthreads();
 
@@ -263,7 +323,7 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   if (r_end > p.R) r_end = p.R;
 
   const int col = tid & 255;  // the column of both tiles this thread stages
-  const int kg = tid >> 8;    // it stages k-groups kg and kg + 2 (8 rows each)
+  const int kg = __builtin_amdgcn_readfirstlane(tid >> 8);  // it stages k-groups kg and kg + 2 (wave-uniform)
   float bs = 0.f, bt = 0.f;
   if constexpr (TB == TB_AFFINE_RELU) {
     bs = p.b_s[n0 + col];
@@ -271,65 +331,74 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   }
 
   float ra[2][8], rb[2][8], rb2[2];
-  unsigned pi0 = 0, pj0 = 0;  // pair decode (i = r % B, j = r / B) of this thread's first row, carried along
   const unsigned pB = (unsigned)p.pairB;
-  if constexpr (TB == TB_PAIRSUM_RELU) {
-    const unsigned ru = (unsigned)(r_begin + 8 * kg);
-    pj0 = ru / pB;
-    pi0 = ru - pj0 * pB;
-  }
+  const long lda = p.lda, ldb = p.ldb;
 
-  auto fetch = [&](long k0, auto masked_c) {
-    constexpr bool MASKED = decltype(masked_c)::value;
-    const float* Ak = p.A + k0 * p.lda + m0 + col;
+  // SAFE = false: slab known to lie inside [r_begin, r_end).  SAFE = true: rows >= r_end are read from the last valid
+  // row instead (and zeroed by commit).
+  // Addresses = wave-uniform row base (scalar registers) + the thread's column as a 32-bit offset.
+  auto fetch_a = [&](long k0, auto safe_c) {
+    constexpr bool SAFE = decltype(safe_c)::value;
+    const float* Ak = p.A + k0 * lda + m0;
+    const int lim = (int)(r_end - 1 - k0);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int rr0 = 8 * (kg + 2 * g);
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        long ro = rr0 + e;
-        if (MASKED && k0 + ro >= r_end) ro = r_begin - k0;
-        ra[g][e] = Ak[ro * p.lda];
+        int ro = 8 * (kg + 2 * g) + e;
+        if (SAFE) ro = ro < lim ? ro : lim;
+        const float* rowp = Ak + (long)ro * lda;  // uniform
+        ra[g][e] = rowp[(unsigned)col];
       }
-      if constexpr (TB == TB_PAIRSUM_RELU) {
-        unsigned i = pi0 + 16 * g, j = pj0;
-        while (i >= pB) {
-          i -= pB;
-          ++j;
-        }
-        if (MASKED && k0 + rr0 >= r_end) i = 0, j = 0;
-        const float* Bi = p.B + (long)i * p.ldb + n0 + col;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          long eo = e;
-          if (MASKED && k0 + rr0 + e >= r_end) eo = 0;
-          rb[g][e] = Bi[eo * p.ldb];
-        }
-        rb2[g] = p.B2[(long)j * p.ldb2 + n0 + col];
-      } else {
-        const float* Bk = p.B + k0 * p.ldb + n0 + col;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          long ro = rr0 + e;
-          if (MASKED && k0 + ro >= r_end) ro = r_begin - k0;
-          rb[g][e] = Bk[ro * p.ldb];
-        }
-      }
-    }
+  };
+  auto fetch_b = [&](long k0, auto safe_c) {
+    constexpr bool SAFE = decltype(safe_c)::value;
+    const int lim = (int)(r_end - 1 - k0);
     if constexpr (TB == TB_PAIRSUM_RELU) {
-      pi0 += BK;
-      while (pi0 >= pB) {
-        pi0 -= pB;
-        ++pj0;
+      // rows 8 * (kg + 2g) .. + 7 of the slab: pairB % 8 == 0 and k0 % 8 == 0, so the 8 rows share j = r / pairB
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int rr0 = 8 * (kg + 2 * g);
+        if (SAFE) rr0 = rr0 < lim ? rr0 : (lim & ~7);
+        const unsigned ru = (unsigned)(k0 + rr0);
+        const unsigned j = ru / pB;
+        const unsigned i = ru - j * pB;
+        const float* Bi = p.B + (long)i * ldb + n0;  // uniform
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int eo = e;
+          if (SAFE) eo = (rr0 + e) < lim ? e : (lim - rr0 > 0 ? lim - rr0 : 0);
+          const float* rowp = Bi + (long)eo * ldb;
+          rb[g][e] = rowp[(unsigned)col];
+        }
+        const float* B2j = p.B2 + (long)j * p.ldb2 + n0;
+        rb2[g] = B2j[(unsigned)col];
       }
+    } else {
+      const float* Bk = p.B + k0 * ldb + n0;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int ro = 8 * (kg + 2 * g) + e;
+          if (SAFE) ro = ro < lim ? ro : lim;
+          const float* rowp = Bk + (long)ro * ldb;
+          rb[g][e] = rowp[(unsigned)col];
+        }
     }
   };
 
-  auto pin_fetched = [&]() {
+  auto pin_a = [&]() {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ra[g][e]));
+  };
+  auto pin_b = [&]() {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ra[g][e]), "+v"(rb[g][e]));
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(rb[g][e]));
       if constexpr (TB == TB_PAIRSUM_RELU) asm volatile("" : "+v"(rb2[g]));
     }
   };
@@ -348,22 +417,33 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
     *reinterpret_cast<bf16x8*>(dst + 4) = lo;
   };
 
-  auto commit = [&](int buf, long k0, auto masked_c) {
-    constexpr bool MASKED = decltype(masked_c)::value;
+  auto commit_a = [&](int buf, long k0, auto safe_c) {
+    constexpr bool SAFE = decltype(safe_c)::value;
     float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDK;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      float a[8], b[8];
+      float a[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         a[e] = ra[g][e];
+        if (SAFE && k0 + 8 * (kg + 2 * g) + e >= r_end) a[e] = 0.f;
+      }
+      store8(As + col * LDK + 8 * (kg + 2 * g), a);
+    }
+  };
+  auto commit_b = [&](int buf, long k0, auto safe_c) {
+    constexpr bool SAFE = decltype(safe_c)::value;
+    float* Bs = smem + buf * STAGE + BM * LDK;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
         b[e] = rb[g][e];
         if constexpr (TB == TB_AFFINE_RELU) b[e] = relu(fmaf(b[e], bs, bt));
         if constexpr (TB == TB_PAIRSUM_RELU) b[e] = relu(b[e] + rb2[g]);
-        if (MASKED && k0 + 8 * (kg + 2 * g) + e >= r_end) a[e] = 0.f, b[e] = 0.f;
+        if (SAFE && k0 + 8 * (kg + 2 * g) + e >= r_end) b[e] = 0.f;
       }
-      store8(As + col * LDK + 8 * (kg + 2 * g), a);
       store8(Bs + col * LDK + 8 * (kg + 2 * g), b);
     }
   };
@@ -406,42 +486,60 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   using std::integral_constant;
   using std::false_type;
   using std::true_type;
+  auto weave = [&](auto nvalu_c) {
+#if !defined(PN_B3_NOWEAVE)
+    constexpr int NV = decltype(nvalu_c)::value;
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);
+#pragma unroll
+    for (int i = 0; i < WM * WN * 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#endif
+  };
+  // slab t covers rows [r_begin + 32 t, +32); slabs 0 .. nf-1 are full, slab nf (if any) is the ragged tail.
+  // Same two-region pipeline as the NT kernel: region 1 = k-step 0 x staging of A(t+1), then issue A(t+2);
+  // region 2 = k-step 1 x staging of B(t+1), then issue B(t+2).
   if (r_begin < r_end) {
-    const bool first_full = r_begin + BK <= r_end;
-    if (first_full) {
-      fetch(r_begin, false_type{});
-      pin_fetched();
-      commit(0, r_begin, false_type{});
-    } else {
-      fetch(r_begin, true_type{});
-      pin_fetched();
-      commit(0, r_begin, true_type{});
-    }
+    const long span = r_end - r_begin;
+    const int nf = (int)(span / BK);
+    const int ns = nf + ((span % BK) ? 1 : 0);
+    auto K0 = [&](int t) { return r_begin + (long)t * BK; };
+    auto body = [&](int t, auto safe_c) {  // computes slab t, stages slab t+1, issues the loads of slab t+2
+      const int cur = t & 1;
+      const int t2 = t + 2 < ns ? t + 2 : t + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      pin_a();
+      compute(cur, integral_constant<int, 0>{});
+      commit_a(cur ^ 1, K0(t + 1), safe_c);
+      weave(integral_constant<int, 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_a(K0(t2), safe_c);
+      __builtin_amdgcn_sched_barrier(0);
+      pin_b();
+      compute(cur, integral_constant<int, 1>{});
+      commit_b(cur ^ 1, K0(t + 1), safe_c);
+      weave(integral_constant<int, (TB == TB_PLAIN ? 2 : 3)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_b(K0(t2), safe_c);
+      __syncthreads();
+    };
+    fetch_a(K0(0), true_type{});
+    fetch_b(K0(0), true_type{});
+    pin_a();
+    pin_b();
+    commit_a(0, K0(0), true_type{});
+    commit_b(0, K0(0), true_type{});
+    fetch_a(K0(ns > 1 ? 1 : 0), true_type{});
+    fetch_b(K0(ns > 1 ? 1 : 0), true_type{});
     __syncthreads();
-    int cur = 0;
-    long k0 = r_begin;
-    for (; k0 + 2 * BK <= r_end; k0 += BK) {  // the next slab is a full one
-      fetch(k0 + BK, false_type{});
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, 0>{});
-      __builtin_amdgcn_sched_barrier(0);
-      pin_fetched();
-      compute(cur, integral_constant<int, 1>{});
-      commit(cur ^ 1, k0 + BK, false_type{});
-      __syncthreads();
-      cur ^= 1;
-    }
-    if (k0 + BK < r_end) {  // ragged last slab
-      fetch(k0 + BK, true_type{});
-      compute(cur, integral_constant<int, 0>{});
-      compute(cur, integral_constant<int, 1>{});
-      pin_fetched();
-      commit(cur ^ 1, k0 + BK, true_type{});
-      __syncthreads();
-      cur ^= 1;
-    }
-    compute(cur, integral_constant<int, 0>{});
-    compute(cur, integral_constant<int, 1>{});
+    int t = 0;
+    for (; t + 2 < nf; ++t) body(t, false_type{});  // slabs t+1 and t+2 are full ones
+    for (; t + 1 < ns; ++t) body(t, true_type{});
+    compute((ns - 1) & 1, integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    compute((ns - 1) & 1, integral_constant<int, 1>{});
   }
 
   float* out = p.Cpart + (long)split * p.M * p.ldc;
