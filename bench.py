@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default=os.environ.get("PN_MATH_MODE", "f32"),
                     help="arithmetic of the pair-grid GEMMs: exact f32 MFMA (default) or split-bf16 products")
+    ap.add_argument("--no-fast-mode", action="store_true",
+                    help="skip the extra bf16x3 measurement reported under 'fast_mode' when --math f32")
     args = ap.parse_args()
 
     from protnote_amd import _lib
@@ -155,22 +157,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
-    sync()
-    _lib.prof_begin()
-    t0 = time.time()
-    loss = None
-    for _ in range(args.steps):
-        loss = train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
-    sync()
-    elapsed = time.time() - t0
-    prof = _lib.prof_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss.item())
+    def timed_run():
+        for _ in range(args.warmup):
+            train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
+        sync()
+        _lib.prof_begin()
+        t0 = time.time()
+        loss = None
+        for _ in range(args.steps):
+            loss = train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
+        sync()
+        elapsed = time.time() - t0
+        prof = _lib.prof_end()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof, float(loss.item())
+
+    def family(prof):  # dominant family: launches that contract over the full pair grid with a 3072x3072 weight
+        big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12} or prof
+        tot_ms = sum(v[1] for v in big.values())
+        tot_fl = sum(v[2] for v in big.values())
+        n_launch = sum(v[0] for v in big.values())
+        return (tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0), n_launch, tot_ms, tot_fl
+
+    elapsed, prof, loss_val = timed_run()
+    fast = None
+    if args.math == "f32" and not args.no_fast_mode:  # same workload once more on the opt-in bf16x3 arithmetic
+        _lib.set_math_mode("bf16x3")
+        f_elapsed, f_prof, f_loss = timed_run()
+        _lib.set_math_mode("f32")
+        f_ach = family(f_prof)[0]
+        fast = {"math": "bf16x3 (f32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate)",
+                "value": world * B * NL * args.steps / f_elapsed, "unit": "pairs/s",
+                "ms_per_step": f_elapsed / args.steps * 1e3, "final_loss": f_loss,
+                "roofline": {"bound": "mfma", "achieved": f_ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": f_ach / BF16_MFMA_PEAK_TFLOPS,
+                             "note": "algorithmic (f32-equivalent) flops over the dense bf16 peak; each costs three "
+                                     "bf16 MFMA flops, so the ceiling of frac is 1/3"}}
 
     if rank == 0:
         pairs = world * B * NL * args.steps
@@ -178,14 +203,7 @@ def main():
         for kind, (cnt, ms, fl) in sorted(prof.items()):
             kernels[KIND_NAMES.get(kind, str(kind))] = {
                 "launches": cnt, "ms_total": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0}
-        # dominant family: launches that contract over the full pair grid with a 3072x3072 weight
-        big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12}
-        if not big:
-            big = prof
-        tot_ms = sum(v[1] for v in big.values())
-        tot_fl = sum(v[2] for v in big.values())
-        n_launch = sum(v[0] for v in big.values())
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        achieved, n_launch, tot_ms, tot_fl = family(prof)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -217,6 +235,8 @@ def main():
                          "flops_per_launch": tot_fl / max(n_launch, 1)},
             "kernels": kernels,
         }
+        if fast is not None:
+            out["fast_mode"] = fast
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
