@@ -53,7 +53,7 @@ __device__ __forceinline__ HiLo split4(float4 v) {
 }
 
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_bf16x3_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) void gemm_nt_bf16x3_kernel(const GemmParams p) {
   constexpr int BK = 32;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;

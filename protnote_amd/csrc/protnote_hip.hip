@@ -188,10 +188,15 @@ extern "C" int pn_set_math_mode(int mode) {
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
 
+#ifndef PN_B3_WAVES16
+#define PN_B3_WAVES16 0
+#endif
 template <int AK, int EK>
 static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
-  using Cfg = GemmCfg<4, 2, 2, 4, 32>;
-  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, 2, 2, 4>;
+  // E_ROWDOT's partial-slab layout is tied to 2 wave columns per tile (rowdot_nparts)
+  constexpr bool W16 = PN_B3_WAVES16 && EK != E_ROWDOT;
+  using Cfg = GemmCfg<4, (W16 ? 4 : 2), 2, (W16 ? 2 : 4), 32>;
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, (W16 ? 4 : 2), 2, (W16 ? 2 : 4)>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));

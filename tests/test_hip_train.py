@@ -510,3 +510,36 @@ def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
         # true gradient is exactly 0 and the f32 result is rounding noise
         err = (p.grad.cpu().double() - ref).norm().item()
         assert err <= tol * ref.norm().item() + 1e-6 * gmax * ref.numel() ** 0.5, (name, err, ref.norm().item())
+
+
+def test_gradient_accumulation_matches_single_step(golden_dir):
+    """GRADIENT_ACCUMULATION_STEPS = 2 (ProtNoteTrainer.py:732-755): two backward passes of the same batch with the
+    loss halved accumulate to the gradient of one plain step (no optimizer update in between), so the Adam update
+    after the second pass equals the single-step update; nothing is applied after the first pass."""
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    g = _g(golden_dir, "protnote_small_concatenation.npz")
+
+    def fresh():
+        m, _ = make_protnote(g, DEV)
+        _freeze_encoder(m)
+        m.train()
+        return m, FusedClipAdam(head_parameters(m), lr=3e-4, max_norm=1.0)
+
+    batch = {"sequence_onehots": torch.from_numpy(g["x"]).to(DEV), "sequence_lengths": torch.from_numpy(g["lens"]).to(DEV),
+             "label_embeddings": torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV),
+             "label_multihots": torch.from_numpy(g["multihots"]).float().to(DEV)}
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    m1, o1 = fresh()
+    l_full = train_step(m1, loss_fn, o1, batch)
+    m2, o2 = fresh()
+    w0 = o2.flat_w.clone()
+    l_half = train_step(m2, loss_fn, o2, batch, gradient_accumulation_steps=2, batch_idx=0)
+    assert torch.equal(o2.flat_w, w0) and o2.flat_g.abs().sum() > 0      # accumulated, not applied
+    np.testing.assert_allclose(2 * float(l_half), float(l_full), rtol=1e-6)
+    train_step(m2, loss_fn, o2, batch, gradient_accumulation_steps=2, batch_idx=1)
+    assert o2.flat_g.abs().sum() == 0                                     # zero_grad after the update
+    _assert_adam_close(o2.flat_w.cpu().numpy(), o1.flat_w.cpu().numpy(), "flat_w")
