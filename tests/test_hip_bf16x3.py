@@ -139,3 +139,51 @@ def test_bf16x3_train_step_vs_oracle(bf16x3, B, NL, chunk):
         worst = max(worst, rel)
         assert rel < 1e-2, (name, rel)
     print(f"bf16x3 train: logit err {err:.2e}, worst grad rel {worst:.2e}")
+
+
+def test_bf16x3_training_tracks_f32():
+    """Four optimisation steps (fwd + bwd + clip + Adam, lr 3e-4) of the full-width head on a 64 x 1100 pair grid, once
+    in exact f32 and once with the bf16x3 GEMMs, from the same initial state: the loss trajectories and the logits of
+    the final model stay together (same accuracy class as run-to-run f32 noise through Adam's sign-like updates)."""
+    import protnote_amd
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    gen = torch.Generator().manual_seed(5)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1100
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float().to(DEV)
+
+    def run(mode):
+        protnote_amd.set_math_mode(mode)
+        try:
+            model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                             projection_head_hidden_dim_scale_factor=3)
+            model.load_state_dict(sd)
+            model = model.to(DEV).train()
+            opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
+            losses = []
+            for _ in range(4):
+                logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+                l = BCEWithLogitsLoss()(logits, y)
+                l.backward()
+                opt.step()
+                opt.zero_grad()
+                losses.append(l.item())
+            model.eval()
+            with torch.no_grad():
+                final, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            return np.array(losses), final.cpu().numpy()
+        finally:
+            protnote_amd.set_math_mode("f32")
+
+    l32, f32 = run("f32")
+    lb3, fb3 = run("bf16x3")
+    assert l32[-1] < l32[0]                                   # it trains
+    np.testing.assert_allclose(lb3, l32, rtol=2e-3)
+    assert np.abs(fb3 - f32).max() < 2e-2 * max(1.0, np.abs(f32).max()), np.abs(fb3 - f32).max()
+    print("losses f32", l32, "bf16x3", lb3, "final logit diff", np.abs(fb3 - f32).max())
