@@ -52,7 +52,10 @@ __device__ __forceinline__ HiLo split4(float4 v) {
   return r;
 }
 
-template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN>
+// GEN = false: the pair-grid fast path (one K segment, K % 32 == 0, N % BN == 0: no masks anywhere).
+// GEN = true : segmented K with a ragged tail, ragged N, the dilated-conv tap gather (A_CONV) - the encoder's convs
+//              and the row MLPs; invalid operand quads are zeroed by selects, loads stay unconditional.
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, bool GEN = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) void gemm_nt_bf16x3_kernel(const GemmParams p) {
   constexpr int BK = 32;
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -62,9 +65,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   constexpr int KV = BK / 8;    // threads per tile row (8 k-values each)
   constexpr int RPP = NT / KV;  // tile rows covered per pass of the workgroup
   constexpr int NQA = BM / RPP;
-  constexpr int NQB = BN / RPP;
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/thread mismatch");
-  static_assert(AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "operand kind not built for bf16x3");
+  constexpr int NQB = (BN + RPP - 1) / RPP;  // BN = 192 (conv tile): the second pass covers rows 128..191 only
+  static_assert(BM % RPP == 0, "tile/thread mismatch");
+  static_assert(AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU || AK == A_CONV,
+                "operand kind not built for bf16x3");
+  static_assert(AK != A_CONV || GEN, "the conv gather needs the general path");
   constexpr int STAGE = (BM + BN) * LDK;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 
   const float* arow[NQA];
   const float* arow2[NQA];
+  int a_t[NQA], a_len[NQA];
 #pragma unroll
   for (int q = 0; q < NQA; ++q) {
     int r = row0 + r_in + q * RPP;
@@ -98,39 +104,112 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
       arow[q] = p.A + (long)r * p.lda + 8 * kv;
       arow2[q] = nullptr;
     }
+    a_t[q] = 0;
+    a_len[q] = 0;
+    if constexpr (AK == A_CONV) {
+      const int b = r / p.L;
+      a_t[q] = r - b * p.L;
+      a_len[q] = p.lens[b];
+    }
   }
   const float* brow[NQB];
+  bool bvalid[NQB];
 #pragma unroll
-  for (int q = 0; q < NQB; ++q) brow[q] = p.W + (long)(col0 + r_in + q * RPP) * p.ldw + 8 * kv;
+  for (int q = 0; q < NQB; ++q) {
+    const int n = col0 + r_in + q * RPP;
+    bvalid[q] = (r_in + q * RPP < BN) && (!GEN || n < p.N);
+    brow[q] = p.W + (long)(bvalid[q] ? n : 0) * p.ldw + 8 * kv;
+  }
 
-  const int nslab = p.Kseg / BK;
+  const int spt = GEN ? (p.Kseg + BK - 1) / BK : p.Kseg / BK;  // slabs per segment
+  const int nslab = GEN ? p.nseg * spt : spt;
+  const bool conv_affine = (AK == A_CONV) && (p.a_scale != nullptr);
 
   float4 ra[NQA][2], ra2[NQA][2], rb[NQB][2];
   float4 rsc[2], rsh[2];
+  unsigned avalid = 0xffffffffu, bmask = 0xffffffffu;  // bit 2q+h: quad h of pass q is live (GEN only)
 
   auto fetch_a = [&](int s) {
-    const int c = s * BK;
+    if constexpr (!GEN) {
+      const int c = s * BK;
 #pragma unroll
-    for (int q = 0; q < NQA; ++q)
+      for (int q = 0; q < NQA; ++q)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ra[q][h] = ld4(arow[q] + c + 4 * h);
-        if constexpr (AK == A_PAIRSUM_RELU) ra2[q][h] = ld4(arow2[q] + c + 4 * h);
+        for (int h = 0; h < 2; ++h) {
+          ra[q][h] = ld4(arow[q] + c + 4 * h);
+          if constexpr (AK == A_PAIRSUM_RELU) ra2[q][h] = ld4(arow2[q] + c + 4 * h);
+        }
+      if constexpr (AK == A_AFFINE_RELU) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          rsc[h] = ld4(p.a_scale + c + 8 * kv + 4 * h);
+          rsh[h] = ld4(p.a_shift + c + 8 * kv + 4 * h);
+        }
       }
-    if constexpr (AK == A_AFFINE_RELU) {
+    } else {
+      const int seg = s / spt;
+      const int c0 = (s - seg * spt) * BK;  // column of this slab within the segment (thread adds 8 kv + 4 h)
+      bool kok[2];
+      int cc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        rsc[h] = ld4(p.a_scale + c + 8 * kv + 4 * h);
-        rsh[h] = ld4(p.a_shift + c + 8 * kv + 4 * h);
+        kok[h] = c0 + 8 * kv + 4 * h < p.Kseg;
+        cc[h] = kok[h] ? c0 + 4 * h : -8 * kv;  // clamped to the row start (arow already holds + 8 kv)
+      }
+      avalid = 0;
+      if constexpr (AK == A_CONV) {
+        const int sh = (seg - p.nseg / 2) * p.dil;
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+          const int tt = a_t[q] + sh;
+          const bool ok = (a_t[q] < a_len[q]) && (tt >= 0) && (tt < a_len[q]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            ra[q][h] = ld4(arow[q] + (long)(ok ? sh : 0) * p.lda + cc[h]);
+            avalid |= ((ok && kok[h]) ? 1u : 0u) << (2 * q + h);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQA; ++q)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            ra[q][h] = ld4(arow[q] + cc[h]);
+            if constexpr (AK == A_PAIRSUM_RELU) ra2[q][h] = ld4(arow2[q] + cc[h]);
+            avalid |= (kok[h] ? 1u : 0u) << (2 * q + h);
+          }
+      }
+      if (AK == A_AFFINE_RELU || conv_affine) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          rsc[h] = ld4(p.a_scale + 8 * kv + cc[h]);
+          rsh[h] = ld4(p.a_shift + 8 * kv + cc[h]);
+        }
       }
     }
   };
   auto fetch_b = [&](int s) {
-    const int c = s * BK;
+    if constexpr (!GEN) {
+      const int c = s * BK;
 #pragma unroll
-    for (int q = 0; q < NQB; ++q)
+      for (int q = 0; q < NQB; ++q)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) rb[q][h] = ld4(brow[q] + c + 4 * h);
+        for (int h = 0; h < 2; ++h) rb[q][h] = ld4(brow[q] + c + 4 * h);
+    } else {
+      const int seg = s / spt;
+      const int c0 = (s - seg * spt) * BK;
+      bmask = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool kok = c0 + 8 * kv + 4 * h < p.Kseg;
+        const int cc = kok ? c0 + 4 * h : -8 * kv;
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+          rb[q][h] = ld4(brow[q] + (long)seg * p.Kseg + cc);
+          bmask |= ((kok && bvalid[q]) ? 1u : 0u) << (2 * q + h);
+        }
+      }
+    }
   };
   auto pin_a = [&]() {
 #pragma unroll
@@ -162,6 +241,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
     *reinterpret_cast<bf16x8*>(dst + 4) = lo;
   };
 
+  auto sel4 = [](bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  };
   auto commit_a = [&](int buf) {
     float* As = smem + buf * STAGE;
 #pragma unroll
@@ -170,7 +252,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v[h] = ra[q][h];
-        if constexpr (AK == A_AFFINE_RELU) {
+        if (AK == A_AFFINE_RELU || (AK == A_CONV && conv_affine)) {
           v[h].x = relu(fmaf(v[h].x, rsc[h].x, rsh[h].x));
           v[h].y = relu(fmaf(v[h].y, rsc[h].y, rsh[h].y));
           v[h].z = relu(fmaf(v[h].z, rsc[h].z, rsh[h].z));
@@ -181,6 +263,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
           v[h].z = relu(v[h].z + ra2[q][h].z);
           v[h].w = relu(v[h].w + ra2[q][h].w);
         }
+        if constexpr (GEN) v[h] = sel4((avalid >> (2 * q + h)) & 1u, v[h]);
       }
       store8(As + (r_in + q * RPP) * LDK + 8 * kv, v[0], v[1]);
     }
@@ -188,7 +271,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   auto commit_b = [&](int buf) {
     float* Bs = smem + buf * STAGE + BM * LDK;
 #pragma unroll
-    for (int q = 0; q < NQB; ++q) store8(Bs + (r_in + q * RPP) * LDK + 8 * kv, rb[q][0], rb[q][1]);
+    for (int q = 0; q < NQB; ++q) {
+      float4 v0 = rb[q][0], v1 = rb[q][1];
+      if constexpr (GEN) {
+        v0 = sel4((bmask >> (2 * q)) & 1u, v0);
+        v1 = sel4((bmask >> (2 * q + 1)) & 1u, v1);
+      }
+      if (BN % RPP == 0 || r_in + q * RPP < BN) store8(Bs + (r_in + q * RPP) * LDK + 8 * kv, v0, v1);
+    }
   };
 
   f32x16 acc[WM][WN];

@@ -188,15 +188,10 @@ extern "C" int pn_set_math_mode(int mode) {
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
 
-#ifndef PN_B3_WAVES16
-#define PN_B3_WAVES16 0
-#endif
-template <int AK, int EK>
+template <int AK, int EK, int WAVES_N, int WN, bool GEN>
 static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
-  // E_ROWDOT's partial-slab layout is tied to 2 wave columns per tile (rowdot_nparts)
-  constexpr bool W16 = PN_B3_WAVES16 && EK != E_ROWDOT;
-  using Cfg = GemmCfg<4, (W16 ? 4 : 2), 2, (W16 ? 2 : 4), 32>;
-  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, (W16 ? 4 : 2), 2, (W16 ? 2 : 4)>;
+  using Cfg = GemmCfg<4, WAVES_N, 2, WN, 32>;
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -204,8 +199,10 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     attr_done[dev] = true;
   }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  if (p.Kseg % 4 != 0) return fail("gemm: K segment %d not a multiple of 4", p.Kseg);
   const long tm = (p.M + Cfg::BM - 1) / Cfg::BM;
-  const long tn = p.Nstore / Cfg::BN;
+  const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
   GemmParams pp = p;
   pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
   pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
@@ -216,7 +213,7 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
   {
-    ProfScope ps(1000 + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    ProfScope ps(1000 + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
@@ -231,10 +228,18 @@ static int rowdot_nparts(int n);
 #endif
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
-  if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
-    if (g_math_mode == 1 && PN_BIG && variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 &&
-        p.N % 256 == 0 && p.Nstore == p.N)
-      return launch_gemm_bf16x3<AK, EK>(p, st);
+  if (g_math_mode == 1 && PN_BIG) {  // opt-in bf16x3 arithmetic (gemm_bf16x3.hpp)
+    if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
+      // pair-grid shapes: no masks needed
+      if (variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N)
+        return launch_gemm_bf16x3<AK, EK, 2, 4, false>(p, st);
+    }
+    if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU) && EK == E_STORE) {  // row MLPs over the label set (W_l)
+      if (variant == 0 && p.M >= 8192 && p.N >= 512) return launch_gemm_bf16x3<AK, EK, 2, 4, true>(p, st);
+    }
+    if constexpr (AK == A_CONV && EK == E_CONV) {  // encoder convolutions, 256x192 tiles
+      if (variant == 3) return launch_gemm_bf16x3<AK, EK, 2, 3, true>(p, st);
+    }
   }
   if constexpr ((EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) ||
                 (EK == E_PAIRADD && AK == A_PAIRPROD)) {

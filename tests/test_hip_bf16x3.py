@@ -187,3 +187,51 @@ def test_bf16x3_training_tracks_f32():
     np.testing.assert_allclose(lb3, l32, rtol=2e-3)
     assert np.abs(fb3 - f32).max() < 2e-2 * max(1.0, np.abs(f32).max()), np.abs(fb3 - f32).max()
     print("losses f32", l32, "bf16x3", lb3, "final logit diff", np.abs(fb3 - f32).max())
+
+
+def test_bf16x3_encoder_and_label_projection(bf16x3):
+    """In bf16x3 mode the encoder's convolutions (implicit GEMM: tap gather, ragged K = 1100 / 550 / 20, ragged N) and
+    the W_l row MLP over a large label set also run on the split-bf16 kernel (general path): embeddings vs the oracle
+    (eval and train-mode BatchNorm statistics), label projection vs the oracle."""
+    from tests.helpers import make_encoder, random_encoder_sd
+    from protnote_amd.models.ProtNote import ProtNote
+
+    cfg = dict(num_labels=11, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+               num_resnet_blocks=5, bottleneck_factor=0.5)
+    gen = torch.Generator().manual_seed(11)
+    sd = random_encoder_sd(cfg, gen)
+    lens = [512, 1, 333, 512, 77, 500, 40, 511, 256, 129]
+    ids = torch.randint(0, 20, (len(lens), 512), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    lens_t = torch.tensor(lens)
+    ref = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, x, lens_t)
+    enc = make_encoder(sd, "", cfg, DEV).eval()
+    for p in enc.parameters():
+        p.requires_grad = False
+    emb = enc.get_embeddings(x.to(DEV), lens_t.to(DEV))
+    err = (emb.cpu() - ref).abs().max().item()
+    assert err < 5e-4 * max(1.0, ref.abs().max().item()), err
+    # train-mode BatchNorm (batch statistics from the epilogue's column sums) + running-stat updates
+    sd_t = {k: v.clone() for k, v in sd.items()}
+    ref_t = O.proteinfer_get_embeddings(sd_t, x, lens_t, training=True)
+    enc.train()
+    emb_t = enc.get_embeddings(x.to(DEV), lens_t.to(DEV))
+    err_t = (emb_t.cpu() - ref_t).abs().max().item()
+    assert err_t < 5e-4 * max(1.0, ref_t.abs().max().item()), err_t
+    got = {k: v.cpu() for k, v in enc.state_dict().items()}
+    for k, v in sd_t.items():
+        if k.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(got[k].numpy(), v.numpy(), atol=2e-4, rtol=2e-3, err_msg=k)
+    # W_l over 9000 labels (row GEMMs with M >= 8192)
+    hsd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(hsd)
+    model = model.to(DEV).eval()
+    lab = torch.randn(9000, 1024, generator=gen)
+    with torch.no_grad():
+        L_e = model._project_eval(model.W_l, lab.to(DEV)).cpu()
+    ref_L = O.mlp_rows({k: v.clone() for k, v in hsd.items()}, "W_l.", lab, training=False)
+    errL = (L_e - ref_L).abs().max().item()
+    assert errL < 5e-4 * max(1.0, ref_L.abs().max().item()), errL
+    print(f"bf16x3 encoder err {err:.2e} (train-BN {err_t:.2e}), W_l err {errL:.2e}")
