@@ -435,8 +435,12 @@ extern "C" int pn_ap_compute(const uint32_t* keys, const uint8_t* hits, int N_L,
     if (cap != n) {
       uint32_t* ck = (uint32_t*)(base + p.compact_keys);
       uint8_t* chh = (uint8_t*)(base + p.compact_hits);
-      hipLaunchKernelGGL(k_ap_compact, dim3((unsigned)((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), N_L), dim3(256), 0, st, keys,
-                         hits, ck, chh, (long)n, (long)cap);
+      for (int j0 = 0; j0 < N_L; j0 += 65535) {  // gridDim.y limit
+        const int nl = N_L - j0 < 65535 ? N_L - j0 : 65535;
+        hipLaunchKernelGGL(k_ap_compact, dim3((unsigned)((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64), nl), dim3(256), 0, st,
+                           keys + (size_t)j0 * cap, hits + (size_t)j0 * cap, ck + (size_t)j0 * n, chh + (size_t)j0 * n, (long)n,
+                           (long)cap);
+      }
       kin = ck;
       hin = chh;
     }

@@ -28,3 +28,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_big_device_buffers():
+    """The full-size tests hold ~200 GB (stored pre-activations of the 8.2 M-pair grid); hand the blocks back to the
+    driver afterwards so the next full-size test does not have to fit beside torch's cached, differently sized ones."""
+    yield
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.memory_reserved() > 32e9:
+        import gc
+
+        import protnote_amd
+
+        gc.collect()
+        protnote_amd.free_workspaces()
+        torch.cuda.empty_cache()
