@@ -222,6 +222,8 @@ def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
     if buf is None or buf.numel() < nbytes:
         buf = None
         _ws_cache.pop(key, None)
+        if nbytes > (8 << 30):  # same reason as train_path._save_buf: do not keep the outgrown block cached
+            torch.cuda.empty_cache()
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

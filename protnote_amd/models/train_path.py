@@ -45,6 +45,8 @@ def _save_buf(model, tag, nbytes, device):
     if buf is None or buf.numel() < nbytes or buf.device != device:
         cache.pop(tag, None)
         buf = None
+        if nbytes > (8 << 30):  # growing a multi-GB store: give the old block back to the driver first, torch's
+            torch.cuda.empty_cache()  # caching allocator would otherwise keep it next to the new, larger one
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         cache[tag] = buf
     return buf
