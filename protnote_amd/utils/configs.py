@@ -78,3 +78,34 @@ def build_models(config: dict, num_labels: int = None, label_encoder=None, featu
         train_sequence_encoder=p["TRAIN_SEQUENCE_ENCODER"], feature_fusion=feature_fusion or p["FEATURE_FUSION"],
         temperature=p["SUPCON_TEMP"])
     return enc, model
+
+
+def build_training(config: dict, model, world_size: int = 1):
+    """Loss, optimiser and epoch driver from the `params` section, as ProtNoteTrainer.__init__ / _set_optimizer read it
+    (ProtNoteTrainer.py:89-245): LOSS_FN (+ FOCAL_LOSS_*, BCE_POS_WEIGHT, LABEL_SMOOTHING), OPTIMIZER (Adam | AdamW;
+    WEIGHT_DECAY only for AdamW), LEARNING_RATE, CLIP_VALUE (null = no clipping), GRADIENT_ACCUMULATION_STEPS,
+    DECISION_TH.  The encoder joins the optimiser's parameter list only with TRAIN_SEQUENCE_ENCODER.
+    Returns (loss_fn, optimizer, trainer); `trainer.evaluate(loader, estimate_map=params['ESTIMATE_MAP'])`."""
+    import torch
+
+    from ..models.ProtNoteTrainer import Trainer
+    from ..models.train_path import head_parameters
+    from .losses import get_loss
+    from .optim import FusedClipAdam
+
+    p = config["params"]
+    loss_fn = get_loss(config, bce_pos_weight=torch.tensor(float(p.get("BCE_POS_WEIGHT", 1))))
+    name = p.get("OPTIMIZER", "Adam")
+    if name not in ("Adam", "AdamW"):
+        raise NotImplementedError(f"OPTIMIZER={name}: the fused optimiser implements Adam and AdamW")
+    params = list(head_parameters(model))
+    if p.get("TRAIN_SEQUENCE_ENCODER", False):
+        params += list(model.sequence_encoder.trunk_parameters())
+    clip = p.get("CLIP_VALUE", 1)
+    opt = FusedClipAdam(params, lr=p.get("LEARNING_RATE", 3e-4),
+                        weight_decay=p.get("WEIGHT_DECAY", 0.0) if name == "AdamW" else 0.0,
+                        max_norm=None if clip is None else float(clip))
+    th = p.get("DECISION_TH", 0.5)
+    trainer = Trainer(model, loss_fn, opt, world_size=world_size, threshold=0.5 if th is None else th,
+                      gradient_accumulation_steps=p.get("GRADIENT_ACCUMULATION_STEPS", 1))
+    return loss_fn, opt, trainer

@@ -75,3 +75,12 @@ def test_build_models_matches_reference_parameter_counts():
               "sequence_encoder.conv1.weight", "sequence_encoder.resnet_blocks.4.bn_activation_2.0.running_var",
               "sequence_encoder.resnet_blocks.0.masked_conv1.bias", "sequence_encoder.output_layer.weight"):
         assert k in keys, k
+
+
+def test_build_training_rejects_unknown_optimizer():
+    import copy
+
+    cfg = copy.deepcopy(CFG)
+    cfg["params"].update(OPTIMIZER="SGD", FOCAL_LOSS_GAMMA=2, FOCAL_LOSS_ALPHA=-1, LABEL_SMOOTHING=0.0)
+    with pytest.raises(NotImplementedError, match="OPTIMIZER=SGD"):
+        CF.build_training(cfg, model=None)

@@ -543,3 +543,30 @@ def test_gradient_accumulation_matches_single_step(golden_dir):
     train_step(m2, loss_fn, o2, batch, gradient_accumulation_steps=2, batch_idx=1)
     assert o2.flat_g.abs().sum() == 0                                     # zero_grad after the update
     _assert_adam_close(o2.flat_w.cpu().numpy(), o1.flat_w.cpu().numpy(), "flat_w")
+
+
+def test_build_training_from_config(golden_dir):
+    """params -> (loss, fused optimiser, epoch driver): AdamW weight decay, CLIP_VALUE null, accumulation and the
+    decision threshold reach the objects that use them; one epoch over two batches runs and updates the weights once
+    (GRADIENT_ACCUMULATION_STEPS = 2)."""
+    from protnote_amd.utils.configs import build_training
+
+    g = _g(golden_dir, "protnote_small_concatenation.npz")
+    model, _ = make_protnote(g, DEV)
+    _freeze_encoder(model)
+    cfg = {"params": {"LOSS_FN": "FocalLoss", "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1, "LABEL_SMOOTHING": 0.0,
+                      "BCE_POS_WEIGHT": 1, "OPTIMIZER": "AdamW", "WEIGHT_DECAY": 0.001, "LEARNING_RATE": 1e-3,
+                      "CLIP_VALUE": None, "GRADIENT_ACCUMULATION_STEPS": 2, "DECISION_TH": 0.3,
+                      "TRAIN_SEQUENCE_ENCODER": False}}
+    loss_fn, opt, trainer = build_training(cfg, model)
+    assert opt.weight_decay == 0.001 and opt.max_norm is None and opt.lr == 1e-3
+    assert trainer.threshold == 0.3 and trainer.gradient_accumulation_steps == 2
+    batch = {"sequence_onehots": torch.from_numpy(g["x"]).to(DEV), "sequence_lengths": torch.from_numpy(g["lens"]).to(DEV),
+             "label_embeddings": torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV),
+             "label_multihots": torch.from_numpy(g["multihots"]).float().to(DEV)}
+    w0 = opt.flat_w.clone()
+    out = trainer.train_one_epoch([batch, batch])
+    assert opt.step_count == 1 and not torch.equal(opt.flat_w, w0)
+    assert np.isfinite(out["loss"]) and 0.0 <= out["f1_micro"] <= 1.0
+    ev = trainer.evaluate([batch], estimate_map=True)
+    assert 0.0 <= ev["map_micro"] <= 1.0
