@@ -35,7 +35,7 @@ KIND_NAMES = {
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
 }
 KIND_NAMES.update({1000: "nt:plain [bf16x3]", 1010: "nt:bn_relu(z) [bf16x3]", 1020: "nt:pairsum_relu [bf16x3]",
-                   1012: "nt:bn_relu(z)->rowdot [bf16x3]", 1022: "nt:pairsum_relu->rowdot [bf16x3]",
+                   1031: "nt:conv [bf16x3]", 1012: "nt:bn_relu(z)->rowdot [bf16x3]", 1022: "nt:pairsum_relu->rowdot [bf16x3]",
                    1100: "tn:plain x plain [bf16x3]", 1101: "tn:plain x bn_relu [bf16x3]",
                    1102: "tn:plain x pairsum [bf16x3]"})
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)

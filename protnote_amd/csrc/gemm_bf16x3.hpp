@@ -5,8 +5,10 @@
 // path stays the exact-f32 engine of gemm_engine.hpp.  Same operand generators / epilogues / tile order as there.
 //
 // Restrictions (the pair-grid GEMMs of the hot path meet them): one K segment, K % 32 == 0, N % BN == 0.
-// LDS row = 32 k-values as 4 groups of [hi k0..7 (16 B)][lo k0..7 (16 B)] + 16 B pad = 144 B: a thread owns 8
-// consecutive k of a row (two float4 global loads), so both planes are written with ds_write_b128 and a fragment
+// LDS row = 32 k-values as 4 groups of [hi x 8 (16 B)][lo x 8 (16 B)] + 16 B pad = 144 B: thread kv of a row owns the
+// k-values {4kv..4kv+3} and {16+4kv..16+4kv+3} of the slab (two float4 loads; the four threads of a row read one
+// contiguous 64-byte half line per load instruction; which 8 k share an MFMA k-group is free as long as both operands
+// agree), so both planes are written with ds_write_b128 and a fragment
 // (row = lane % 32, k-group = 2*kstep + lane / 32) is one ds_read_b128 per plane - no register shuffling, and the
 // 144 B stride keeps every 16-lane group on 16 distinct 16-byte slots for reads and writes alike.
 #pragma once
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
     if constexpr (AK == A_PAIRSUM_RELU) {
       const int j = r / p.pairB;
       const int i = r - j * p.pairB;
-      arow[q] = p.A + (long)i * p.lda + 8 * kv;
-      arow2[q] = p.A2 + (long)j * p.lda2 + 8 * kv;
+      arow[q] = p.A + (long)i * p.lda + 4 * kv;
+      arow2[q] = p.A2 + (long)j * p.lda2 + 4 * kv;
     } else {
-      arow[q] = p.A + (long)r * p.lda + 8 * kv;
+      arow[q] = p.A + (long)r * p.lda + 4 * kv;
       arow2[q] = nullptr;
     }
     a_t[q] = 0;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   for (int q = 0; q < NQB; ++q) {
     const int n = col0 + r_in + q * RPP;
     bvalid[q] = (r_in + q * RPP < BN) && (!GEN || n < p.N);
-    brow[q] = p.W + (long)(bvalid[q] ? n : 0) * p.ldw + 8 * kv;
+    brow[q] = p.W + (long)(bvalid[q] ? n : 0) * p.ldw + 4 * kv;
   }
 
   const int spt = GEN ? (p.Kseg + BK - 1) / BK : p.Kseg / BK;  // slabs per segment
@@ -136,25 +138,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
       for (int q = 0; q < NQA; ++q)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          ra[q][h] = ld4(arow[q] + c + 4 * h);
-          if constexpr (AK == A_PAIRSUM_RELU) ra2[q][h] = ld4(arow2[q] + c + 4 * h);
+          ra[q][h] = ld4(arow[q] + c + 16 * h);
+          if constexpr (AK == A_PAIRSUM_RELU) ra2[q][h] = ld4(arow2[q] + c + 16 * h);
         }
       if constexpr (AK == A_AFFINE_RELU) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          rsc[h] = ld4(p.a_scale + c + 8 * kv + 4 * h);
-          rsh[h] = ld4(p.a_shift + c + 8 * kv + 4 * h);
+          rsc[h] = ld4(p.a_scale + c + 4 * kv + 16 * h);
+          rsh[h] = ld4(p.a_shift + c + 4 * kv + 16 * h);
         }
       }
     } else {
       const int seg = s / spt;
-      const int c0 = (s - seg * spt) * BK;  // column of this slab within the segment (thread adds 8 kv + 4 h)
+      const int c0 = (s - seg * spt) * BK;  // column of this slab within the segment (thread adds 4 kv + 16 h)
       bool kok[2];
       int cc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        kok[h] = c0 + 8 * kv + 4 * h < p.Kseg;
-        cc[h] = kok[h] ? c0 + 4 * h : -8 * kv;  // clamped to the row start (arow already holds + 8 kv)
+        kok[h] = c0 + 4 * kv + 16 * h < p.Kseg;
+        cc[h] = kok[h] ? c0 + 16 * h : -4 * kv;  // clamped to the row start (arow already holds + 4 kv)
       }
       avalid = 0;
       if constexpr (AK == A_CONV) {
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
       if (AK == A_AFFINE_RELU || conv_affine) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          rsc[h] = ld4(p.a_scale + 8 * kv + cc[h]);
-          rsh[h] = ld4(p.a_shift + 8 * kv + cc[h]);
+          rsc[h] = ld4(p.a_scale + 4 * kv + cc[h]);
+          rsh[h] = ld4(p.a_shift + 4 * kv + cc[h]);
         }
       }
     }
@@ -194,15 +196,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 #pragma unroll
       for (int q = 0; q < NQB; ++q)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) rb[q][h] = ld4(brow[q] + c + 4 * h);
+        for (int h = 0; h < 2; ++h) rb[q][h] = ld4(brow[q] + c + 16 * h);
     } else {
       const int seg = s / spt;
       const int c0 = (s - seg * spt) * BK;
       bmask = 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bool kok = c0 + 8 * kv + 4 * h < p.Kseg;
-        const int cc = kok ? c0 + 4 * h : -8 * kv;
+        const bool kok = c0 + 4 * kv + 16 * h < p.Kseg;
+        const int cc = kok ? c0 + 16 * h : -4 * kv;
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
           rb[q][h] = ld4(brow[q] + (long)seg * p.Kseg + cc);

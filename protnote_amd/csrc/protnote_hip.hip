@@ -205,6 +205,10 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   const long tn = (p.Nstore + Cfg::BN - 1) / Cfg::BN;
   GemmParams pp = p;
   pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  // pair-sum operand: A comes from two small tables, so the only streamed operand is W - give each XCD ONE column
+  // tile at a time (32 row tiles x 1): its 3 MB W panel stays in that XCD's L2 instead of 4 panels thrashing it
+  // (fabric fetch per launch 0.8 TB -> W once per block; measured +1.4 % on the eval pair head)
+  if (!GEN && AK == A_PAIRSUM_RELU && pp.xcd_bc && tm >= 64) pp.xcd_bc = 1;
   pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
   long grid = tm * tn;
   if (pp.xcd_bc) {
