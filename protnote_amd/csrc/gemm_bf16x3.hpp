@@ -399,7 +399,14 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
 
   const int ntn = p.N / BN, ntm = p.M / BM;
   int tile_m, tile_n;
-  if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {  // same XCD regions as gemm_tn_kernel
+  if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {
+    // the B operand comes from two small tables: only dz streams, so give each XCD as few dz column panels as
+    // possible (4 x 2 regions: 3 of the 12 panels instead of 6)
+    const int rm = ntm / 4, rn = ntn / 2;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    tile_m = (xcd >> 1) * rm + w / rn;
+    tile_n = (xcd & 1) * rn + w % rn;
+  } else if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {  // same XCD regions as gemm_tn_kernel
     const int rm = ntm / 2, rn = ntn / 4;
     const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
     tile_m = (xcd >> 2) * rm + w / rn;
