@@ -31,7 +31,7 @@ import torch  # noqa: E402
 KIND_NAMES = {
     0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
     12: "nt:bn_relu(z)->rowdot", 22: "nt:pairsum_relu->rowdot", 3: "nt:plain->scale",
-    100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
+    104: "tn:plain x conv tap (encoder wgrad)", 100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
 }
 KIND_NAMES.update({1000: "nt:plain [bf16x3]", 1010: "nt:bn_relu(z) [bf16x3]", 1020: "nt:pairsum_relu [bf16x3]",
@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default=os.environ.get("PN_MATH_MODE", "f32"),
                     help="arithmetic of the pair-grid GEMMs: exact f32 MFMA (default) or split-bf16 products")
+    ap.add_argument("--train-encoder", action="store_true",
+                    help="TRAIN_SEQUENCE_ENCODER: True - the ProteInfer trunk is trained too (non-default workload)")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3 measurement reported under 'fast_mode' when --math f32")
     args = ap.parse_args()
@@ -147,7 +149,13 @@ def main():
     model = build_model(dev)
     model.train()
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
-    opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
+    params = list(head_parameters(model))
+    if args.train_encoder:
+        model.train_sequence_encoder = True
+        for q in model.sequence_encoder.trunk_parameters():
+            q.requires_grad = True
+        params += list(model.sequence_encoder.trunk_parameters())
+    opt = FusedClipAdam(params, lr=3e-4, max_norm=1.0)
     B, L, NL = args.batch, args.seq_len, args.labels
     batch = synthetic_batch(B, L, NL, dev, seed=1000 + rank)
     counts = torch.zeros(3, NL, dtype=torch.float32, device=dev)
@@ -222,7 +230,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[3]: train step fwd+bwd+clip+Adam, BCE loss, per-GPU batch "
                                    f"{B} x L={L}, {NL} GO-sized label set, random-init ProteInfer(1100ch,5 blocks)+"
-                                   "ProtNote(concatenation head 3x3072, 4-layer projections), frozen encoder",
+                                   "ProtNote(concatenation head 3x3072, 4-layer projections), "
+                                   + ("trainable encoder" if args.train_encoder else "frozen encoder"),
                        "global_batch": world * B, "seq_len": L, "n_labels": NL,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": loss_val},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
