@@ -147,7 +147,7 @@ typedef struct pn_mlp_grads {
 typedef struct pn_pairhead_grads {
   float* dw[PN_MAX_LAYERS];
   float* dgamma[PN_MAX_LAYERS];
-  float* dbeta[PN_MAX_LAYERS];
+  float* dbeta[PN_MAX_LAYERS]; /* layer without BatchNorm (OUTPUT_MLP_BATCHNORM: False): gradient of its Linear bias */
   float* dw_out; /* [h] */
   float* db_out; /* [1] */
 } pn_pairhead_grads;

@@ -1325,14 +1325,17 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
                                      size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
-  for (int l = 0; l < hd->nlayers; ++l)
-    if (hd->bn[l].weight == nullptr) return fail("pairhead train: layer %d has no BatchNorm (unsupported)", l);
   const int h = hd->h, d = hd->d, n = hd->nlayers;
   const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
   PairSave sv;
   PairTrainWs w;
   if (!pair_save_carve(hd, B, NL, S, bs, sv)) return fail("pairhead train: save buffer too small");
+  // OUTPUT_MLP_BATCHNORM: False -> layer l is Linear(bias) + ReLU: s = 1, t = bias, no statistics
+  auto fold_nobn = [&](int l) {
+    hipLaunchKernelGGL(k_fold_nobn, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bias[l], h, h, sv.s[l], sv.t[l], sv.mean[l],
+                       sv.invstd[l]);
+  };
   if (!pair_train_ws_carve(hd, B, NL, bw, w)) return fail("pairhead train: workspace too small");
 
   const float* w1 = hd->w[0];
@@ -1355,6 +1358,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
   }
   if (!prod) {
+    if (hd->bn[0].weight == nullptr) fold_nobn(0);
+    else
     hipLaunchKernelGGL(k_bn_fold_pair, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.sumA,
                        (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL,
                        hd->bn_eps, hd->bn_momentum, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]);
@@ -1375,6 +1380,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     p.padd1 = sv.A1; p.ldp1 = h; p.padd2 = sv.B1; p.ldp2 = h;
     p.C = sv.zbuf[0] + (size_t)S * h; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
     PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
+    if (hd->bn[0].weight == nullptr) fold_nobn(0);
+    else
     hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.S1,
                        (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[0], sv.t[0],
                        sv.mean[0], sv.invstd[0]);
@@ -1395,6 +1402,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
       p.A = sv.zbuf[l - 1] + (size_t)S * h; p.lda = h; p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
       PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
     }
+    if (hd->bn[l].weight == nullptr) fold_nobn(l);
+    else
     hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[l], (const double*)w.S1,
                        (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[l], sv.t[l],
                        sv.mean[l], sv.invstd[l]);

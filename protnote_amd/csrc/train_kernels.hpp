@@ -230,6 +230,16 @@ __global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const doub
   if (dw_out && dwacc) dw_out[c] = (float)dwacc[c];
 }
 
+// Layer without BatchNorm (OUTPUT_MLP_BATCHNORM: False): the "fold" is u = z + bias, nothing to normalise or track.
+__global__ void k_fold_nobn(const float* bias, int C, int ld, float* s, float* t, float* mean_out, float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  s[c] = c < C ? 1.f : 0.f;
+  t[c] = (c < C && bias) ? bias[c] : 0.f;
+  mean_out[c] = 0.f;
+  invstd_out[c] = 1.f;
+}
+
 // BatchNorm (train) fold for the separable first pair layer: z1[i,j] = A[i] + Bm[j] over the full B x NL grid:
 // mean = mean_i(A) + mean_j(Bm), biased var = var_i(A) + var_j(Bm) (cross term vanishes on a full grid).
 __global__ void k_bn_fold_pair(pn_bn bn, const double* sumA, const double* sqA, double nA, const double* sumB,

@@ -136,6 +136,8 @@ class _HeadsTrainFn(torch.autograd.Function):
             if bn is not None:
                 gr.dgamma[i] = gbuf(bn.weight)
                 gr.dbeta[i] = gbuf(bn.bias)
+            elif lin.bias is not None:  # OUTPUT_MLP_BATCHNORM: False - the slot carries the Linear bias gradient
+                gr.dbeta[i] = gbuf(lin.bias)
         gr.dw_out = gbuf(out.weight)
         gr.db_out = gbuf(out.bias)
         dP_e = torch.empty_like(P_e)

@@ -197,7 +197,7 @@ def _train_step(model, loss_fn, inputs, targets, clip=1.0, lr=3e-4):
     return logits.detach().numpy().copy(), float(loss.detach()), grads, float(total_norm)
 
 
-def golden_protnote():
+def golden_protnote(variants=None):
     from protnote.models.protein_encoders import ProteInfer
     from protnote.models.ProtNote import ProtNote
     from protnote.utils.losses import get_loss
@@ -213,7 +213,11 @@ def golden_protnote():
     lens = [50, 3, 21, 50, 17, 44]
     lmax = 50
     n_labels = 10
-    for fusion in ("concatenation", "concatenation_diff", "concatenation_prod", "similarity"):
+    base_head_cfg = dict(head_cfg)
+    if variants is None:
+        variants = [(f, True) for f in ("concatenation", "concatenation_diff", "concatenation_prod", "similarity")]
+    for fusion, out_bn in variants:
+        head_cfg = dict(base_head_cfg, outout_mlp_add_batchnorm=out_bn)  # OUTPUT_MLP_BATCHNORM
         g = torch.Generator().manual_seed(99)
         torch.manual_seed(1)
         enc = ProteInfer(activation=torch.nn.ReLU, **enc_cfg)
@@ -298,7 +302,7 @@ def golden_protnote():
                         out["train_enc_BCE/grad/" + n3] = p3.grad.numpy().copy()
         finally:
             PN.torch.rand_like = real_rand_like
-        fn = os.path.join(OUT, f"protnote_small_{fusion}.npz")
+        fn = os.path.join(OUT, f"protnote_small_{fusion}{'' if out_bn else '_nobn'}.npz")
         np.savez_compressed(fn, **out)
         print(os.path.basename(fn), os.path.getsize(fn) // 1024, "KiB")
 
@@ -537,7 +541,8 @@ if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
-    jobs = {"encoder": golden_encoder, "protnote": golden_protnote, "losses": golden_losses_metrics,
+    jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
+            "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers}
     for name, fn in jobs.items():

@@ -47,7 +47,10 @@ def test_encoder_pad_invariance(golden_dir):
 
 @pytest.mark.parametrize("fusion", FUSIONS)
 def test_protnote_eval(golden_dir, fusion):
-    g = _load(golden_dir, f"protnote_small_{fusion}.npz")
+    _check_eval(_load(golden_dir, f"protnote_small_{fusion}.npz"), fusion)
+
+
+def _check_eval(g, fusion):
     sd = O.as_torch_sd(g, "sd/")
     x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
     lab = torch.from_numpy(g["label_embeddings"])
@@ -65,7 +68,19 @@ def test_protnote_eval(golden_dir, fusion):
 @pytest.mark.parametrize("fusion", FUSIONS)
 @pytest.mark.parametrize("loss", ("BCE", "FocalLoss"))
 def test_protnote_train_step(golden_dir, fusion, loss):
-    g = _load(golden_dir, f"protnote_small_{fusion}.npz")
+    _check_train(_load(golden_dir, f"protnote_small_{fusion}.npz"), fusion, loss)
+
+
+def test_protnote_output_mlp_without_batchnorm(golden_dir):
+    """OUTPUT_MLP_BATCHNORM: False (get_mlp ProtNote.py:337-378 with batch_norm=False: Linear layers carry biases)."""
+    g = _load(golden_dir, "protnote_small_concatenation_nobn.npz")
+    assert "sd/output_layer.0.bias" in g.files and "sd/output_layer.1.weight" not in g.files
+    _check_eval(g, "concatenation")
+    _check_train(g, "concatenation", "BCE")
+    _check_train(g, "concatenation", "FocalLoss")
+
+
+def _check_train(g, fusion, loss):
     sd = O.as_torch_sd(g, "sd/")
     x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
     lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
