@@ -81,9 +81,19 @@ def _split_layers(seq):
             out.append([m, None])
         elif isinstance(m, nn.BatchNorm1d):
             out[-1][1] = m
-        elif isinstance(m, nn.Dropout) and m.p > 0 and m.training:
-            raise NotImplementedError("dropout > 0 in train mode is not implemented in protnote_amd")
+        elif isinstance(m, nn.Dropout) and m.p > 0 and m.training and out:
+            # (a Dropout in FRONT of the first Linear is the embedding dropout of reference ProtNote.py:83-86; the
+            # train path applies it to the input rows, see input_dropout_p)
+            raise NotImplementedError("dropout > 0 between the layers of an MLP (OUTPUT_MLP_DROPOUT) is not "
+                                      "implemented in protnote_amd")
     return out
+
+
+def input_dropout_p(seq) -> float:
+    """p of the nn.Dropout that SEQUENCE_EMBEDDING_DROPOUT / LABEL_EMBEDDING_DROPOUT put in front of W_p / W_l."""
+    if isinstance(seq, nn.Sequential) and len(seq) > 0 and isinstance(seq[0], nn.Dropout):
+        return float(seq[0].p)
+    return 0.0
 
 
 class ProtNote(nn.Module):

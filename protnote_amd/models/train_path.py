@@ -207,4 +207,13 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
     else:
         raise ValueError("Incompatible sequence parameters passed to forward method.")
     L.require_hip(P_f, L_f)
+    # SEQUENCE_EMBEDDING_DROPOUT / LABEL_EMBEDDING_DROPOUT (ProtNote.py:83-86): Bernoulli masks on the [B, 1100] and
+    # [N_L, 1024] input rows (after the label noise, as the wrapped W_l sees them); torch's device RNG, like the noise
+    from .ProtNote import input_dropout_p
+
+    p_seq, p_lab = input_dropout_p(model.W_p), input_dropout_p(model.W_l)
+    if p_seq > 0:
+        P_f = torch.nn.functional.dropout(P_f, p_seq, training=True)
+    if p_lab > 0:
+        L_f = torch.nn.functional.dropout(L_f, p_lab, training=True)
     return _HeadsTrainFn.apply(model, P_f, L_f, *head_parameters(model))

@@ -625,3 +625,45 @@ def test_output_mlp_without_batchnorm_golden(golden_dir, loss, monkeypatch):
     for k in g.files:
         if k.startswith(p + "sd_after/output_layer"):
             _assert_adam_close(got[k[len(p + "sd_after/"):]], g[k], k)
+
+
+def test_embedding_dropouts(golden_dir):
+    """SEQUENCE_EMBEDDING_DROPOUT / LABEL_EMBEDDING_DROPOUT (reference ProtNote.py:83-86 wraps W_p / W_l in
+    Sequential(Dropout, MLP): checkpoint keys move to W_p.1.*): same logits and gradients as the dropout-free model
+    fed the masked, rescaled rows (masks regenerated from the same device RNG state); eval ignores the dropouts."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(3)
+    kw = dict(protein_embedding_dim=32, label_embedding_dim=16, latent_dim=16, output_mlp_hidden_dim_scale_factor=2,
+              output_mlp_num_layers=2, projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=2)
+    plain = ProtNote(**kw).to(DEV)
+    drop = ProtNote(sequence_embedding_dropout=0.25, label_embedding_dropout=0.5, **kw).to(DEV)
+    assert "W_p.1.0.weight" in drop.state_dict() and "W_l.1.0.weight" in drop.state_dict()
+    drop.load_state_dict({k.replace("W_p.", "W_p.1.").replace("W_l.", "W_l.1."): v for k, v in plain.state_dict().items()})
+    B, NL = 9, 21
+    P_f = torch.randn(B, 32, generator=gen).to(DEV)
+    lab = torch.randn(NL, 16, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.3).float().to(DEV)
+    plain.train()
+    drop.train()
+    torch.manual_seed(11)
+    out_d, _ = drop(sequence_embeddings=P_f, label_embeddings=lab)
+    BCEWithLogitsLoss()(out_d, y).backward()
+    torch.manual_seed(11)   # the two masks, in the order forward_train draws them
+    P_m = torch.nn.functional.dropout(P_f, 0.25, training=True)
+    L_m = torch.nn.functional.dropout(lab, 0.5, training=True)
+    assert (P_m == 0).any() and (L_m == 0).any()
+    out_p, _ = plain(sequence_embeddings=P_m, label_embeddings=L_m)
+    BCEWithLogitsLoss()(out_p, y).backward()
+    np.testing.assert_allclose(out_d.detach().cpu().numpy(), out_p.detach().cpu().numpy(), atol=1e-6)
+    gp = dict(plain.named_parameters())
+    for n, p in drop.named_parameters():
+        ref = gp[n.replace("W_p.1.", "W_p.").replace("W_l.1.", "W_l.")].grad
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.cpu().numpy(), atol=1e-7 + 1e-5 * ref.abs().max().item())
+    plain.eval()
+    drop.eval()
+    with torch.no_grad():
+        a, _ = drop(sequence_embeddings=P_f, label_embeddings=lab)
+        b, _ = plain(sequence_embeddings=P_f, label_embeddings=lab)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6)
