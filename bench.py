@@ -72,13 +72,15 @@ def build_model(device, seed=42, unit_scale_weights=False):
     return model.to(device)
 
 
-def synthetic_batch(B, L, NL, device, seed):
+def synthetic_batch(B, L, NL, device, seed, ragged=False):
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(0, 20, (B, L), generator=g)
     onehots = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
     return {
         "sequence_onehots": onehots.to(device),
-        "sequence_lengths": torch.full((B,), L, dtype=torch.int64, device=device),
+        # SURVEY 8d variant: lengths ~ U[64, L] padded to L (the pad residues are masked by the kernels)
+        "sequence_lengths": (torch.randint(min(64, L), L + 1, (B,), generator=g) if ragged
+                             else torch.full((B,), L, dtype=torch.int64)).to(device),
         "label_embeddings": torch.randn(NL, 1024, generator=g).to(device),
         "label_token_counts": torch.randint(3, 40, (NL,), generator=g).to(device),
         "label_multihots": (torch.rand(B, NL, generator=g) < 1.6e-3).to(torch.int64).to(device),
@@ -128,6 +130,7 @@ def main():
                     help="arithmetic of the pair-grid GEMMs: exact f32 MFMA (default) or split-bf16 products")
     ap.add_argument("--train-encoder", action="store_true",
                     help="TRAIN_SEQUENCE_ENCODER: True - the ProteInfer trunk is trained too (non-default workload)")
+    ap.add_argument("--ragged-lengths", action="store_true", help="sequence lengths ~ U[64, L] padded to L")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3 measurement reported under 'fast_mode' when --math f32")
     args = ap.parse_args()
@@ -157,7 +160,7 @@ def main():
         params += list(model.sequence_encoder.trunk_parameters())
     opt = FusedClipAdam(params, lr=3e-4, max_norm=1.0)
     B, L, NL = args.batch, args.seq_len, args.labels
-    batch = synthetic_batch(B, L, NL, dev, seed=1000 + rank)
+    batch = synthetic_batch(B, L, NL, dev, seed=1000 + rank, ragged=args.ragged_lengths)
     counts = torch.zeros(3, NL, dtype=torch.float32, device=dev)
 
     def sync():
@@ -222,6 +225,9 @@ def main():
         # f32 mode: algorithmic flops against the f32-MFMA peak.  bf16x3 mode: the same algorithmic flops (each costs
         # three bf16 MFMA flops) against the dense bf16 peak - the ceiling of that ratio is 1/3.
         peak = F32_MFMA_PEAK_TFLOPS if args.math == "f32" else BF16_MFMA_PEAK_TFLOPS
+        # SURVEY 8d also defines the head's work densely (the reference's own computation, joint tensor included):
+        # 151.0 MFLOP per pair fwd+bwd; the factorised implementation issues 3 x 37.75 = 113.3 MFLOP per pair
+        dense_tflops = pairs * 151.0e6 / elapsed / 1e12
         out = {
             "metric": "protein-label pairs/sec (fwd+bwd)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,6 +246,8 @@ def main():
                                     if args.math == "f32" else
                                     "pair-grid 3072x3072 bf16x3 GEMM family (gemm_nt_bf16x3_kernel / "
                                     "gemm_tn_bf16x3_kernel); achieved = algorithmic (f32-equivalent) flops"),
+                         "whole_step_tflops_dense_definition": dense_tflops,
+                         "whole_step_tflops_issued": pairs * 113.26e6 / elapsed / 1e12,
                          "launches": n_launch, "avg_ms_per_launch": tot_ms / max(n_launch, 1),
                          "flops_per_launch": tot_fl / max(n_launch, 1)},
             "kernels": kernels,
