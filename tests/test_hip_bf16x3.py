@@ -273,3 +273,26 @@ def test_bf16x3_full_size_step_matches_f32():
     worst = max((g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30) for n in g0)
     assert worst < 2e-2, worst
     print(f"full size: max |logit diff| {err:.2e}, loss {l0:.6f} vs {l1:.6f}, worst grad rel {worst:.2e}")
+
+
+@pytest.mark.parametrize("latent,scale", [(500, 2), (512, 2)])
+def test_bf16x3_mode_other_widths(bf16x3, latent, scale):
+    """Widths the split-bf16 kernels do not take (hidden = 1000: not a multiple of 256) silently stay on the exact f32
+    kernels; widths they do take (hidden = 1024) run on them - either way the logits match the oracle."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(8)
+    h = latent * scale
+    sd = random_head_sd(gen, 1100, 1024, latent, h, 2, h, 2)
+    B, NL = 64, 1100
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    model = ProtNote(latent_dim=latent, output_mlp_hidden_dim_scale_factor=scale, output_mlp_num_layers=2,
+                     projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=scale)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 1e-3, err
