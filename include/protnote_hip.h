@@ -202,11 +202,16 @@ int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int NL, int d, 
 /* Loss forward + d(mean loss)/dlogit + per-label TP/FN/FP in one pass over logits [B][N]
  * (utils/losses.py:190-213 FocalLoss, :275-276 BCEWithLogits(pos_weight); ProtNoteTrainer.py:61-83).
  * kind 0 = BCE, 1 = focal.  Exactly one of targets_f32 / targets_i64 is non-NULL.  tp/fn/fp (each [N], f32
- * holding integer counts) are ACCUMULATED into when non-NULL.  ws: >= 256 bytes. */
+ * holding integer counts) are ACCUMULATED into when non-NULL.
+ * Element weights (the reference's other BCE variants, kind 0): weight_mode 0 = none; 1 = BatchWeightedBCE
+ * (losses.py:124-146: positives and negatives of the batch weigh total/2 each); 2 = WeightedBCE / CBLoss
+ * (losses.py:78-121, 214-241: row i weighs sum_j label_weights[j] * target[i][j]; label_weights [N] on the device).
+ * rgd_temperature >= 0: RGDBCE (losses.py:58-75: mean loss m times exp(min(m, T) / (T + 1)), factor detached).
+ * ws: >= 512 + 4*B bytes. */
 int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B, int N,
                     int kind, float pos_weight, float gamma, float alpha, float smoothing, float threshold,
-                    float* loss_out, float* dlogits, float* tp, float* fn, float* fp, void* ws, size_t ws_bytes,
-                    void* stream);
+                    float* loss_out, float* dlogits, float* tp, float* fn, float* fp, int weight_mode,
+                    const float* label_weights, float rgd_temperature, void* ws, size_t ws_bytes, void* stream);
 
 /* calculate_tp_fn_fp (ProtNoteTrainer.py:61-83) on probabilities; outputs are overwritten. */
 int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,

@@ -197,6 +197,47 @@ def focal_loss(logits: Tensor, target: Tensor, gamma: float = 2.0, alpha: float 
     return loss.mean()
 
 
+def rgd_bce_loss(logits: Tensor, target: Tensor, temperature: float) -> Tensor:
+    """losses.py:58-75 RGDBCE.  The reference passes the legacy argument `reduce="none"`, which torch reads as
+    reduce=True, i.e. reduction 'mean': the re-weighting acts on the scalar mean loss, m * exp(min(m, T) / (T + 1))
+    with the factor detached."""
+    m = F.binary_cross_entropy_with_logits(logits, target)
+    return m * torch.exp(torch.clamp(m.detach(), max=temperature) / (temperature + 1))
+
+
+def batch_weights_v2(label_weights: Tensor, target: Tensor) -> Tensor:
+    """losses.py:214-241: every element of row i weighs sum_j label_weights[j] * target[i, j]."""
+    return (label_weights.float() * target).sum(dim=1, keepdim=True).expand_as(target)
+
+
+def weighted_bce_loss(logits: Tensor, target: Tensor, label_weights: Tensor) -> Tensor:
+    """losses.py:109-121 WeightedBCE."""
+    return F.binary_cross_entropy_with_logits(logits, target, weight=batch_weights_v2(label_weights, target))
+
+
+def cb_label_weights(label_counts: Tensor, beta: float = 0.9999) -> Tensor:
+    """losses.py:86-99 CBLoss: (1 - beta) / (1 - beta^n_j), infinite effective number where it would be 0,
+    normalised to sum to the number of classes."""
+    eff = 1.0 - torch.pow(torch.tensor(beta), label_counts.float())
+    eff = torch.where(eff == 0, torch.tensor(float("inf")), eff)
+    w = (1.0 - beta) / eff
+    return w / torch.sum(w) * len(label_counts)
+
+
+def cb_loss(logits: Tensor, target: Tensor, label_counts: Tensor, beta: float = 0.9999) -> Tensor:
+    """losses.py:78-106."""
+    return weighted_bce_loss(logits, target, cb_label_weights(label_counts, beta))
+
+
+def batch_weighted_bce_loss(logits: Tensor, target: Tensor, epsilon: float = 1e-10) -> Tensor:
+    """losses.py:124-146 BatchWeightedBCE: positives and negatives of the batch weigh total/2 each."""
+    num_pos = target.sum() + epsilon
+    num_neg = target.numel() - num_pos + epsilon
+    total = num_pos + num_neg
+    w = target * ((1.0 / num_pos) * (total / 2.0)) + (1 - target) * ((1.0 / num_neg) * (total / 2.0))
+    return F.binary_cross_entropy_with_logits(logits, target, weight=w)
+
+
 def tp_fn_fp(probs: Tensor, labels: Tensor, threshold: float = 0.5):
     """ProtNoteTrainer.py:61-83."""
     preds = (probs >= threshold).float()

@@ -1627,12 +1627,17 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
 extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B,
                                int N, int kind, float pos_weight, float gamma, float alpha, float smoothing,
                                float threshold, float* loss_out, float* dlogits, float* tp, float* fn, float* fp,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               int weight_mode, const float* label_weights, float rgd_temperature, void* ws,
+                               size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (ws_bytes < 256) return fail("loss: workspace too small");
+  if (ws_bytes < 512 + (size_t)B * sizeof(float)) return fail("loss: workspace too small (need 512 + 4*B bytes)");
   if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("loss: pass exactly one target array");
-  double* acc = (double*)ws;
-  HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), st));
+  if (weight_mode < 0 || weight_mode > 2) return fail("loss: weight_mode must be 0, 1 (batch) or 2 (label weights)");
+  if (weight_mode == 2 && label_weights == nullptr) return fail("loss: weight_mode 2 needs label_weights");
+  double* acc = (double*)ws;               // [0] loss sum, [1] number of positives
+  float* posneg = (float*)((char*)ws + 256);
+  float* row_w = (float*)((char*)ws + 512);
+  HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
   LossParams p;
   memset(&p, 0, sizeof(p));
   p.logits = logits; p.tf = targets_f32; p.ti = targets_i64; p.B = B; p.N = N; p.kind = kind;
@@ -1640,9 +1645,25 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
   p.grad_scale = 1.f / ((float)B * (float)N);
   p.dlogits = dlogits; p.loss_sum = acc; p.tp = tp; p.fn = fn; p.fp = fp;
   p.rows_per_block = 32;
+  if (weight_mode != 0) {
+    hipLaunchKernelGGL(k_target_weights, dim3(nblk(B, 4)), dim3(256), 0, st, targets_f32, targets_i64, B, N,
+                       weight_mode == 2 ? label_weights : (const float*)nullptr,
+                       weight_mode == 2 ? row_w : (float*)nullptr, acc + 1);
+    if (weight_mode == 1) {
+      hipLaunchKernelGGL(k_posneg_weights, dim3(1), dim3(1), 0, st, (const double*)(acc + 1), (double)B * (double)N,
+                         1e-10, posneg);
+      p.posneg = posneg;
+    } else {
+      p.row_w = row_w;
+    }
+  }
   hipLaunchKernelGGL(k_loss, dim3(nblk(N, 256), nblk(B, 32)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)acc, loss_out, 1,
-                     1.f / ((float)B * (float)N));
+  if (rgd_temperature >= 0.f)
+    hipLaunchKernelGGL(k_rgd_scale, dim3(dlogits ? 1024 : 1), dim3(256), 0, st, (const double*)acc,
+                       1.0 / ((double)B * (double)N), rgd_temperature, dlogits, (long)B * N, loss_out);
+  else
+    hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)acc, loss_out, 1,
+                       1.f / ((float)B * (float)N));
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -424,7 +424,51 @@ struct LossParams {
   double* loss_sum;    // scalar accumulator
   float *tp, *fn, *fp; // [N] accumulators (+=) or null
   int rows_per_block;
+  const float* row_w;   // [B] element weight of row i (WeightedBCE / CBLoss, losses.py:214-241) or null
+  const float* posneg;  // [2] = (weight of positives, weight of negatives) (BatchWeightedBCE) or null
 };
+
+// number of positive targets -> (w_pos, w_neg) of BatchWeightedBCE (losses.py:131-139)
+__global__ void k_posneg_weights(const double* npos_in, double numel, double eps, float* out) {
+  const double num_pos = npos_in[0] + eps;
+  const double num_neg = numel - num_pos + eps;
+  const double total = num_pos + num_neg;
+  out[0] = (float)((1.0 / num_pos) * (total / 2.0));
+  out[1] = (float)((1.0 / num_neg) * (total / 2.0));
+}
+
+// row_w[i] = sum_j label_weights[j] * target[i][j];  npos += sum of targets  (one wave per row)
+__global__ __launch_bounds__(256) void k_target_weights(const float* tf, const int64_t* ti, int B, int N,
+                                                        const float* label_weights, float* row_w, double* npos) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  float w = 0.f, c = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float y = tf ? tf[(long)i * N + j] : (float)ti[(long)i * N + j];
+    c += y;
+    if (label_weights) w += label_weights[j] * y;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    w += __shfl_xor(w, o);
+    c += __shfl_xor(c, o);
+  }
+  if (lane == 0) {
+    if (row_w) row_w[i] = w;
+    if (npos) atomicAdd(npos, (double)c);
+  }
+}
+
+// RGDBCE as the reference computes it (mean loss m re-weighted by exp(min(m, T) / (T + 1)), factor detached)
+__global__ void k_rgd_scale(const double* loss_sum, double inv_count, float temperature, float* dlogits, long n,
+                            float* loss_out) {
+  const float m = (float)(loss_sum[0] * inv_count);
+  const float f = expf(fminf(m, temperature) / (temperature + 1.f));
+  const long stride = (long)gridDim.x * blockDim.x;
+  if (dlogits)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dlogits[i] *= f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = m * f;
+}
 
 __device__ __forceinline__ float softplusf(float x) {  // log(1+exp(x)), stable
   return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
@@ -474,6 +518,11 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
           l *= at;
           g *= at;
         }
+      }
+      if (p.row_w || p.posneg) {
+        const float wgt = p.row_w ? p.row_w[i] : (y * p.posneg[0] + (1.f - y) * p.posneg[1]);
+        l *= wgt;
+        g *= wgt;
       }
       lsum += (double)l;
       if (p.dlogits) p.dlogits[idx] = g * p.grad_scale;

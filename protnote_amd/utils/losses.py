@@ -3,8 +3,8 @@
 BCE (BCEWithLogitsLoss(reduction='mean', pos_weight), reference :275-276) and FocalLoss (reference :171-213,
 the shipped default) run as ONE fused HIP pass over the [B, N_L] logits (pn_loss_fwd_bwd) that produces the
 mean loss and d loss / d logits together; backward just scales the cached gradient.  The reference's other
-losses (RGDBCE, CBLoss, WeightedBCE, BatchWeightedBCE, SupCon) are non-default ablations outside the hot path
-and raise NotImplementedError."""
+BCE variants ride on the same pass: BatchWeightedBCE and WeightedBCE / CBLoss as element weights, RGDBCE as a
+rescale by a device-side scalar.  SupCon (unused in the reference) raises NotImplementedError."""
 import torch
 
 from .. import _lib as L
@@ -14,7 +14,8 @@ _BCE, _FOCAL = 0, 1
 
 class _FusedLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, kind, pos_weight, gamma, alpha, smoothing, counts=None, threshold=0.5):
+    def forward(ctx, logits, target, kind, pos_weight, gamma, alpha, smoothing, counts=None, threshold=0.5,
+                weight_mode=0, label_weights=None, rgd_temperature=-1.0):
         L.require_hip(logits, target)
         if logits.dim() != 2 or target.shape != logits.shape:
             raise ValueError("expected logits and targets of the same [B, N] shape")
@@ -27,7 +28,12 @@ class _FusedLossFn(torch.autograd.Function):
             tf = target.detach().float().contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
-        ws = L.workspace(256, x.device, "loss")
+        ws = L.workspace(512 + 4 * B, x.device, "loss")
+        lw = None
+        if label_weights is not None:
+            lw = label_weights.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            if lw.numel() != N:
+                raise ValueError(f"label_weights must have one entry per label ({N}), got {lw.numel()}")
         tp = fn = fp = None
         if counts is not None:  # [3, N] f32 accumulators of per-label TP / FN / FP (ProtNoteTrainer.py:61-83)
             if counts.shape != (3, N) or counts.dtype != torch.float32 or not counts.is_contiguous():
@@ -35,7 +41,8 @@ class _FusedLossFn(torch.autograd.Function):
             tp, fn, fp = counts[0], counts[1], counts[2]
         L.check(L.lib().pn_loss_fwd_bwd(L.ptr(x), L.ptr(tf), L.ptr(ti), B, N, kind, float(pos_weight), float(gamma),
                                         float(alpha), float(smoothing), float(threshold), L.ptr(loss), L.ptr(dlog),
-                                        L.ptr(tp), L.ptr(fn), L.ptr(fp), L.ptr(ws), ws.numel(), L.stream_ptr()))
+                                        L.ptr(tp), L.ptr(fn), L.ptr(fp), int(weight_mode), L.ptr(lw),
+                                        float(rgd_temperature), L.ptr(ws), ws.numel(), L.stream_ptr()))
         ctx.dlog = dlog
         return loss.reshape(())
 
@@ -43,7 +50,7 @@ class _FusedLossFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         g = ctx.dlog * grad_out
         ctx.dlog = None
-        return g, None, None, None, None, None, None, None, None
+        return (g,) + (None,) * 11
 
 
 class _CountsMixin:
@@ -79,6 +86,60 @@ class FocalLoss(_CountsMixin, torch.nn.Module):
                                   self.metric_counts, self.decision_threshold)
 
 
+class RGDBCE(_CountsMixin, torch.nn.Module):
+    """Reference losses.py:58-75.  As executed there (legacy `reduce="none"` = mean reduction) the re-weighting acts on
+    the scalar mean loss: m * exp(min(m, T) / (T + 1)), factor detached."""
+
+    def __init__(self, temperature: float):
+        super().__init__()
+        assert temperature is not None, "temperature must be provided and not None"
+        self.temperature = float(temperature)
+
+    def forward(self, input, target):
+        return _FusedLossFn.apply(input, target, _BCE, 1.0, 0.0, -1.0, 0.0, self.metric_counts,
+                                  self.decision_threshold, 0, None, self.temperature)
+
+
+class BatchWeightedBCE(_CountsMixin, torch.nn.Module):
+    """Reference losses.py:124-146: positives and negatives of the batch weigh total/2 each (epsilon 1e-10)."""
+
+    def __init__(self, epsilon=1e-10):
+        super().__init__()
+        if epsilon != 1e-10:
+            raise NotImplementedError("BatchWeightedBCE: only the reference's epsilon=1e-10 is built into the kernel")
+
+    def forward(self, input, target):
+        return _FusedLossFn.apply(input, target, _BCE, 1.0, 0.0, -1.0, 0.0, self.metric_counts,
+                                  self.decision_threshold, 1, None, -1.0)
+
+
+class WeightedBCE(_CountsMixin, torch.nn.Module):
+    """Reference losses.py:109-121: every element of row i weighs sum_j label_weights[j] * target[i, j]."""
+
+    def __init__(self, label_weights: torch.Tensor):
+        super().__init__()
+        assert label_weights is not None, "label_weights must be provided and not None"
+        self.label_weights = label_weights
+
+    def forward(self, input, target):
+        return _FusedLossFn.apply(input, target, _BCE, 1.0, 0.0, -1.0, 0.0, self.metric_counts,
+                                  self.decision_threshold, 2, self.label_weights, -1.0)
+
+
+class CBLoss(WeightedBCE):
+    """Reference losses.py:78-106: class-balanced label weights (1 - beta) / (1 - beta^n_j) (infinite effective number
+    where it would be 0), normalised to sum to the number of classes, then the WeightedBCE row weighting."""
+
+    def __init__(self, label_weights: torch.Tensor, beta=0.9999):
+        assert label_weights is not None, "label_weights must be provided and not None"
+        counts = torch.as_tensor(label_weights).float()
+        eff = 1.0 - torch.pow(torch.tensor(beta), counts)
+        eff = torch.where(eff == 0, torch.tensor(float("inf")), eff)
+        w = (1.0 - beta) / eff
+        super().__init__(w / torch.sum(w) * len(counts))
+        self.beta = beta
+
+
 def get_loss(config: dict, label_weights: torch.Tensor = None, bce_pos_weight: torch.Tensor = None):
     name = config["params"]["LOSS_FN"]
     if name == "BCE":
@@ -86,6 +147,14 @@ def get_loss(config: dict, label_weights: torch.Tensor = None, bce_pos_weight: t
     if name == "FocalLoss":
         return FocalLoss(gamma=config["params"]["FOCAL_LOSS_GAMMA"], alpha=config["params"]["FOCAL_LOSS_ALPHA"],
                          label_smoothing=config["params"]["LABEL_SMOOTHING"])
-    if name in ("WeightedBCE", "CBLoss", "BatchWeightedBCE", "RGDBCE", "SupCon"):
-        raise NotImplementedError(f"LOSS_FN={name} is a non-default ablation outside the MI355X hot path")
+    if name == "WeightedBCE":
+        return WeightedBCE(label_weights=label_weights)
+    if name == "CBLoss":
+        return CBLoss(label_weights=label_weights)
+    if name == "BatchWeightedBCE":
+        return BatchWeightedBCE()
+    if name == "RGDBCE":
+        return RGDBCE(temperature=config["params"]["RGDBCE_TEMP"])
+    if name == "SupCon":
+        raise NotImplementedError("LOSS_FN=SupCon (marked 'not currently using' in the reference) is not implemented")
     raise ValueError(f"Unknown loss function {name}")

@@ -308,6 +308,35 @@ def golden_protnote(variants=None):
 
 
 # --------------------------------------------------------------------------------------------
+def golden_losses_extra():
+    """The reference's other LOSS_FN choices (losses.py:58-170: RGDBCE, CBLoss, WeightedBCE, BatchWeightedBCE)."""
+    from protnote.utils.losses import get_loss
+
+    g = torch.Generator().manual_seed(17)
+    logits = torch.randn(29, 41, generator=g) * 2.5
+    y = (torch.rand(29, 41, generator=g) < 0.15).to(torch.int64)
+    y[3] = 0                                   # a protein without positives (zero row weight)
+    label_weights = torch.rand(41, generator=g) * 5 + 0.1          # WeightedBCE: inverse-frequency style weights
+    label_counts = torch.randint(0, 400, (41,), generator=g).float()  # CBLoss: label frequencies (some zero)
+    label_counts[5] = 0
+    out = {"logits": logits.numpy(), "multihots": y.numpy(), "label_weights": label_weights.numpy(),
+           "label_counts": label_counts.numpy()}
+    cases = {"RGDBCE": ({"LOSS_FN": "RGDBCE", "RGDBCE_TEMP": 0.12}, None),
+             "RGDBCE_hot": ({"LOSS_FN": "RGDBCE", "RGDBCE_TEMP": 5.0}, None),
+             "BatchWeightedBCE": ({"LOSS_FN": "BatchWeightedBCE"}, None),
+             "WeightedBCE": ({"LOSS_FN": "WeightedBCE"}, label_weights),
+             "CBLoss": ({"LOSS_FN": "CBLoss"}, label_counts)}
+    for name, (params, lw) in cases.items():
+        fn = get_loss({"params": params}, label_weights=lw)
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg, y.float())
+        l.backward()
+        out[name + "/loss"] = l.detach().numpy()
+        out[name + "/dlogits"] = lg.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "losses_extra.npz"), **out)
+    print("losses_extra.npz")
+
+
 def golden_losses_metrics():
     from protnote.utils.losses import get_loss, FocalLoss
     from protnote.models.ProtNoteTrainer import calculate_tp_fn_fp, calculate_f1, calculate_f1_micro
@@ -542,7 +571,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
-            "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics,
+            "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers}
     for name, fn in jobs.items():

@@ -667,3 +667,32 @@ def test_embedding_dropouts(golden_dir):
         a, _ = drop(sequence_embeddings=P_f, label_embeddings=lab)
         b, _ = plain(sequence_embeddings=P_f, label_embeddings=lab)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6)
+
+
+def test_extra_losses_golden(golden_dir):
+    """LOSS_FN = RGDBCE / BatchWeightedBCE / WeightedBCE / CBLoss through get_loss: value and d/dlogits against the
+    reference, with the TP/FN/FP counting still fused into the same pass."""
+    from protnote_amd.utils.losses import get_loss
+
+    g = _g(golden_dir, "losses_extra.npz")
+    logits = torch.from_numpy(g["logits"]).to(DEV)
+    y = torch.from_numpy(g["multihots"]).to(DEV)
+    lw, lc = torch.from_numpy(g["label_weights"]), torch.from_numpy(g["label_counts"])
+    cases = {"RGDBCE": ({"LOSS_FN": "RGDBCE", "RGDBCE_TEMP": 0.12}, None),
+             "RGDBCE_hot": ({"LOSS_FN": "RGDBCE", "RGDBCE_TEMP": 5.0}, None),
+             "BatchWeightedBCE": ({"LOSS_FN": "BatchWeightedBCE"}, None),
+             "WeightedBCE": ({"LOSS_FN": "WeightedBCE"}, lw), "CBLoss": ({"LOSS_FN": "CBLoss"}, lc)}
+    for name, (params, w) in cases.items():
+        for tgt in (y.float(), y):               # float and int64 targets
+            fn = get_loss({"params": params}, label_weights=w)
+            counts = torch.zeros(3, y.shape[1], device=DEV)
+            fn.metric_counts, fn.decision_threshold = counts, 0.5
+            lg = logits.clone().requires_grad_(True)
+            l = fn(lg, tgt)
+            l.backward()
+            np.testing.assert_allclose(l.item(), float(g[name + "/loss"]), rtol=2e-6, err_msg=name)
+            ref = g[name + "/dlogits"]
+            np.testing.assert_allclose(lg.grad.cpu().numpy(), ref, atol=1e-9 + 2e-6 * np.abs(ref).max(), rtol=2e-5,
+                                       err_msg=name)
+            pred = (torch.sigmoid(logits) >= 0.5).float()
+            np.testing.assert_array_equal(counts[0].cpu().numpy(), (pred * y).sum(0).cpu().numpy())

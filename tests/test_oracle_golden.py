@@ -131,6 +131,22 @@ def test_losses_and_metrics(golden_dir):
         np.testing.assert_array_equal(O.f1_micro(tp, fn, fp).numpy(), g[f"th{th}/f1_micro"])
 
 
+def test_extra_losses(golden_dir):
+    """RGDBCE / BatchWeightedBCE / WeightedBCE / CBLoss (reference losses.py:58-146) - value and d/dlogits."""
+    g = _load(golden_dir, "losses_extra.npz")
+    logits, y = torch.from_numpy(g["logits"]), torch.from_numpy(g["multihots"]).float()
+    lw, lc = torch.from_numpy(g["label_weights"]), torch.from_numpy(g["label_counts"])
+    fns = {"RGDBCE": lambda x: O.rgd_bce_loss(x, y, 0.12), "RGDBCE_hot": lambda x: O.rgd_bce_loss(x, y, 5.0),
+           "BatchWeightedBCE": lambda x: O.batch_weighted_bce_loss(x, y),
+           "WeightedBCE": lambda x: O.weighted_bce_loss(x, y, lw), "CBLoss": lambda x: O.cb_loss(x, y, lc)}
+    for name, fn in fns.items():
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg)
+        l.backward()
+        np.testing.assert_allclose(float(l), float(g[name + "/loss"]), rtol=1e-6, err_msg=name)
+        np.testing.assert_allclose(lg.grad.numpy(), g[name + "/dlogits"], atol=1e-9, rtol=1e-5, err_msg=name)
+
+
 def test_protnote_train_encoder_grads(golden_dir):
     """TRAIN_SEQUENCE_ENCODER: True - the oracle's encoder gradients equal the reference's."""
     g = _load(golden_dir, "protnote_small_concatenation.npz")
