@@ -1422,6 +1422,8 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
                                void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
+  if (NL > 65535 || B > 65535)  // the layer-1 reductions put one label / protein per gridDim.y entry
+    return fail("pairhead bwd: at most 65535 labels and 65535 proteins per step (got %d x %d)", B, NL);
   const int h = hd->h, d = hd->d, n = hd->nlayers;
   const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
