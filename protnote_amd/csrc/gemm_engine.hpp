@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   // fetch(): branch-free - every load is issued unconditionally from a clamped (always valid) address and
   // invalid lanes are zeroed by selects in commit(), so the loads of slab s+1 stay in flight under the
   // MFMAs of slab s (a predicated load would put an s_waitcnt vmcnt(0) in front of the MFMA block).
-  auto fetch = [&](int s) {
+  auto fetch_a = [&](int s) {
     const int seg = s / spt;
     const int c = (s - seg * spt) * BK + 4 * kv;
     const bool kok = c < p.Kseg;
@@ -358,6 +358,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
         rq = ld4(p.dz_q + cc);
       }
     }
+  };
+  auto fetch_b = [&](int s) {
+    const int seg = s / spt;
+    const int c = (s - seg * spt) * BK + 4 * kv;
+    const bool kok = c < p.Kseg;
+    const int cc = kok ? c : 0;
     bmask = 0;
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
@@ -366,23 +372,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
     }
   };
 
-  auto pin_fetched = [&]() {
+  auto fetch = [&](int s) {
+    fetch_a(s);
+    fetch_b(s);
+  };
+
+  auto pin_a = [&]() {
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       pin4(ra[q]);
       if constexpr (AK == A_PAIRSUM_RELU || AK == A_DZ_ELEM || AK == A_PAIRPROD) pin4(ra2[q]);
     }
+  };
+  auto pin_b = [&]() {
 #pragma unroll
     for (int q = 0; q < NQB; ++q) pin4(rb[q]);
+  };
+  auto pin_fetched = [&]() {
+    pin_a();
+    pin_b();
   };
 
   auto sel4 = [](bool ok, float4 v) {
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
-  auto commit = [&](int buf) {
+  auto commit_a = [&](int buf) {
     float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       float4 v = ra[q];
@@ -420,10 +436,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
       }
       *reinterpret_cast<float4*>(As + (r_in + q * RPP) * LDK + 4 * kv) = sel4(ok, v);
     }
+  };
+  auto commit_b = [&](int buf) {
+    float* Bs = smem + buf * STAGE + BM * LDK;
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
       *reinterpret_cast<float4*>(Bs + (r_in + q * RPP) * LDK + 4 * kv) = sel4((bmask >> q) & 1u, rb[q]);
     }
+  };
+
+  auto commit = [&](int buf) {
+    commit_a(buf);
+    commit_b(buf);
   };
 
   f32x16 acc[WM][WN];
@@ -466,7 +490,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   fetch(0);
   pin_fetched();
   commit(0);
+#if !defined(PN_F32_PIPE1) && !defined(PN_ABL)
+  fetch(nslab > 1 ? 1 : 0);
+#endif
   __syncthreads();
+  // (PN_F32_PIPE1 selects the earlier single-region loop: all loads of slab s+1 issued at the top of slab s and waited
+  //  for in its middle.  Measured on the train step: 7.34 s vs 7.19 s with the two-region loop below.)
 #if defined(PN_ABL) && PN_ABL == 1  // ablation: MFMA + LDS fragment reads only
   for (int s = 0; s + 1 < nslab; ++s)
     compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
@@ -498,6 +527,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   for (int s = 0; s + 1 < nslab; ++s) {
     compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
     __syncthreads();
+  }
+#elif !defined(PN_F32_PIPE1)
+  // two-region pipeline (as in gemm_bf16x3.hpp): A(s+1) staged under the first half of the MFMAs, B(s+1) under the
+  // second; the loads of slab s+2 are issued as soon as their registers are free - a full slab to land
+  for (int s = 0; s + 1 < nslab; ++s) {
+    const int cur = s & 1;
+    const int nxt = s + 2 < nslab ? s + 2 : s + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    pin_a();
+    compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 16>{});
+    commit_a(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_a(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    pin_b();
+    compute(cur, integral_constant<int, BK / 16>{}, integral_constant<int, BK / 8>{});
+    commit_b(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_b(nxt);
+    // raw barrier: LDS traffic drained, but the global loads just issued stay in flight across it (a
+    // __syncthreads() here makes hipcc wait vmcnt(0) at the top of the next slab)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 #else
   for (int s = 0; s + 1 < nslab; ++s) {
