@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   }
 
   float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
-  unsigned rowok = 0, tapok = 0;
+  unsigned rowok = 0, rowok_b = 0, tapok = 0;
 
   // branch-free fetch: rows past the split end are clamped to the split's first row and zeroed by selects in
   // commit().  The pair-grid decode (i = r % B, j = r / B) of the thread's first row is carried incrementally
@@ -126,9 +126,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     pj0 = ru / pB;
     pi0 = ru - pj0 * pB;
   }
-  auto fetch = [&](long k0) {
+  auto fetch_a = [&](long k0) {
     rowok = 0;
-    tapok = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       long r = k0 + rr + 8 * q;
@@ -141,6 +140,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         const float g = p.gvec[r];
         rg[q] = make_float4(g, g, g, g);
       }
+    }
+  };
+  auto fetch_b = [&](long k0) {
+    rowok_b = 0;
+    tapok = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      long r = k0 + rr + 8 * q;
+      const bool ok = r < r_end;
+      rowok_b |= (ok ? 1u : 0u) << q;
+      r = ok ? r : r_begin;
       if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) {
         unsigned i = pi0 + 8 * q, j = pj0;
         while (i >= pB) {  // at most one iteration when B >= 24
@@ -174,15 +184,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
-  auto commit = [&](int buf) {
+  auto commit_a = [&](int buf) {
     float* As = smem + buf * STAGE;
-    float* Bs = As + BK * LDM;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       pin4(ra[q]);
-      pin4(rb[q]);
       if constexpr (TA != TA_PLAIN) pin4(rg[q]);
-      if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) pin4(rb2[q]);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -195,6 +202,19 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         a.z = (fmaf(a.z, ms.z, mt.z) > 0.f ? g.z * mcs.z : 0.f) + fmaf(mq.z, a.z, mp.z);
         a.w = (fmaf(a.w, ms.w, mt.w) > 0.f ? g.w * mcs.w : 0.f) + fmaf(mq.w, a.w, mp.w);
       }
+      *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = sel4(ok && a_ok, a);
+    }
+  };
+  auto commit_b = [&](int buf) {
+    float* Bs = smem + buf * STAGE + BK * LDM;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      pin4(rb[q]);
+      if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) pin4(rb2[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = (rowok_b >> q) & 1u;
       float4 b = rb[q];
       bool bok = ok && b_ok;
       if constexpr (TB == TB_CONVTAP) {
@@ -222,7 +242,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         b.z = relu(b.z + rb2[q].z);
         b.w = relu(b.w + rb2[q].w);
       }
-      *reinterpret_cast<float4*>(As + (rr + 8 * q) * LDM + 4 * c4) = sel4(ok && a_ok, a);
       *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = sel4(bok, b);
     }
   };
@@ -241,19 +260,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   // Fragment reads are 8-byte: lane l takes columns (2l, 2l+1) of k-row fk, i.e. MFMA tile 0 of a wave owns the
   // even and tile 1 the odd columns of its 64-wide strip (un-permuted in the epilogue).  The fragments of
   // k-pair kk+1 are read before the MFMAs of k-pair kk so the LDS latency sits under the matrix pipe.
-  auto compute = [&](int buf) {
+  // k-pairs [KK0, KK1) of the slab
+  auto compute = [&](int buf, auto kk0_c, auto kk1_c) {
+    constexpr int KK0 = decltype(kk0_c)::value, KK1 = decltype(kk1_c)::value;
     const float* As = smem + buf * STAGE + fk * LDM + wm * 64 + 2 * fcol;
     const float* Bs = smem + buf * STAGE + BK * LDM + fk * LDN + wn * 64 * NGN + 2 * fcol;
-    float2 a = *reinterpret_cast<const float2*>(As);
+    float2 a = *reinterpret_cast<const float2*>(As + 2 * KK0 * LDM);
     float2 b[NGN];
 #pragma unroll
-    for (int g = 0; g < NGN; ++g) b[g] = *reinterpret_cast<const float2*>(Bs + g * 64);
+    for (int g = 0; g < NGN; ++g) b[g] = *reinterpret_cast<const float2*>(Bs + 2 * KK0 * LDN + g * 64);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = KK0; kk < KK1; ++kk) {
       float2 na = a, nb[NGN];
 #pragma unroll
       for (int g = 0; g < NGN; ++g) nb[g] = b[g];
-      if (kk + 1 < BK / 2) {
+      if (kk + 1 < KK1) {
         na = *reinterpret_cast<const float2*>(As + (2 * kk + 2) * LDM);
 #pragma unroll
         for (int g = 0; g < NGN; ++g) nb[g] = *reinterpret_cast<const float2*>(Bs + (2 * kk + 2) * LDN + g * 64);
@@ -271,22 +292,36 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     }
   };
 
+  // Two-region pipeline (see gemm_engine.hpp): A(t+1) is staged under the first 8 k-pairs of slab t, B(t+1) under
+  // the last 8; the loads of slab t+2 go out as soon as their registers are free (rows past r_end are clamped and
+  // masked, so over-fetching one slab at the end is harmless).
+  using std::integral_constant;
   if (r_begin < r_end) {
-    fetch(r_begin);
-    commit(0);
+    fetch_a(r_begin);
+    fetch_b(r_begin);
+    commit_a(0);
+    commit_b(0);
+    fetch_a(r_begin + BK);
+    fetch_b(r_begin + BK);
     __syncthreads();
     int cur = 0;
     long k0 = r_begin;
     for (; k0 + BK < r_end; k0 += BK) {
-      fetch(k0 + BK);
       __builtin_amdgcn_sched_barrier(0);
-      compute(cur);
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+      commit_a(cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      commit(cur ^ 1);
-      __syncthreads();
+      fetch_a(k0 + 2 * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+      commit_b(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_b(k0 + 2 * BK);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       cur ^= 1;
     }
-    compute(cur);
+    compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
   }
 
   float* out = p.Cpart + (long)split * p.M * p.ldc;
