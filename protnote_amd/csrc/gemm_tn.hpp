@@ -306,6 +306,34 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     __syncthreads();
     int cur = 0;
     long k0 = r_begin;
+#if defined(PN_TN_ABL) && PN_TN_ABL == 1  // ablation: MFMA + LDS fragment reads only
+    for (; k0 + BK < r_end; k0 += BK) compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
+#elif defined(PN_TN_ABL) && PN_TN_ABL == 2  // ablation: MFMA + operand transform + LDS writes + barrier, no global loads
+    for (; k0 + BK < r_end; k0 += BK) {
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+      commit_a(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+      commit_b(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+#elif defined(PN_TN_ABL) && PN_TN_ABL == 3  // ablation: MFMA + global loads + barrier, no transform / LDS writes
+    for (; k0 + BK < r_end; k0 += BK) {
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+      fetch_a(k0 + 2 * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+      fetch_b(k0 + 2 * BK);
+      for (int q = 0; q < NQ; ++q) { pin4(ra[q]); pin4(rb[q]); }
+      __syncthreads();
+    }
+#elif defined(PN_TN_ABL) && PN_TN_ABL == 4  // ablation: MFMA + barrier only
+    for (; k0 + BK < r_end; k0 += BK) {
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
+      __syncthreads();
+    }
+#endif
     for (; k0 + BK < r_end; k0 += BK) {
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
