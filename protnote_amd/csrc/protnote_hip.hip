@@ -164,6 +164,9 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   // 32 (256x256 tiles, 1 workgroup/CU) workgroups are resident per XCD
   const int resident = (Cfg::BM * Cfg::BN >= 256 * 256) ? 32 : 64;
   pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  // pair-sum operand (A from two small tables): W is the only streamed operand - one column tile per XCD block keeps
+  // its 3 MB panel in that XCD's L2 (fabric fetch per launch 1.48 TB -> see profiles/hbm_traffic.json)
+  if (AK == A_PAIRSUM_RELU && resident == 32 && pp.xcd_bc && tm >= 64) pp.xcd_bc = 1;
   pp.xcd_br = pp.xcd_bc ? resident / pp.xcd_bc : 0;
   long grid = tm * tn;
   if (pp.xcd_bc) {
