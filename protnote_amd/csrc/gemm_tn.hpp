@@ -328,6 +328,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
       for (int q = 0; q < NQ; ++q) { pin4(ra[q]); pin4(rb[q]); }
       __syncthreads();
     }
+#elif defined(PN_TN_ABL) && PN_TN_ABL == 5  // ablation: the real two-region loop without operand transform / LDS writes
+    for (; k0 + BK < r_end; k0 += BK) {
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+      for (int q = 0; q < NQ; ++q) pin4(ra[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_a(k0 + 2 * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+      for (int q = 0; q < NQ; ++q) pin4(rb[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_b(k0 + 2 * BK);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
 #elif defined(PN_TN_ABL) && PN_TN_ABL == 4  // ablation: MFMA + barrier only
     for (; k0 + BK < r_end; k0 += BK) {
       compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
