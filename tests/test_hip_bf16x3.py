@@ -296,3 +296,35 @@ def test_bf16x3_mode_other_widths(bf16x3, latent, scale):
         out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
     err = (out.cpu() - ref).abs().max().item()
     assert err < 1e-3, err
+
+
+def test_bf16x3_map_parity(bf16x3):
+    """BASELINE metric 'mAP parity vs reference' in bf16x3 mode: micro / macro AP of the device metrics over the HIP
+    logits (full-width head, 256 x 300 pairs: large enough for the split-bf16 kernels) against the AP of the CPU
+    oracle's logits."""
+    from oracle import metrics_oracle as MO
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.evaluation import DeviceAveragePrecision
+
+    gen = torch.Generator().manual_seed(31)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 256, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    y = (torch.rand(B, NL, generator=gen) < torch.sigmoid(2 * ref - 2)).numpy()
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    assert (out.cpu() - ref).abs().max().item() < 1e-3
+    acc = DeviceAveragePrecision(NL, B, DEV)
+    acc.update(torch.sigmoid(out), torch.from_numpy(y).to(DEV))
+    m = acc.compute()
+    pr = torch.sigmoid(ref).numpy()
+    mi_ref = MO.average_precision_fast(pr.ravel(), y.ravel())
+    ma_ref = float(np.nanmean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)]))
+    assert 0.2 < mi_ref < 0.99
+    assert abs(m["map_micro"] - mi_ref) < 1e-4 and abs(m["map_macro"] - ma_ref) < 2e-4, (m, mi_ref, ma_ref)
