@@ -2,6 +2,8 @@
 """bench.py - ProtNote train step (fwd + bwd + clip + Adam) on MI355X, BASELINE.json configs[2]/[3].
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1            # no torchrun env: re-executes itself under
+                                                              # torch.distributed.run with 8 ranks (RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -16,17 +18,26 @@ achieved = 2*rows*h*h FLOP per launch / mean launch duration from hipEvents reco
 inside the timed region (pn_prof_begin/end); peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, dense f32).
 `cpu_baseline` times the CPU oracle's train step (a port of the reference algorithm, pinned to reference
 golden vectors) on a bounded sample of the same workload, rank 0 at N=1 only.
+
+Outside the headline timed region the same process also measures (each with its own `roofline`):
+  `fast_mode`     the same train step on the opt-in bf16x3 arithmetic,
+  `forward_only`  BASELINE configs[1]: eval forward, B=256 x L=512 x 32102 labels,
+  `zero_shot`     BASELINE configs[4]: variable-length sequences (log-uniform 32..2048) in length buckets
+                  {128..2048}, two descriptions per label ensembled, GO-sized label table then an EC-sized table
+                  swapped in at run time on the same model object (sequences sharded over ranks at N>1),
+  `comm`          (N>1) device time of every collective of the timed region.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 KIND_NAMES = {
     0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
@@ -34,15 +45,15 @@ KIND_NAMES = {
     104: "tn:plain x conv tap (encoder wgrad)", 100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
 }
-KIND_NAMES.update({1000: "nt:plain [bf16x3]", 1010: "nt:bn_relu(z) [bf16x3]", 1020: "nt:pairsum_relu [bf16x3]",
-                   1031: "nt:conv [bf16x3]", 1012: "nt:bn_relu(z)->rowdot [bf16x3]", 1022: "nt:pairsum_relu->rowdot [bf16x3]",
-                   1100: "tn:plain x plain [bf16x3]", 1101: "tn:plain x bn_relu [bf16x3]",
-                   1102: "tn:plain x pairsum [bf16x3]"})
+KIND_NAMES.update({1000 + k: v + " [bf16x3]" for k, v in list(KIND_NAMES.items())})
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: Peak BF16 MFMA, dense
+BUCKETS = (128, 256, 512, 1024, 2048)
 
 
 def build_model(device, seed=42, unit_scale_weights=False):
+    import torch
+
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.protein_encoders import ProteInfer
 
@@ -73,6 +84,8 @@ def build_model(device, seed=42, unit_scale_weights=False):
 
 
 def synthetic_batch(B, L, NL, device, seed, ragged=False):
+    import torch
+
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(0, 20, (B, L), generator=g)
     onehots = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
@@ -90,6 +103,8 @@ def synthetic_batch(B, L, NL, device, seed, ragged=False):
 def cpu_baseline(seconds_hint=20.0):
     """Oracle train step (reference algorithm restated, f32, torch-CPU) on a bounded sample of the same
     workload: B=16 proteins, L=512, N_L=8192 labels, full-width model (~20 s of CPU work on 32 threads)."""
+    import torch
+
     from oracle import protnote_oracle as O
     from tests.helpers import random_encoder_sd, random_head_sd
 
@@ -117,6 +132,80 @@ def cpu_baseline(seconds_hint=20.0):
                       f"{dt:.1f} s on {cores} threads"}
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: run N ranks of this script under
+    torch.distributed.run on this node (one process per GPU, RCCL), and hand back its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def family(prof):
+    """Dominant family: launches that contract over the full pair grid with a 3072x3072 weight
+    -> (TFLOP/s, launches, total ms, total flop)."""
+    big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12} or prof
+    tot_ms = sum(v[1] for v in big.values())
+    tot_fl = sum(v[2] for v in big.values())
+    n_launch = sum(v[0] for v in big.values())
+    return (tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0), n_launch, tot_ms, tot_fl
+
+
+def kernel_table(prof):
+    out = {}
+    for kind, (cnt, ms, fl) in sorted(prof.items()):
+        out[KIND_NAMES.get(kind, str(kind))] = {
+            "launches": cnt, "ms_total": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0}
+    return out
+
+
+def roofline_block(prof, math_mode, kernel_note):
+    ach, n_launch, tot_ms, tot_fl = family(prof)
+    peak = F32_MFMA_PEAK_TFLOPS if math_mode == "f32" else BF16_MFMA_PEAK_TFLOPS
+    blk = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+           "kernel": kernel_note, "launches": n_launch, "avg_ms_per_launch": tot_ms / max(n_launch, 1),
+           "flops_per_launch": tot_fl / max(n_launch, 1), "family_ms": tot_ms}
+    if math_mode != "f32":
+        blk["note"] = ("algorithmic (f32-equivalent) flops over the dense bf16 peak; each costs three bf16 MFMA "
+                       "flops, so the ceiling of frac is 1/3")
+    return blk
+
+
+def zero_shot_batches(n_seq, batch, rank, world, dev, seed=5):
+    """configs[4] workload: lengths log-uniform in [32, 2048], padded to their bucket; batches of one bucket each,
+    dealt round-robin to the ranks."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.exp(torch.rand(n_seq, generator=g) * (math.log(2048) - math.log(32)) + math.log(32)).long().clamp(32, 2048)
+    ids = torch.randint(0, 20, (n_seq, 2048), generator=g)
+    batches, k = [], 0
+    for bi, bmax in enumerate(BUCKETS):
+        lo = BUCKETS[bi - 1] if bi else 0
+        rows = torch.nonzero((lens > lo) & (lens <= bmax)).flatten()
+        for s in range(0, len(rows), batch):
+            r = rows[s:s + batch]
+            mine = (k % world) == rank
+            k += 1
+            if not mine:
+                continue
+            x = torch.nn.functional.one_hot(ids[r, :bmax], 20).permute(0, 2, 1).float().contiguous()
+            for kk, i in enumerate(r):
+                x[kk, :, lens[i]:] = 0
+            batches.append((x.to(dev), lens[r].to(dev)))
+    return batches, int(lens.sum()), n_seq
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,23 +222,39 @@ def main():
     ap.add_argument("--ragged-lengths", action="store_true", help="sequence lengths ~ U[64, L] padded to L")
     ap.add_argument("--no-fast-mode", action="store_true",
                     help="skip the extra bf16x3 measurement reported under 'fast_mode' when --math f32")
+    ap.add_argument("--no-extra", action="store_true", help="skip the forward_only / zero_shot sub-benchmarks")
+    ap.add_argument("--zero-shot-seqs", type=int, default=512, help="sequences in the zero_shot sub-benchmark")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
+    import torch
+    import torch.distributed as dist
 
     from protnote_amd import _lib
     from protnote_amd.models.ProtNoteTrainer import train_step
     from protnote_amd.models.train_path import head_parameters
-    from protnote_amd.utils.distributed import init_from_env
+    from protnote_amd.utils import distributed as D
     from protnote_amd.utils.losses import get_loss
     from protnote_amd.utils.optim import FusedClipAdam
-    import torch.distributed as dist
 
-    rank, local, world = init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank, local, world = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus {args.gpus} does it itself when no torchrun env is set)")
+    dry = os.environ.get("PN_SHARE_GPU") == "1"  # several ranks on one GPU over gloo: plumbing check only
+    if world > 1:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        if not dry and dist.get_backend() != "nccl":
+            raise SystemExit(f"multi-GPU bench must run over RCCL (backend 'nccl'), got {dist.get_backend()!r}")
+        if not dry and torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} visible GPUs")
     dev = torch.device("cuda", torch.cuda.current_device())  # set by init_from_env (LOCAL_RANK)
 
     _lib.set_math_mode(args.math)
-    model = build_model(dev)
+    model = build_model(dev, seed=42 + rank)  # deliberately different per rank: sync_initial_state must fix it
     model.train()
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     params = list(head_parameters(model))
@@ -159,6 +264,8 @@ def main():
             q.requires_grad = True
         params += list(model.sequence_encoder.trunk_parameters())
     opt = FusedClipAdam(params, lr=3e-4, max_norm=1.0)
+    if world > 1:
+        D.sync_initial_state(model, opt)  # DDP-construction semantics: rank 0's weights / buffers everywhere
     B, L, NL = args.batch, args.seq_len, args.labels
     batch = synthetic_batch(B, L, NL, dev, seed=1000 + rank, ragged=args.ragged_lengths)
     counts = torch.zeros(3, NL, dtype=torch.float32, device=dev)
@@ -168,66 +275,140 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run():
-        for _ in range(args.warmup):
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def timed_train(steps, warmup):
+        for _ in range(warmup):
             train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
         sync()
+        D.comm_timing(world > 1)
         _lib.prof_begin()
         t0 = time.time()
         loss = None
-        for _ in range(args.steps):
+        for _ in range(steps):
             loss = train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
         sync()
         elapsed = time.time() - t0
         prof = _lib.prof_end()
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, prof, float(loss.item())
+        comm = D.comm_stats() if world > 1 else None
+        D.comm_timing(False)
+        return max_over_ranks(elapsed), prof, float(loss.item()), comm
 
-    def family(prof):  # dominant family: launches that contract over the full pair grid with a 3072x3072 weight
-        big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12} or prof
-        tot_ms = sum(v[1] for v in big.values())
-        tot_fl = sum(v[2] for v in big.values())
-        n_launch = sum(v[0] for v in big.values())
-        return (tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0), n_launch, tot_ms, tot_fl
+    def timed_eval(fn, steps, warmup):
+        with torch.no_grad():
+            for _ in range(warmup):
+                fn()
+            sync()
+            _lib.prof_begin()
+            t0 = time.time()
+            for _ in range(steps):
+                fn()
+            sync()
+            elapsed = time.time() - t0
+        return max_over_ranks(elapsed), _lib.prof_end()
 
-    elapsed, prof, loss_val = timed_run()
+    # ------------------------------------------------------------------ headline: train step
+    elapsed, prof, loss_val, comm = timed_train(args.steps, args.warmup)
     fast = None
     if args.math == "f32" and not args.no_fast_mode:  # same workload once more on the opt-in bf16x3 arithmetic
         _lib.set_math_mode("bf16x3")
-        f_elapsed, f_prof, f_loss = timed_run()
+        f_elapsed, f_prof, f_loss, _ = timed_train(args.steps, args.warmup)
         _lib.set_math_mode("f32")
-        f_ach = family(f_prof)[0]
         fast = {"math": "bf16x3 (f32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate)",
                 "value": world * B * NL * args.steps / f_elapsed, "unit": "pairs/s",
                 "ms_per_step": f_elapsed / args.steps * 1e3, "final_loss": f_loss,
-                "roofline": {"bound": "mfma", "achieved": f_ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": f_ach / BF16_MFMA_PEAK_TFLOPS,
-                             "note": "algorithmic (f32-equivalent) flops over the dense bf16 peak; each costs three "
-                                     "bf16 MFMA flops, so the ceiling of frac is 1/3"}}
+                "roofline": roofline_block(f_prof, "bf16x3", "pair-grid 3072x3072 bf16x3 GEMM family"),
+                "kernels": kernel_table(f_prof)}
+
+    # ------------------------------------------------------------------ sub-benchmarks (outside the headline region)
+    extra = {}
+    if not args.no_extra:
+        # the train-step activation store (2 x 101 GB) is not needed any more
+        import protnote_amd
+
+        model.__dict__.pop("_pn_train_save", None)
+        protnote_amd.free_workspaces()
+        torch.cuda.empty_cache()
+        model.eval()
+        modes = [args.math] + (["bf16x3"] if args.math == "f32" and not args.no_fast_mode else [])
+
+        def fwd_only():
+            model(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
+                  label_embeddings=batch["label_embeddings"])
+
+        fo = {}
+        for mode in modes:
+            _lib.set_math_mode(mode)
+            e_el, e_prof = timed_eval(fwd_only, max(1, min(args.steps, 3)), 1)
+            n = max(1, min(args.steps, 3))
+            enc_ms = sum(v[1] for k, v in e_prof.items() if k % 1000 == 31)
+            fo[mode] = {"value": world * B * NL * n / e_el, "unit": "pairs/s", "ms_per_forward": e_el / n * 1e3,
+                        "encoder_share_of_gemm_time": enc_ms / max(sum(v[1] for v in e_prof.values()), 1e-9),
+                        "roofline": roofline_block(e_prof, mode, "pair-grid 3072x3072 GEMM family (eval forward)"),
+                        "kernels": kernel_table(e_prof)}
+        extra["forward_only"] = {"workload": f"BASELINE configs[1]: eval forward, per-GPU batch {B} x L={L}, {NL} labels, "
+                                             "1 description per label", **fo}
+
+        model.inference_descriptions_per_label = 2
+        zb, residues, n_seq = zero_shot_batches(args.zero_shot_seqs, 128, rank, world, dev)
+        gz = torch.Generator().manual_seed(7)
+        tables = [("GO-2019 (32102 labels x 2 descriptions)", torch.randn(32102 * 2, 1024, generator=gz).to(dev)),
+                  ("EC (5134 labels x 2 descriptions)", torch.randn(5134 * 2, 1024, generator=gz).to(dev))]
+        zs = {}
+        for mode in modes:
+            _lib.set_math_mode(mode)
+            res = {}
+            for name, table in tables:  # the label table is swapped between the two timed passes, same model object
+                def run(table=table):
+                    for x, l in zb:
+                        model(sequence_onehots=x, sequence_lengths=l, label_embeddings=table)
+
+                with torch.no_grad():
+                    if zb:
+                        model(sequence_onehots=zb[0][0], sequence_lengths=zb[0][1], label_embeddings=table)
+                z_el, z_prof = timed_eval(run, 1, 0)
+                gemm_ms = max(sum(v[1] for v in z_prof.values()), 1e-9)
+                enc_ms = sum(v[1] for k, v in z_prof.items() if k % 1000 == 31)
+                res[name] = {"value": n_seq * table.shape[0] / z_el, "unit": "pairs/s (description rows scored)",
+                             "sequences_per_s": n_seq / z_el, "seconds": z_el,
+                             "encoder_share_of_gemm_time": enc_ms / gemm_ms,
+                             "roofline": roofline_block(z_prof, mode, "pair-grid 3072x3072 GEMM family (eval chunks)")}
+            zs[mode] = res
+        extra["zero_shot"] = {"workload": f"BASELINE configs[4]: {n_seq} sequences ({residues} residues), lengths "
+                                          f"log-uniform 32..2048 padded to buckets {list(BUCKETS)}, batch 128, two "
+                                          "descriptions per label ensembled, GO table then EC table swapped at run "
+                                          "time; batches dealt round-robin to the ranks", **zs}
+        _lib.set_math_mode(args.math)
+        model.inference_descriptions_per_label = 1
 
     if rank == 0:
         pairs = world * B * NL * args.steps
-        kernels = {}
-        for kind, (cnt, ms, fl) in sorted(prof.items()):
-            kernels[KIND_NAMES.get(kind, str(kind))] = {
-                "launches": cnt, "ms_total": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0}
-        achieved, n_launch, tot_ms, tot_fl = family(prof)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        # f32 mode: algorithmic flops against the f32-MFMA peak.  bf16x3 mode: the same algorithmic flops (each costs
-        # three bf16 MFMA flops) against the dense bf16 peak - the ceiling of that ratio is 1/3.
-        peak = F32_MFMA_PEAK_TFLOPS if args.math == "f32" else BF16_MFMA_PEAK_TFLOPS
+        traffic, traffic_src = None, None
+        for cand in ("r02_hbm_traffic.json", "hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", cand)
+            if args.math == "f32" and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("bytes_per_launch")
+                    traffic_src = f"profiles/{cand} (separate rocprofv3 --pmc passes of this command; not measured in this run)"
+                    break
+                except Exception:
+                    traffic = None
         # SURVEY 8d also defines the head's work densely (the reference's own computation, joint tensor included):
         # 151.0 MFLOP per pair fwd+bwd; the factorised implementation issues 3 x 37.75 = 113.3 MFLOP per pair
-        dense_tflops = pairs * 151.0e6 / elapsed / 1e12
+        roof = roofline_block(prof, args.math,
+                              "pair-grid 3072x3072 f32-MFMA GEMM family (gemm_nt_kernel / gemm_tn_kernel)"
+                              if args.math == "f32" else
+                              "pair-grid 3072x3072 bf16x3 GEMM family (gemm_nt_bf16x3_kernel / gemm_tn_bf16x3_kernel); "
+                              "achieved = algorithmic (f32-equivalent) flops")
+        roof.update({"traffic": traffic, "traffic_source": traffic_src,
+                     "whole_step_tflops_dense_definition": pairs * 151.0e6 / elapsed / 1e12,
+                     "whole_step_tflops_issued": pairs * 113.26e6 / elapsed / 1e12,
+                     "family_share_of_step": roof["family_ms"] / (elapsed * 1e3)})
         out = {
             "metric": "protein-label pairs/sec (fwd+bwd)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -240,24 +421,24 @@ def main():
                                    + ("trainable encoder" if args.train_encoder else "frozen encoder"),
                        "global_batch": world * B, "seq_len": L, "n_labels": NL,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": loss_val},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic if args.math == "f32" else None,
-                         "kernel": ("pair-grid 3072x3072 f32-MFMA GEMM family (gemm_nt_kernel / gemm_tn_kernel)"
-                                    if args.math == "f32" else
-                                    "pair-grid 3072x3072 bf16x3 GEMM family (gemm_nt_bf16x3_kernel / "
-                                    "gemm_tn_bf16x3_kernel); achieved = algorithmic (f32-equivalent) flops"),
-                         "whole_step_tflops_dense_definition": dense_tflops,
-                         "whole_step_tflops_issued": pairs * 113.26e6 / elapsed / 1e12,
-                         "launches": n_launch, "avg_ms_per_launch": tot_ms / max(n_launch, 1),
-                         "flops_per_launch": tot_fl / max(n_launch, 1)},
-            "kernels": kernels,
+            "roofline": roof,
+            "kernels": kernel_table(prof),
         }
+        if world > 1:
+            per_step = {k: {"calls_per_step": v["calls"] / args.steps, "bytes_per_call": v["bytes"] / max(v["calls"], 1),
+                            "ms_per_step": v["ms"] / args.steps} for k, v in (comm or {}).items()}
+            out["comm"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                           "collectives_rank0": per_step,
+                           "ms_per_step_total": sum(v["ms_per_step"] for v in per_step.values()),
+                           "share_of_step": sum(v["ms_per_step"] for v in per_step.values()) / (elapsed / args.steps * 1e3)}
         if fast is not None:
             out["fast_mode"] = fast
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -61,3 +61,16 @@ def binned_auprc(scores, labels, thresholds) -> float:
     prec.append(1.0)
     rec.append(0.0)
     return float(sum((rec[k] - rec[k + 1]) * prec[k] for k in range(len(thresholds))))
+
+
+def macro_mean(per_label_ap, empty_label_ap=0.0) -> float:
+    """Macro average over the label axis.  A label with no positive has an undefined AP (NaN above).  torcheval 0.0.7's
+    precision-recall curve turns the 0/0 recalls of such a label into 1.0 ("If recalls are NaNs, set NaNs to 1.0s"),
+    which makes its Riemann sum the precision at the top-ranked item = 0, and `average="macro"` then takes the plain
+    mean over num_labels - i.e. such labels COUNT as 0 (this is why the reference evaluates with
+    `only_represented_labels`, ProtNoteTrainer.py:469-472,517-519).  torcheval is absent here, so that reading is
+    **parity unpinned**; `empty_label_ap=None` gives the other convention (skip those labels)."""
+    a = np.asarray(per_label_ap, dtype=np.float64)
+    if empty_label_ap is None:
+        return float(np.nanmean(a))
+    return float(np.mean(np.where(np.isnan(a), float(empty_label_ap), a)))

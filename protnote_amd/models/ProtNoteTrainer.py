@@ -35,12 +35,14 @@ def calculate_f1_micro(total_tp_per_label, total_fn_per_label, total_fp_per_labe
 
 
 def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, threshold=0.5,
-               gradient_accumulation_steps=1, batch_idx=0):
+               gradient_accumulation_steps=1, batch_idx=0, is_last_batch=False):
     """One optimisation step: forward, loss, backward, (data-parallel gradient all-reduce), clip + Adam,
     per-label TP/FN/FP accumulation into `counts` ([3, N] f32) when given.  Returns the detached loss.
     GRADIENT_ACCUMULATION_STEPS (ProtNoteTrainer.py:732-755): the loss is divided by the number of accumulation steps,
     gradients add up in the flat buffer, and all-reduce + clip + Adam + zero_grad run on every
-    `gradient_accumulation_steps`-th batch (`batch_idx` counts from 0)."""
+    `gradient_accumulation_steps`-th batch (`batch_idx` counts from 0; the reference's counter is
+    `training_step = batch_idx + 1`, :687,741) and on the last batch of an epoch (`is_last_batch`, :741-743), so no
+    partial window leaks into the next epoch."""
     from ..utils.distributed import allreduce_gradients, broadcast_buffers
 
     if world_size > 1:
@@ -54,7 +56,7 @@ def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, t
     if gradient_accumulation_steps > 1:
         loss = loss / gradient_accumulation_steps
     loss.backward()
-    if (batch_idx + 1) % gradient_accumulation_steps == 0:
+    if (batch_idx + 1) % gradient_accumulation_steps == 0 or is_last_batch:
         if world_size > 1:
             allreduce_gradients(optimizer)
         optimizer.step()
@@ -72,53 +74,76 @@ class Trainer:
     """Minimal epoch driver around the fused step (reference ProtNoteTrainer.train_one_epoch :675-825 and
     evaluate :449-673, without W&B / checkpoint cadence / threshold search): per-batch train_step with the loss pass
     counting TP/FN/FP, ONE fused [3, N_L] all-reduce per epoch (the reference does three dist.reduce calls,
-    :637-639/:795-797), F1 macro/micro from the counts, and - for evaluation - mAP from the collected logits."""
+    :637-639/:795-797), F1 macro/micro from the counts, and - for evaluation - mAP from the collected logits.
+    The per-batch losses are summed on the device: no host synchronisation inside an epoch."""
 
     def __init__(self, model, loss_fn, optimizer=None, world_size=1, threshold=0.5, gradient_accumulation_steps=1):
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.world_size, self.threshold = world_size, threshold
         self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.training_step = 0  # global batch counter across epochs (reference :687,851)
+        if world_size > 1:  # what wrapping in DistributedDataParallel does (bin/main.py:452): start from rank 0's state
+            from ..utils.distributed import sync_initial_state
+
+            sync_initial_state(model, optimizer)
 
     def _metrics(self, counts, loss_sum, n_batches):
-        from ..utils.distributed import allreduce_counts
+        from ..utils.distributed import allreduce_counts, allreduce_mean_loss
 
         counts = allreduce_counts(counts)
         tp, fn, fp = counts[0], counts[1], counts[2]
-        return {"loss": loss_sum / max(n_batches, 1), "f1_macro": float(calculate_f1(tp, fn, fp).mean()),
+        # sync_and_compute(avg_loss) (:655,812): the mean over ALL ranks' batches, not the local one
+        loss = allreduce_mean_loss(float(loss_sum), n_batches, counts.device)
+        return {"loss": loss, "f1_macro": float(calculate_f1(tp, fn, fp).mean()),
                 "f1_micro": float(calculate_f1_micro(tp, fn, fp))}
 
     def train_one_epoch(self, loader):
         self.model.train()
-        counts, loss_sum, n = None, 0.0, 0
-        for batch in loader:
+        counts, loss_sum, n = None, None, 0
+        try:
+            n_total = len(loader)
+        except TypeError:
+            n_total = None
+        it = iter(loader)
+        batch = next(it, None)
+        while batch is not None:
+            nxt = next(it, None)  # look-ahead: the last batch of the epoch always steps (reference :741-743)
             if counts is None:
-                counts = torch.zeros(3, batch["label_multihots"].shape[1], dtype=torch.float32,
-                                     device=batch["label_multihots"].device)
-            loss_sum += float(train_step(self.model, self.loss_fn, self.optimizer, batch, world_size=self.world_size,
-                                         counts=counts, threshold=self.threshold,
-                                         gradient_accumulation_steps=self.gradient_accumulation_steps, batch_idx=n))
+                dev = batch["label_multihots"].device
+                counts = torch.zeros(3, batch["label_multihots"].shape[1], dtype=torch.float32, device=dev)
+                loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+            last = nxt is None or (n_total is not None and n + 1 == n_total)
+            loss = train_step(self.model, self.loss_fn, self.optimizer, batch, world_size=self.world_size,
+                              counts=counts, threshold=self.threshold,
+                              gradient_accumulation_steps=self.gradient_accumulation_steps,
+                              batch_idx=self.training_step, is_last_batch=last)
+            self.training_step += 1
+            loss_sum += loss.double()
             n += 1
+            batch = nxt
         return self._metrics(counts, loss_sum, n)
 
     @torch.no_grad()
     def evaluate(self, loader, with_map=True, estimate_map=False, map_thresholds=50):
         """`estimate_map` follows ESTIMATE_MAP (ProtNoteTrainer.py:477-489): False -> exact AUPRC, True -> binned
         AUPRC with `map_thresholds` thresholds; `with_map=False` is ESTIMATE_MAP: None.  Either way the scores never
-        leave the device (the reference moves every batch to the CPU, :540-543)."""
+        leave the device (the reference moves every batch to the CPU, :540-543).  Leaves the model in train mode, as
+        the reference does (:671)."""
         from ..utils.evaluation import DeviceAveragePrecision, DeviceBinnedAUPRC
 
         self.model.eval()
-        counts, loss_sum, n, ap = None, 0.0, 0, None
+        counts, loss_sum, n, ap = None, None, 0, None
         for batch in loader:
             y = batch["label_multihots"]
             if counts is None:
                 counts = torch.zeros(3, y.shape[1], dtype=torch.float32, device=y.device)
+                loss_sum = torch.zeros((), dtype=torch.float64, device=y.device)
             logits, _ = self.model(sequence_onehots=batch["sequence_onehots"],
                                    sequence_lengths=batch["sequence_lengths"],
                                    label_embeddings=batch["label_embeddings"])
             if hasattr(self.loss_fn, "metric_counts"):
                 self.loss_fn.metric_counts, self.loss_fn.decision_threshold = counts, self.threshold
-            loss_sum += float(self.loss_fn(logits, y))
+            loss_sum += self.loss_fn(logits, y).detach().double()
             n += 1
             if with_map:
                 if ap is None:
@@ -132,4 +157,5 @@ class Trainer:
         if ap is not None:
             m = ap.compute()
             out.update(map_micro=m["map_micro"], map_macro=m["map_macro"])
+        self.model.train()
         return out

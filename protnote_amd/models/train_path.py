@@ -60,6 +60,9 @@ class _HeadsTrainFn(torch.autograd.Function):
         st = L.stream_ptr()
         ctx.model = model
         ctx.param_list = params
+        # The saved activations live in ONE buffer per model (2 x 101 GB at the bench config: a second copy cannot
+        # exist), so a forward invalidates the previous forward's backward.  Stamp it; backward checks the stamp.
+        ctx.generation = model.__dict__["_pn_train_generation"] = model.__dict__.get("_pn_train_generation", 0) + 1
         B, NL = P_f.shape[0], L_f.shape[0]
         mp, lp = model._mlp_desc(model.W_p)
         ml, ll = model._mlp_desc(model.W_l)
@@ -101,6 +104,14 @@ class _HeadsTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
+        if model is None:
+            raise RuntimeError("protnote_amd: backward called twice on one train-mode forward (the saved activations "
+                               "are consumed in place; retain_graph is not supported)")
+        if model.__dict__.get("_pn_train_generation") != ctx.generation:
+            raise RuntimeError("protnote_amd: another train-mode forward ran on this model before this backward; the "
+                               "saved activations (one buffer per model) were overwritten.  Call backward() after "
+                               "each forward (gradient accumulation does exactly that), or run extra forwards under "
+                               "torch.no_grad() / model.eval()")
         lib = L.lib()
         st = L.stream_ptr()
         P_f, L_f, P_e, L_e = ctx.P_f, ctx.L_f, ctx.P_e, ctx.L_e

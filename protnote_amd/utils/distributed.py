@@ -1,8 +1,13 @@
 """Data-parallel plumbing for one-process-per-GPU runs over RCCL/xGMI (reference bin/main.py:192-200,452 and
 ProtNoteTrainer.py:637-639,795-797).  Proteins are sharded across ranks; labels, label embeddings, weights and
-Adam state are replicated; BatchNorm statistics stay per-rank (SYNC_BN False).  Collectives per step:
-ONE all-reduce(avg) of the flat gradient buffer and ONE broadcast of the flat BN-buffer block (DDP's
-broadcast_buffers); per epoch ONE all-reduce of the fused [3, N_L] TP/FN/FP block."""
+Adam state are replicated; BatchNorm statistics stay per-rank (SYNC_BN False).  Collectives:
+  * once, when the optimiser is attached: ONE broadcast of rank 0's flat parameter / Adam-moment / BN-buffer blocks
+    (what DistributedDataParallel does at construction, bin/main.py:452);
+  * per step: ONE all-reduce(avg) of the flat gradient buffer and ONE broadcast of the flat BN-buffer block (DDP's
+    broadcast_buffers);
+  * per epoch: ONE all-reduce of the fused [3, N_L] TP/FN/FP block and one of (loss sum, batch count).
+Every collective is timed with events on the stream it is issued on (`comm_stats()`), so a scaling run shows where
+the non-scaling part comes from."""
 import os
 
 import torch
@@ -26,41 +31,148 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def active() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def shard_batch(n_items: int, rank: int, world: int):
     """Rank-strided protein shard, as the reference samplers do (samplers.py:61,111)."""
     return list(range(rank, n_items, world))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# per-collective timing (device time between two events on the issuing stream; read by bench.py)
+# ---------------------------------------------------------------------------------------------------------------
+_stats = {}     # name -> [calls, bytes, [pending (e0, e1)], ms_done]
+_timing = False
+
+
+def comm_timing(on: bool) -> None:
+    """Switch event timing of the collectives on/off and clear what was recorded."""
+    global _timing
+    _timing = bool(on)
+    _stats.clear()
+
+
+class _Timed:
+    def __init__(self, name, tensor):
+        self.on = _timing and tensor.is_cuda
+        self.rec = _stats.setdefault(name, [0, 0, [], 0.0])
+        self.rec[0] += 1
+        self.rec[1] += tensor.numel() * tensor.element_size()
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            self.rec[2].append((self.e0, self.e1))
+        return False
+
+
+def comm_stats():
+    """{name: {"calls", "bytes", "ms"}} - synchronises the device to read the events."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    out = {}
+    for name, rec in _stats.items():
+        for e0, e1 in rec[2]:
+            rec[3] += e0.elapsed_time(e1)
+        rec[2] = []
+        out[name] = {"calls": rec[0], "bytes": rec[1], "ms": rec[3]}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# collectives
+# ---------------------------------------------------------------------------------------------------------------
 def _float_buffers(model):
     return [b for _, b in model.named_buffers() if b.is_floating_point()]
 
 
-def broadcast_buffers(model, src: int = 0):
-    """DDP broadcast_buffers equivalent: rank `src`'s BN running statistics replace everyone's, as ONE
-    flat broadcast."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    bufs = _float_buffers(model)
+def _int_buffers(model):
+    return [b for _, b in model.named_buffers() if not b.is_floating_point()]
+
+
+def _broadcast_list(bufs, src, name):
     if not bufs:
         return
-    flat = torch.cat([b.reshape(-1) for b in bufs])
-    dist.broadcast(flat, src=src)
-    off = 0
-    for b in bufs:
-        b.copy_(flat[off:off + b.numel()].view_as(b))
-        off += b.numel()
+    flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+    with _Timed(name, flat):
+        dist.broadcast(flat, src=src)
+    if dist.get_rank() != src:
+        with torch.no_grad():
+            torch._foreach_copy_(bufs, [c.view_as(b) for b, c in zip(bufs, flat.split([b.numel() for b in bufs]))])
+
+
+def broadcast_buffers(model, src: int = 0):
+    """DDP broadcast_buffers equivalent: rank `src`'s BN running statistics replace everyone's, as ONE flat
+    broadcast (one concat, one collective, one multi-tensor copy back on the receiving ranks)."""
+    if not active():
+        return
+    _broadcast_list(_float_buffers(model), src, "bn_buffer_broadcast")
+
+
+def sync_initial_state(model, optimizer=None, src: int = 0):
+    """What DistributedDataParallel does when it wraps the model (reference bin/main.py:452): every rank starts from
+    rank `src`'s parameters and buffers.  With a FusedClipAdam the flat weight / moment blocks and the step count
+    travel too, so resumed runs agree as well.  Without this, ranks that were seeded differently stay different
+    forever (gradients are averaged, parameters are not)."""
+    if not active():
+        return
+    if optimizer is not None and hasattr(optimizer, "flat_w"):
+        for name in ("flat_w", "flat_m", "flat_v"):
+            t = getattr(optimizer, name)
+            with _Timed("initial_state_broadcast", t):
+                dist.broadcast(t, src=src)
+        step = torch.tensor([optimizer.step_count], dtype=torch.int64, device=optimizer.flat_w.device)
+        dist.broadcast(step, src=src)
+        optimizer.step_count = int(step.item())
+        owned = {p.data_ptr() for p in optimizer.params}
+    else:
+        owned = set()
+    # frozen encoder etc.; the Parameters themselves (not .data) so their version counters move and caches keyed on
+    # them (the encoder's packed conv weights) refresh
+    rest = [p for p in model.parameters() if p.data_ptr() not in owned]
+    for dt in {t.dtype for t in rest}:
+        _broadcast_list([t for t in rest if t.dtype == dt], src, "initial_state_broadcast")
+    _broadcast_list(_float_buffers(model), src, "initial_state_broadcast")
+    _broadcast_list(_int_buffers(model), src, "initial_state_broadcast")
 
 
 def allreduce_gradients(optimizer):
-    """Average the flat gradient buffer of a FusedClipAdam across ranks (one RCCL all-reduce over xGMI)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    """Average the flat gradient buffer of a FusedClipAdam across ranks: ONE RCCL all-reduce over xGMI (the
+    averaging is the collective's own AVG reduction on RCCL; gloo has no AVG, so the 1/world scale is a second
+    pass there)."""
+    if not active():
         return
-    dist.all_reduce(optimizer.flat_g, op=dist.ReduceOp.SUM)
-    optimizer.flat_g.mul_(1.0 / dist.get_world_size())
+    g = optimizer.flat_g
+    if dist.get_backend() == "nccl":
+        with _Timed("grad_allreduce", g):
+            dist.all_reduce(g, op=dist.ReduceOp.AVG)
+    else:
+        with _Timed("grad_allreduce", g):
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.mul_(1.0 / dist.get_world_size())
 
 
 def allreduce_counts(counts):
     """counts: [3, N_L] f32 block of per-label TP/FN/FP (reference does three dist.reduce calls)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    if active():
+        with _Timed("counts_allreduce", counts):
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
+
+
+def allreduce_mean_loss(loss_sum: float, n_batches: int, device):
+    """sync_and_compute(avg_loss) of the reference (ProtNoteTrainer.py:655,812): the mean over every rank's batches."""
+    if not active():
+        return loss_sum / max(n_batches, 1)
+    t = torch.tensor([loss_sum, float(n_batches)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0] / t[1].clamp(min=1.0))

@@ -1,46 +1,24 @@
-"""Average-precision metrics for mAP parity checks (the arithmetic behind the reference's torcheval
-BinaryAUPRC / MultilabelAUPRC at ProtNoteTrainer.py:477-485 and torchmetrics AveragePrecision in
-utils/evaluation.py:148-169 - third-party there, restated here in numpy and cross-checked against
-sklearn.metrics.average_precision_score in tests/test_evaluation.py).
+"""Evaluation metrics on the device: the twins of the reference's torcheval BinaryAUPRC / MultilabelAUPRC and
+BinaryBinnedAUPRC / MultilabelBinnedAUPRC (ProtNoteTrainer.py:477-485).  Scores stay in HBM for the whole evaluation
+(no per-batch D2H as at ProtNoteTrainer.py:540-543); the arithmetic is in csrc/metrics.hip.  There is no host-side
+implementation in this package - the numpy restatement used to check the kernels lives in oracle/metrics_oracle.py
+(test infrastructure).
 
-Two implementations of the same definition:
-  * `DeviceAveragePrecision` / `DeviceBinnedAUPRC` - the product path: scores stay in HBM for the whole evaluation
-    (no per-batch D2H as at ProtNoteTrainer.py:540-543), metrics come from the HIP kernels in csrc/metrics.hip;
-  * `average_precision` / `map_micro` / `map_macro` - small numpy helpers for notebooks and host-side checks.
-"""
-import numpy as np
+Labels without a positive: their AP is 0/0.  `empty_label_ap` (default 0.0) is the value such a label contributes to the
+macro mean - torcheval's MultilabelAUPRC(average="macro") averages over ALL num_labels and scores an all-negative
+label 0 (its curve code replaces the NaN recalls by 1.0), which is why the reference masks unrepresented labels
+(`only_represented_labels`, ProtNoteTrainer.py:469-472,517-519).  torcheval is not installed here, so this convention
+is "parity unpinned"; pass `empty_label_ap=None` to leave those labels out of the mean instead.  `ap_per_label`
+always reports them as NaN."""
 import torch
 
 from .. import _lib
 
 
-def average_precision(scores, labels) -> float:
-    """AP = sum_n (R_n - R_{n-1}) P_n over the distinct score thresholds, descending (ties share a threshold)."""
-    scores = np.asarray(scores, dtype=np.float64).ravel()
-    labels = np.asarray(labels).ravel() > 0
-    npos = int(labels.sum())
-    if npos == 0:
-        return float("nan")
-    order = np.argsort(-scores, kind="mergesort")
-    s, y = scores[order], labels[order]
-    last_of_group = np.r_[s[1:] != s[:-1], True]
-    tp = np.cumsum(y)[last_of_group].astype(np.float64)
-    k = (np.flatnonzero(last_of_group) + 1).astype(np.float64)
-    precision, recall = tp / k, tp / npos
-    return float(np.sum(np.diff(np.r_[0.0, recall]) * precision))
-
-
-def map_micro(scores, labels) -> float:
-    """One AP over all (sequence, label) pairs (reference: BinaryAUPRC on flattened predictions)."""
-    return average_precision(scores, labels)
-
-
-def map_macro(scores, labels) -> float:
-    """Mean of per-label AP over labels that have at least one positive."""
-    scores, labels = np.asarray(scores), np.asarray(labels)
-    aps = [average_precision(scores[:, j], labels[:, j]) for j in range(scores.shape[1])]
-    aps = [a for a in aps if not np.isnan(a)]
-    return float(np.mean(aps)) if aps else float("nan")
+def _macro(ap: torch.Tensor, empty_label_ap) -> float:
+    if empty_label_ap is None:
+        return float(torch.nanmean(ap))
+    return float(torch.where(torch.isnan(ap), torch.full_like(ap, float(empty_label_ap)), ap).mean())
 
 
 _LABEL_KIND = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}
@@ -66,10 +44,11 @@ class DeviceAveragePrecision:
     update(scores [B, N_L] f32, labels [B, N_L]) transposes the batch into a label-major accumulator
     (4 + 1 bytes per pair: 16 GB for 100 k sequences x 32 k labels); compute() sorts every label's column
     (rocPRIM segmented radix sort) and evaluates AP = sum over distinct thresholds of (recall step) x precision in
-    f64.  Labels without a positive get NaN and are left out of the macro mean (`ap_per_label` has them)."""
+    f64.  Labels without a positive: NaN in `ap_per_label`, `empty_label_ap` in the macro mean (module docstring)."""
 
-    def __init__(self, num_labels: int, capacity: int, device, growable: bool = False):
+    def __init__(self, num_labels: int, capacity: int, device, growable: bool = False, empty_label_ap=0.0):
         _require_hip_device(device)
+        self.empty_label_ap = empty_label_ap
         self.num_labels, self.capacity, self.n, self.growable = int(num_labels), max(int(capacity), 1), 0, growable
         self.keys = torch.empty(self.num_labels, self.capacity, dtype=torch.int32, device=device)
         self.hits = torch.empty(self.num_labels, self.capacity, dtype=torch.uint8, device=device)
@@ -139,7 +118,7 @@ class DeviceAveragePrecision:
         _lib.check(L.pn_ap_compute(_lib.ptr(keys), _lib.ptr(hits), self.num_labels, n, cap, _lib.ptr(ap), _lib.ptr(npos),
                                    _lib.ptr(mic) if micro else None, _lib.ptr(mic_n) if micro else None,
                                    _lib.ptr(ws), nbytes, _lib.stream_ptr()))
-        out = {"ap_per_label": ap, "positives_per_label": npos, "map_macro": float(torch.nanmean(ap))}
+        out = {"ap_per_label": ap, "positives_per_label": npos, "map_macro": _macro(ap, self.empty_label_ap)}
         if micro:
             out["map_micro"] = float(mic)
         del ws
@@ -152,8 +131,9 @@ class DeviceBinnedAUPRC:
     `linspace(0, 1, T)`, a prediction counts at threshold t when `p >= t`.  State: two [(N_L+1), T+1] u64 histograms
     (the last row pools all labels); multi-GPU = one all-reduce of the histograms."""
 
-    def __init__(self, num_labels: int, device, threshold=50):
+    def __init__(self, num_labels: int, device, threshold=50, empty_label_ap=0.0):
         _require_hip_device(device)
+        self.empty_label_ap = empty_label_ap
         thr = torch.linspace(0, 1.0, threshold) if isinstance(threshold, int) else torch.as_tensor(threshold)
         self.thresholds = thr.float().to(device).contiguous()
         self.T, self.num_labels = int(self.thresholds.numel()), int(num_labels)
@@ -188,4 +168,4 @@ class DeviceBinnedAUPRC:
                                               _lib.ptr(npos), 1, _lib.stream_ptr()))
         per_label = out[:self.num_labels]
         return {"ap_per_label": per_label, "positives_per_label": npos[:self.num_labels],
-                "map_macro": float(torch.nanmean(per_label)), "map_micro": float(out[self.num_labels])}
+                "map_macro": _macro(per_label, self.empty_label_ap), "map_micro": float(out[self.num_labels])}

@@ -36,13 +36,24 @@ class FusedClipAdam:
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
-        off = 0
-        for p in self.params:  # re-attach views if something replaced them
+        for p, off in self._offsets():  # re-attach views if something replaced them
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+
+    def _offsets(self):
+        off = 0
+        for p in self.params:
+            yield p, off
             off += (p.numel() + 3) // 4 * 4
 
     def step(self):
+        for p, off in self._offsets():
+            # model.to() / .float() / load_state_dict(assign=True) replace p.data: the kernel would then update a
+            # buffer the model no longer reads.  Fail loudly instead of training a detached copy.
+            if p.data_ptr() != self.flat_w.data_ptr() + 4 * off:
+                raise RuntimeError("FusedClipAdam: a parameter no longer aliases the flat weight buffer (the model "
+                                   "was moved / cast / re-assigned after the optimiser was built); rebuild the "
+                                   "optimiser, or call repack()")
         self.step_count += 1
         ws = L.workspace(256, self.flat_w.device, "adam")
         max_norm = -1.0 if self.max_norm is None else float(self.max_norm)
@@ -52,5 +63,59 @@ class FusedClipAdam:
                                           float(self.weight_decay), self.step_count, L.ptr(self.last_grad_norm),
                                           L.ptr(ws), ws.numel(), L.stream_ptr()))
 
+    def repack(self):
+        """Re-adopt the parameters' current values (after the model was moved / re-assigned) as views of flat_w."""
+        with torch.no_grad():
+            for p, off in self._offsets():
+                view = self.flat_w[off:off + p.numel()].view_as(p)
+                if p.data_ptr() != view.data_ptr():
+                    view.copy_(p.data)
+                    p.data = view
+        self.zero_grad()
+
+    # ---- checkpoint interchange with torch.optim.Adam / AdamW (reference utils/models.py:304-321,366-367) ----
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.flat_m, "exp_avg_sq": self.flat_v}
+        """The layout torch.optim.Adam.state_dict() produces for the same parameter list (ids = position in the
+        list the optimiser was built from), so `optimizer_state_dict` of a checkpoint moves both ways between this
+        optimiser and the reference's Adam."""
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in enumerate(self._offsets()):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        if "param_groups" not in sd:  # round-1 flat layout {step, exp_avg, exp_avg_sq}
+            self.step_count = int(sd["step"])
+            self.flat_m.copy_(sd["exp_avg"])
+            self.flat_v.copy_(sd["exp_avg_sq"])
+            return
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError(f"optimizer state has {len(ids)} parameters, this optimiser {len(self.params)}")
+        g0 = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g0["lr"], tuple(g0["betas"]), g0["eps"]
+        self.weight_decay = g0.get("weight_decay", 0.0)
+        steps = set()
+        with torch.no_grad():
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            for pid, (p, off) in zip(ids, self._offsets()):
+                st = sd["state"].get(pid)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {pid}: shape {tuple(st['exp_avg'].shape)} vs {tuple(p.shape)}")
+                n = p.numel()
+                self.flat_m[off:off + n].view_as(p).copy_(st["exp_avg"])
+                self.flat_v[off:off + n].view_as(p).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused step keeps one count")
+        self.step_count = steps.pop() if steps else 0

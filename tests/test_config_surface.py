@@ -84,3 +84,26 @@ def test_build_training_rejects_unknown_optimizer():
     cfg["params"].update(OPTIMIZER="SGD", FOCAL_LOSS_GAMMA=2, FOCAL_LOSS_ALPHA=-1, LABEL_SMOOTHING=0.0)
     with pytest.raises(NotImplementedError, match="OPTIMIZER=SGD"):
         CF.build_training(cfg, model=None)
+
+
+REAL_CONFIG = "/root/reference/configs/base_config.yaml"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REAL_CONFIG),
+                    reason="the reference checkout only exists in the build container")
+def test_real_base_config_builds_and_embedded_copy_agrees():
+    """The reference's own configs/base_config.yaml (read in place - never copied into the repo): every key the
+    embedded test config above uses exists there with the same value, `--override` works on it, and
+    build_models / build_training accept it unmodified."""
+    import copy
+
+    real = CF.load_config(REAL_CONFIG)
+    for section in ("params", "embed_sequences_params"):
+        for k, v in CFG[section].items():
+            assert k in real[section], (section, k)
+            assert real[section][k] == v, (section, k, real[section][k], v)
+    cfg = CF.override_config(copy.deepcopy(real), ["PROTEINFER_NUM_GO_LABELS", "8", "LOSS_FN", "BCE"])
+    enc, model = CF.build_models(cfg)
+    assert sum(p.numel() for p in model.W_p.parameters()) == 25_417_728
+    assert model.feature_fusion == real["params"]["FEATURE_FUSION"]
+    assert model.label_embedding_noising_alpha == real["params"]["LABEL_EMBEDDING_NOISING_ALPHA"]

@@ -36,7 +36,33 @@ def _worker(rank, world, port, q):
     counts = torch.full((3, 7), float(rank + 1))
     D.allreduce_counts(counts)
     shard = D.shard_batch(11, rank, world)
-    q.put((rank, Opt.flat_g.clone(), model[1].running_mean.clone(), model[1].running_var.clone(), counts, shard))
+
+    # DDP-construction semantics: differently seeded ranks end up with rank 0's parameters, Adam state and buffers
+    torch.manual_seed(100 + rank)
+    m2 = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.BatchNorm1d(5))
+    with torch.no_grad():
+        m2[1].running_mean.fill_(float(rank))
+        m2[1].num_batches_tracked.fill_(7 * (rank + 1))
+
+    class Opt2:  # the flat blocks of a FusedClipAdam over m2[0]'s weight
+        params = [m2[0].weight]
+        flat_w = torch.full((15,), float(rank + 1))
+        flat_m = torch.full((15,), 10.0 * (rank + 1))
+        flat_v = torch.full((15,), 100.0 * (rank + 1))
+        step_count = 3 * (rank + 1)
+
+    m2[0].weight.data = Opt2.flat_w.view(5, 3)
+    v0 = m2[0].bias._version
+    D.sync_initial_state(m2, Opt2)
+    mean_loss = D.allreduce_mean_loss(2.0 * (rank + 1), rank + 1, torch.device("cpu"))
+    state = (m2[0].weight.detach().clone(), m2[0].bias.detach().clone(), m2[1].running_mean.clone(),
+             int(m2[1].num_batches_tracked), Opt2.flat_m.clone(), Opt2.flat_v.clone(), Opt2.step_count, mean_loss,
+             m2[0].bias._version > v0 or rank == 0)
+    import pickle
+
+    # by value: tensors handed to an mp queue travel as shared-memory handles that die with this process
+    q.put(pickle.dumps((rank, Opt.flat_g.clone(), model[1].running_mean.clone(), model[1].running_var.clone(), counts,
+                        shard, state)))
     torch.distributed.destroy_process_group()
 
 
@@ -48,16 +74,53 @@ def test_two_rank_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    import pickle
+
+    res = sorted((pickle.loads(q.get(timeout=120)) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     want_g = torch.arange(10, dtype=torch.float32) * 1.5  # mean of x*1 and x*2
     seen = []
-    for rank, g, rm, rv, counts, shard in res:
+    for rank, g, rm, rv, counts, shard, _ in res:
         assert torch.allclose(g, want_g)
         assert torch.all(rm == 1.0) and torch.all(rv == 10.0)  # rank 0's buffers everywhere
         assert torch.all(counts == 3.0)
         seen += shard
     assert sorted(seen) == list(range(11))  # shards partition the batch
     assert res[0][5] == [0, 2, 4, 6, 8, 10] and res[1][5] == [1, 3, 5, 7, 9]
+    # sync_initial_state: everything equals rank 0's; the mean loss is over all ranks' batches ((2 + 4) / (1 + 2))
+    s0, s1 = res[0][6], res[1][6]
+    for a, b in zip(s0[:3], s1[:3]):
+        assert torch.equal(a, b)
+    assert torch.all(s1[0] == 1.0) and torch.all(s1[2] == 0.0)
+    assert s0[3] == s1[3] == 7 and torch.all(s1[4] == 10.0) and torch.all(s1[5] == 100.0) and s0[6] == s1[6] == 3
+    assert abs(s0[7] - 2.0) < 1e-12 and abs(s1[7] - 2.0) < 1e-12
+    assert s1[8], "in-place sync must bump the parameter version (packed-weight caches key on it)"
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment re-executes itself under torch.distributed.run with N
+    ranks on 127.0.0.1 (it used to run ONE rank and report n_gpus: 1)."""
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

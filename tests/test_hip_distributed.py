@@ -30,9 +30,13 @@ def _data():
     return torch.sigmoid(logits).float(), y
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), PN_SHARE_GPU="1", PN_DIST_BACKEND="gloo")
+                      MASTER_PORT=str(port), PN_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        os.environ["PN_SHARE_GPU"] = "1"  # both ranks on device 0, gloo moves the device buffers
+    else:
+        os.environ.pop("PN_SHARE_GPU", None)  # one GPU per rank, RCCL over xGMI
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,7 +49,8 @@ def _worker(rank, world, port, q):
     from tests.helpers import make_protnote
 
     r, _, w = D.init_from_env()
-    dev = "cuda:0"
+    assert torch.distributed.get_backend() == backend
+    dev = f"cuda:{torch.cuda.current_device()}"
     # ---- metrics: each rank holds a strided shard of the proteins
     p, y = _data()
     idx = D.shard_batch(p.shape[0], r, w)
@@ -68,24 +73,35 @@ def _worker(rank, world, port, q):
              "label_embeddings": torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(dev),
              "label_multihots": yy[rows].to(dev)}
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
-    with torch.no_grad():  # make the ranks' BN buffers differ: the step must start from rank 0's
+    with torch.no_grad():  # make the ranks' weights, Adam moments and BN buffers differ: DDP-construction semantics
+        opt.flat_w.mul_(1.0 + 0.05 * r)  # (sync_initial_state) must bring everyone to rank 0's before the step
+        opt.flat_m.add_(0.5 * r)
         for b in model.buffers():
             if b.is_floating_point():
                 b.add_(0.01 * r)
+    w_rank0 = opt.flat_w.clone() if r == 0 else None
+    D.sync_initial_state(model, opt)
+    if r == 0:
+        assert torch.equal(opt.flat_w, w_rank0)
+    D.comm_timing(True)
     train_step(model, loss_fn, opt, batch, world_size=w)
+    comm = D.comm_stats()
+    assert comm["grad_allreduce"]["calls"] == 1 and comm["bn_buffer_broadcast"]["calls"] == 1
+    assert comm["grad_allreduce"]["bytes"] == opt.flat_g.numel() * 4
     q.put((r, m_ap["map_micro"], m_ap["map_macro"], m_ap["ap_per_label"].cpu().numpy(), m_bn["map_micro"],
-           m_bn["map_macro"], opt.flat_w.cpu().numpy()))
+           m_bn["map_macro"], opt.flat_w.cpu().numpy(), float(opt.last_grad_norm.item())))
+    torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu():
+def _run_two_ranks(backend):
     from oracle import metrics_oracle as MO
 
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
@@ -97,12 +113,57 @@ def test_two_ranks_share_one_gpu():
     micro = MO.average_precision_fast(p.numpy().ravel(), y.numpy().ravel())
     thr = torch.linspace(0, 1.0, 50).numpy()
     bmicro = MO.binned_auprc(p.numpy().ravel(), y.numpy().ravel(), thr)
-    bmacro = np.nanmean([MO.binned_auprc(p[:, j].numpy(), y[:, j].numpy(), thr) for j in range(p.shape[1])])
-    for _, mi, ma, apl, bmi, bma, _w in res:  # every rank reports the metric of the WHOLE evaluation set
+    bmacro = MO.macro_mean([MO.binned_auprc(p[:, j].numpy(), y[:, j].numpy(), thr) for j in range(p.shape[1])])
+    for _, mi, ma, apl, bmi, bma, _w, _gn in res:  # every rank reports the metric of the WHOLE evaluation set
         np.testing.assert_allclose(mi, micro, rtol=1e-12)
-        np.testing.assert_allclose(ma, np.nanmean(per), rtol=1e-12)
+        np.testing.assert_allclose(ma, MO.macro_mean(per), rtol=1e-12)
         np.testing.assert_allclose(apl, per, rtol=1e-12)
         np.testing.assert_allclose(bmi, bmicro, rtol=1e-12)
         np.testing.assert_allclose(bma, bmacro, rtol=1e-12)
     # averaged gradients + identical start => identical parameters on both ranks after the step
     np.testing.assert_array_equal(res[0][6], res[1][6])
+    assert res[0][7] == res[1][7] and np.isfinite(res[0][7])  # same averaged gradient -> same clip norm
+    return res
+
+
+def test_two_ranks_share_one_gpu():
+    """1-GPU fallback of the data-parallel test: both ranks on device 0, gloo as the transport."""
+    _run_two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (RCCL over xGMI)")
+def test_two_ranks_rccl():
+    """The same data-parallel step and cross-rank metrics with one GPU per rank over RCCL (backend "nccl"), as
+    bin/main.py:192-200,452 runs the reference.  The result must agree with the gloo transport: the all-reduce
+    averages the same two gradient blocks either way."""
+    res = _run_two_ranks("nccl")
+    ref = _run_two_ranks("gloo")
+    np.testing.assert_allclose(res[0][6], ref[0][6], rtol=0, atol=1e-6)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment must run two ranks and say so (n_gpus: 2, dp2, comm
+    block).  With >= 2 GPUs this is the real RCCL path; on a 1-GPU box both ranks share device 0 over gloo (dry run of
+    the same code: launch, rendezvous, initial-state broadcast, per-step collectives, max-over-ranks timing)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env.update(PN_SHARE_GPU="1", PN_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "16", "--seq-len", "64", "--labels", "512", "--no-cpu-baseline",
+                          "--zero-shot-seqs", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 32
+    assert j["comm"]["rccl_ranks"] == 2 and j["comm"]["backend"] == ("nccl" if two else "gloo")
+    c = j["comm"]["collectives_rank0"]
+    assert c["grad_allreduce"]["calls_per_step"] == 1 and c["bn_buffer_broadcast"]["calls_per_step"] == 1
+    assert j["value"] > 0 and j["forward_only"]["f32"]["value"] > 0
+    assert all(v["value"] > 0 for v in j["zero_shot"]["f32"].values())

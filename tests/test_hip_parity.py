@@ -193,6 +193,69 @@ def test_zero_shot_bucketed_padding_and_label_swap():
     assert ec_out.shape == (6, 11) and (ec_out - ref_ec).abs().max().item() < 5e-4
 
 
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
+def test_zero_shot_full_width_vs_oracle(math_mode):
+    """BASELINE configs[4] at the REAL model width (base_config.yaml: C=1100 / 5 blocks / dil 3^i, d=1024, h=3072,
+    4-layer projections, 3-layer output MLP): sequences of length 2048 / 1500 / 129 / 5 padded to 2048 and to their
+    length buckets, a GO-sized-shaped table of 64 labels x 2 descriptions ensembled (ProtNote.py:308-322), then an
+    EC-shaped table swapped in on the same model object (bin/test_models.py:14-23) - against the CPU oracle's naive
+    formulation.  Tolerance: 5e-4 absolute on O(1) logits (north-star bound 1e-3), in both arithmetic modes."""
+    import protnote_amd
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.protein_encoders import ProteInfer
+
+    gen = torch.Generator().manual_seed(21)
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+                num_resnet_blocks=5, bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
+    enc = ProteInfer(activation=torch.nn.ReLU, **ecfg)
+    model = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024, sequence_encoder=enc,
+                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, inference_descriptions_per_label=2)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    lens = torch.tensor([2048, 1500, 129, 5])
+    ids = torch.randint(0, 20, (len(lens), 2048), generator=gen)
+    go = torch.randn(2 * 64, 1024, generator=gen)
+    ec = torch.randn(2 * 21, 1024, generator=gen)
+    onehots = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float()
+    for b, n in enumerate(lens):
+        onehots[b, :, n:] = 0
+    # the random head gives logits of mean -19 / std 8 (everything saturates in the ensembling's logit(eps=1e-7)):
+    # rescale the output neuron so that the raw logits are ~N(0, 1.5^2) and the tolerance below means something
+    raw = O.protnote_forward({k: v.clone() for k, v in sd.items()}, onehots, lens, go, descriptions_per_label=1)
+    alpha = 1.5 / raw.std().item()
+    sd["output_layer.11.bias"] = alpha * (sd["output_layer.11.bias"] - raw.mean())
+    sd["output_layer.11.weight"] = alpha * sd["output_layer.11.weight"]
+    model.load_state_dict(sd)
+    osd = {k: v.clone() for k, v in sd.items()}
+    ref_go = O.protnote_forward(osd, onehots, lens, go, descriptions_per_label=2)
+    ref_ec = O.protnote_forward(osd, onehots, lens, ec, descriptions_per_label=2)
+    assert 1.0 < ref_go.abs().max().item() < 9.0 and ref_go.shape == (4, 64) and ref_ec.shape == (4, 21)
+
+    def run(rows, lmax, labels):
+        x = onehots[rows][:, :, :lmax].contiguous()
+        with torch.no_grad():
+            out, _ = model(sequence_onehots=x.to(DEV), sequence_lengths=lens[rows].to(DEV),
+                           label_embeddings=labels.to(DEV))
+        return out.cpu()
+
+    protnote_amd.set_math_mode(math_mode)
+    try:
+        full = run(torch.arange(4), 2048, go)
+        err = (full - ref_go).abs().max().item()
+        assert err < 5e-4, err
+        for lmax, rows in {2048: [0, 1], 256: [2], 128: [3]}.items():  # bucketed padding: same logits
+            part = run(torch.tensor(rows), lmax, go)
+            assert (part - ref_go[rows]).abs().max().item() < 5e-4, lmax
+            assert (part - full[rows]).abs().max().item() < (2e-5 if math_mode == "f32" else 2e-4), lmax
+        ec_out = run(torch.arange(4), 2048, ec)  # runtime label-table swap, no model re-creation
+        assert ec_out.shape == (4, 21) and (ec_out - ref_ec).abs().max().item() < 5e-4
+    finally:
+        protnote_amd.set_math_mode("f32")
+
+
 @pytest.mark.parametrize("fusion", ["concatenation_diff", "concatenation_prod"])
 def test_pairhead_eval_fusion_variants_real_width(fusion):
     """3d-wide first layer (P, L, P-L | P.L) at d=1024 / h=3072 against the oracle's materialised joint tensor."""
@@ -246,7 +309,7 @@ def test_map_parity_full_width():
     mi, ma = m["map_micro"], m["map_macro"]
     pr = torch.sigmoid(ref).numpy()
     mi_ref = MO.average_precision_fast(pr.ravel(), y.ravel())
-    ma_ref = float(np.nanmean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)]))
+    ma_ref = MO.macro_mean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)])
     assert 0.2 < mi_ref < 0.99
     assert abs(mi - mi_ref) < 1e-4 and abs(ma - ma_ref) < 1e-4, (mi, mi_ref, ma, ma_ref)
 
