@@ -121,6 +121,14 @@ int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P_e, const f
 int pn_additive_attention(const float* hidden, const int64_t* attention_mask, const float* w, const float* b, int N,
                           int T, int d, float* out, void* stream);
 
+/* Backward of the pooling wrt raw_attn_scorer (training with LABEL_EMBEDDING_POOLING_METHOD: all; autograd of
+ * ProtNote.py:154-166 with frozen token embeddings): dout [N][d] = gradient wrt the pooled embeddings;
+ * dw [d], db [1] are written.  Per-label partials + fixed-order reduction (bit-reproducible). */
+size_t pn_additive_attention_bwd_ws_bytes(int N, int d);
+int pn_additive_attention_bwd(const float* hidden, const int64_t* attention_mask, const float* w, const float* b,
+                              const float* dout, int N, int T, int d, float* dw, float* db, void* ws, size_t ws_bytes,
+                              void* stream);
+
 /* ProtNote.py:308-322: pair logits for NL = n_out*ndesc description rows (consecutive rows = one label)
  * -> out[B][n_out];  ndesc == 1: plain re-layout;  else logit(mean_d sigmoid(x), eps=1e-7).
  * protein_major = 0: input is the label-major pair grid x[j*B + i]; 1: input is x[i*NL + j]. */
@@ -207,7 +215,9 @@ int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int NL, int d, 
  * (losses.py:124-146: positives and negatives of the batch weigh total/2 each); 2 = WeightedBCE / CBLoss
  * (losses.py:78-121, 214-241: row i weighs sum_j label_weights[j] * target[i][j]; label_weights [N] on the device).
  * rgd_temperature >= 0: RGDBCE (losses.py:58-75: mean loss m times exp(min(m, T) / (T + 1)), factor detached).
- * ws: >= 512 + 4*B bytes. */
+ * ws: >= pn_loss_ws_bytes(B, N) (row weights + one f64 loss partial per workgroup: the mean is summed in a fixed
+ * order, no floating-point atomics - the whole train step is bit-reproducible run to run). */
+size_t pn_loss_ws_bytes(int B, int N);
 int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B, int N,
                     int kind, float pos_weight, float gamma, float alpha, float smoothing, float threshold,
                     float* loss_out, float* dlogits, float* tp, float* fn, float* fp, int weight_mode,
@@ -218,7 +228,9 @@ int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* tar
                 float threshold, float* tp, float* fn, float* fp, void* stream);
 
 /* clip_grad_norm_(max_norm) + Adam / AdamW step on flat f32 buffers (ProtNoteTrainer.py:745-755);
- * max_norm <= 0 disables clipping; norm_out (optional, [1]) receives the total gradient norm. */
+ * max_norm <= 0 disables clipping; norm_out (optional, [1]) receives the total gradient norm.
+ * ws: >= PN_ADAM_WS_BYTES (per-workgroup partials of the squared norm, added in a fixed order). */
+#define PN_ADAM_WS_BYTES 32768
 int pn_clip_adam_step(float* w, const float* g, float* m, float* v, long n, float max_norm, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, float* norm_out, void* ws,
                       size_t ws_bytes, void* stream);
@@ -283,10 +295,14 @@ int pn_get_math_mode(void);
 int pn_prof_begin(void);
 int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops);
 
-/* ---- generic f32-MFMA GEMM (unit tests / building block): C[M][N] = relu?(A*s+t)[M][K] W[N][K]^T + bias */
+/* ---- generic f32-MFMA GEMM (unit tests / building block): C[M][N] = relu?(A*s+t)[M][K] W[N][K]^T + bias.
+ * col_sum / col_sumsq (optional, [N] f64): per-column sum and sum of squares of the stored values, WRITTEN (not
+ * accumulated); they need ws >= pn_gemm_nt_stats_ws_bytes(M, N): every workgroup stores its column partials in its
+ * own slot and a fixed-order reduction adds them (train-mode BatchNorm statistics without atomics). */
+size_t pn_gemm_nt_stats_ws_bytes(int M, int N);
 int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K,
                const float* bias, const float* a_scale, const float* a_shift, double* col_sum,
-               double* col_sumsq, int tile_variant, void* stream);
+               double* col_sumsq, int tile_variant, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

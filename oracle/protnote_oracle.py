@@ -141,17 +141,29 @@ def noised_label_embeddings(L_f: Tensor, alpha: float, u: Tensor) -> Tensor:
     return L_f + (2 * u - 1) * (alpha / math.sqrt(L_f.shape[1]))
 
 
+def additive_attention(sd: SD, hidden_states: Tensor, attention_mask: Tensor) -> Tensor:
+    """ProtNote.additive_attention (ProtNote.py:154-166): masked-softmax pooling of token embeddings [N, T, d] with
+    the raw_attn_scorer Linear(d, 1)."""
+    raw = F.linear(hidden_states, sd["raw_attn_scorer.weight"], sd["raw_attn_scorer.bias"]).squeeze(-1)
+    raw = raw.masked_fill(attention_mask == 0, float("-inf"))
+    return torch.bmm(torch.softmax(raw, dim=-1).unsqueeze(1), hidden_states).squeeze(1)
+
+
 def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], label_embeddings: Tensor,
                      *, fusion: str = "concatenation", training: bool = False, temperature: float = 0.07,
                      descriptions_per_label: int = 1, noise_alpha: float = 0.0,
                      noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
                      dilation_base: int = 3, sequence_embeddings: Optional[Tensor] = None,
-                     aux: Optional[dict] = None, train_sequence_encoder: bool = False) -> Tensor:
+                     aux: Optional[dict] = None, train_sequence_encoder: bool = False,
+                     attention_mask: Optional[Tensor] = None) -> Tensor:
     """ProtNote.forward (ProtNote.py:168-334), cached-label-embedding path; the encoder runs under no_grad unless
-    train_sequence_encoder and training (ProtNote.py:248-260)."""
+    train_sequence_encoder and training (ProtNote.py:248-260).  `attention_mask` given = LABEL_EMBEDDING_POOLING_METHOD
+    'all': label_embeddings are token embeddings [N, T, d], pooled AFTER the noise (ProtNote.py:266-267)."""
     L_f = label_embeddings
     if training and label_token_counts is not None and noise_alpha > 0:
         L_f = noised_label_embeddings(L_f, noise_alpha, noise_u)
+    if attention_mask is not None:
+        L_f = additive_attention(sd, L_f, attention_mask)
     if sequence_embeddings is not None:
         P_f = sequence_embeddings
     elif train_sequence_encoder and training:
@@ -276,7 +288,8 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
                clip: Optional[float] = 1.0, lr: float = 3e-4, dilation_base: int = 3,
                adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
-               train_sequence_encoder: bool = False, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+               train_sequence_encoder: bool = False, attention_mask: Optional[Tensor] = None,
+               **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
     """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU).
 
     Updates `sd` in place (params by Adam, BN buffers by the train-mode forward).
@@ -288,7 +301,7 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
     logits = protnote_forward(work, onehots, lens, label_embeddings, fusion=fusion, training=True,
                               noise_alpha=noise_alpha, noise_u=noise_u, temperature=temperature,
                               label_token_counts=label_token_counts, dilation_base=dilation_base,
-                              train_sequence_encoder=train_sequence_encoder)
+                              train_sequence_encoder=train_sequence_encoder, attention_mask=attention_mask)
     y = multihots.float()
     l = bce_loss(logits, y, **loss_kw) if loss == "BCE" else focal_loss(logits, y, **loss_kw)
     grads_t = torch.autograd.grad(l, [leaves[k] for k in names], allow_unused=True)

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libprotnote_hip.so")
 
 PN_MAX_BLOCKS = 16
 PN_MAX_LAYERS = 8
+PN_ADAM_WS_BYTES = 32768
 fp = C.POINTER(C.c_float)
 
 
@@ -83,6 +84,9 @@ _SIGS = {
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_additive_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
+    "pn_additive_attention_bwd_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pn_additive_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_ensemble_logit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_label_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -143,7 +147,9 @@ _SIGS = {
                               C.POINTER(C.c_double)]),
     "pn_gemm_nt": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                             C.c_void_p]),
+                             C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_gemm_nt_stats_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pn_loss_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
 }
 
 

@@ -63,8 +63,10 @@ struct GemmParams {
   const float* bias;     // [N] or null
   const float* resid;    // E_CONV: residual added on valid rows, or null
   long ldr;
-  double* col_sum;       // optional per-column sum / sum of squares of the stored values (train-mode BN)
-  double* col_sumsq;
+  double* col_sum;       // optional per-column sum / sum of squares of the stored values (train-mode BN): written
+  double* col_sumsq;     // (not accumulated) by the launcher from the per-row-tile partials below, in a fixed order
+  float* col_part;       // [row tiles][2][N] f32 partials, one slot per workgroup - no atomics, bit-reproducible
+  double* col_red;       // [64][2][N] scratch of the two-level reduction
   const float* e_scale;  // E_ROWDOT: sum_n relu(acc*e_scale[n]+e_shift[n]) * e_w[n]
   const float* e_shift;
   const float* e_w;
@@ -134,12 +136,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   const int wn = wave % WAVES_N;
   const int hl = lane >> 5;  // which 4-row group of each 8
   const int cl = lane & 31;
-  const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_sum != nullptr);
-  float* red = smem;  // [2][BN] column partials (LDS is free after the final barrier)
-  if (want_stats) {
-    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.f;
-    __syncthreads();
-  }
+  const bool want_stats = (EK == E_STORE || EK == E_CONV || EK == E_PAIRADD) && (p.col_part != nullptr);
+  // [WAVES_M][2][BN] column partials, one slot per (wave row, column): plain stores, summed in wave-row order below
+  float* red = smem;  // (LDS is free after the final barrier of the main loop)
 
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -207,19 +206,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (hl == 0) {
-        atomicAdd(&red[(wn * WN + j) * 32 + cl], s1);
-        atomicAdd(&red[BN + (wn * WN + j) * 32 + cl], s2);
+        red[(wm * 2 + 0) * BN + (wn * WN + j) * 32 + cl] = s1;
+        red[(wm * 2 + 1) * BN + (wn * WN + j) * 32 + cl] = s2;
       }
     }
   }
   if (want_stats) {
     __syncthreads();
-    for (int i = tid; i < BN; i += NT) {
-      const int col = col0 + i;
-      if (col < p.N) {
-        atomicAdd(&p.col_sum[col], (double)red[i]);
-        atomicAdd(&p.col_sumsq[col], (double)red[BN + i]);
-      }
+    const long tile_m = row0 / (WAVES_M * WM * 32);
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int which = i / BN, c = i - which * BN;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) a += red[(w * 2 + which) * BN + c];
+      const int col = col0 + c;
+      if (col < p.N) p.col_part[(tile_m * 2 + which) * p.N + col] = a;
     }
   }
   if constexpr (EK == E_ROWDOT) {

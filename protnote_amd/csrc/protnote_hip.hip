@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "gemm_engine.hpp"
 #include "gemm_bf16x3.hpp"
+#include "train_kernels.hpp"
 
 using namespace pn;
 
@@ -140,6 +141,53 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------
+// fixed-order reduction of per-workgroup partials (train_kernels.hpp): no floating-point atomics anywhere
+// ------------------------------------------------------------------------------------------------
+static inline unsigned nblk(long n, int t) { return (unsigned)((n + t - 1) / t); }
+static const int RED_CHUNKS = 64;
+
+template <class T>
+static int reduce_parts(const T* part, long nparts, int width, int seg, double* d0, double* d1, double* d2,
+                        double* red /* [RED_CHUNKS][width] */, hipStream_t st) {
+  if (nparts <= 0) return fail("reduce_parts: no partials");
+  long per = (nparts + RED_CHUNKS - 1) / RED_CHUNKS;
+  const int nchunk = (int)((nparts + per - 1) / per);
+  hipLaunchKernelGGL((k_part_reduce<T>), dim3(nblk(width, 256), nchunk), dim3(256), 0, st, part, nparts, width, per, red);
+  hipLaunchKernelGGL(k_part_final, dim3(nblk(width, 256)), dim3(256), 0, st, (const double*)red, nchunk, width, seg, d0,
+                     d1, d2);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// scratch of the column statistics a GEMM epilogue produces (GemmParams::col_part / col_red)
+struct ColScr {
+  float* part;
+  double* red;
+};
+static bool colscr_carve(Bump& bp, long M, int N, ColScr& c) {
+  c.part = bp.take<float>((size_t)((M + 127) / 128) * 2 * (size_t)N);  // smallest row tile is 128
+  c.red = bp.take<double>((size_t)RED_CHUNKS * 2 * (size_t)N);
+  return bp.ok;
+}
+// scratch of k_bn_bwd_stats / k_colsum: [row chunks][3][C] partials + the level-1 output
+struct StatScr {
+  double* part;
+  double* red;
+};
+static bool statscr_carve(Bump& bp, long R, long rows_per_block, int C, StatScr& s) {
+  s.part = bp.take<double>((size_t)((R + rows_per_block - 1) / rows_per_block) * 3 * (size_t)C);
+  s.red = bp.take<double>((size_t)RED_CHUNKS * 3 * (size_t)C);
+  return bp.ok;
+}
+
+// column sum / sum of squares of what the GEMM just stored, from its per-row-tile partials
+static int finish_col_stats(const GemmParams& p, long tm, hipStream_t st) {
+  if (p.col_sum == nullptr) return 0;
+  if (p.col_part == nullptr || p.col_red == nullptr) return fail("gemm: column statistics need col_part / col_red scratch");
+  return reduce_parts<float>(p.col_part, tm, 2 * p.N, p.N, p.col_sum, p.col_sumsq, nullptr, p.col_red, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // GEMM launch
 // ------------------------------------------------------------------------------------------------
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
@@ -179,7 +227,7 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
-  return 0;
+  return finish_col_stats(p, tm, st);
 }
 
 // Arithmetic of the pair-grid GEMMs: 0 = exact f32 MFMA (default), 1 = bf16x3 split (gemm_bf16x3.hpp).
@@ -224,7 +272,7 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
-  return 0;
+  return finish_col_stats(p, tm, st);
 }
 
 static int rowdot_nparts(int n);
@@ -449,8 +497,6 @@ __global__ void k_rownorm_inv(const float* __restrict__ x, long ld, int rows, in
   if (lane == 0) out[r] = 1.f / fmaxf(sqrtf(a), 1e-12f);
 }
 
-static inline unsigned nblk(long n, int t) { return (unsigned)((n + t - 1) / t); }
-
 // ------------------------------------------------------------------------------------------------
 // encoder
 // ------------------------------------------------------------------------------------------------
@@ -467,6 +513,7 @@ struct EncWs {
   int* lens32;
   float *x0, *xa, *xb, *z, *s1, *t1, *s2, *t2;
   double *sum_x, *sq_x, *sum_z, *sq_z;
+  ColScr cs;  // per-tile partials of the train-mode BatchNorm statistics
 };
 
 static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
@@ -485,6 +532,7 @@ static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
   w.sq_x = w.sum_x ? w.sum_x + ldc : nullptr;
   w.sum_z = bp.take<double>(2 * (size_t)ldb);
   w.sq_z = w.sum_z ? w.sum_z + ldb : nullptr;
+  colscr_carve(bp, P, ldc, w.cs);
   return bp.ok;
 }
 
@@ -550,6 +598,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     p.A = in; p.lda = ld_in; p.a_scale = s; p.a_shift = t; p.lens = lens32; p.L = L; p.dil = dil;
     p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.bias = bias; p.resid = resid; p.ldr = ld_out;
     p.col_sum = csum; p.col_sumsq = csq;
+    if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
     const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
     return launch_gemm<A_CONV, E_CONV>(p, big ? 3 : pick_variant(ld_out), st);
   };
@@ -557,7 +606,6 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   // conv1: MaskedConv1D(Cin -> C, k, dil 1), no BN/ReLU in front (protein_encoders.py:84-91,110)
   float* x = sv ? sv->X[0] : w.xa;
   float* xn = w.xb;
-  if (training) HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
   PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
              training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
 
@@ -575,7 +623,6 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const double*)w.sum_x,
                          (const double*)w.sq_x, (double)P, bn_eps, bn_mom, e->C, ldc, s1, t1,
                          sv ? sv->m1[i] : (float*)nullptr, sv ? sv->i1[i] : (float*)nullptr);
-      HIP_OK(hipMemsetAsync(w.sum_z, 0, 2 * (size_t)ldb * sizeof(double), st));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const float*)nullptr,
                          bn_eps, e->C, ldc, s1, t1);
@@ -586,7 +633,6 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const double*)w.sum_z,
                          (const double*)w.sq_z, (double)P, bn_eps, bn_mom, e->Cb, ldb, s2, t2,
                          sv ? sv->m2[i] : (float*)nullptr, sv ? sv->i2[i] : (float*)nullptr);
-      HIP_OK(hipMemsetAsync(w.sum_x, 0, 2 * (size_t)ldc * sizeof(double), st));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const float*)nullptr,
                          bn_eps, e->Cb, ldb, s2, t2);
@@ -886,14 +932,27 @@ extern "C" int pn_similarity_fwd(const float* P_e, const float* L_e, int B, int 
 // ------------------------------------------------------------------------------------------------
 // generic GEMM entry (tests / building block)
 // ------------------------------------------------------------------------------------------------
+extern "C" size_t pn_gemm_nt_stats_ws_bytes(int M, int N) {
+  Bump bp(nullptr, (size_t)-1);
+  ColScr c;
+  colscr_carve(bp, M, N, c);
+  return bp.off + 256;
+}
+
 extern "C" int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N,
                           int K, const float* bias, const float* a_scale, const float* a_shift, double* col_sum,
-                          double* col_sumsq, int tile_variant, void* stream) {
+                          double* col_sumsq, int tile_variant, void* ws, size_t ws_bytes, void* stream) {
   if (K % 4 || lda % 4 || ldw % 4) return fail("gemm_nt: K, lda, ldw must be multiples of 4");
   GemmParams p = gp_zero();
   p.M = M; p.N = N; p.Nstore = N; p.Kseg = K;
   p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias;
-  p.col_sum = col_sum; p.col_sumsq = col_sumsq;
+  if (col_sum != nullptr) {
+    if (col_sumsq == nullptr) return fail("gemm_nt: col_sum without col_sumsq");
+    Bump bp(ws, ws_bytes);
+    ColScr c;
+    if (ws == nullptr || !colscr_carve(bp, M, N, c)) return fail("gemm_nt: column statistics need pn_gemm_nt_stats_ws_bytes(M, N) of workspace");
+    p.col_sum = col_sum; p.col_sumsq = col_sumsq; p.col_part = c.part; p.col_red = c.red;
+  }
   const int v = tile_variant < 0 ? pick_variant(N) : tile_variant;
   if (a_scale) {
     p.a_scale = a_scale; p.a_shift = a_shift;
@@ -905,9 +964,6 @@ extern "C" int pn_gemm_nt(const float* A, long lda, const float* W, long ldw, fl
 // ================================================================================================
 //                                      TRAINING PATH
 // ================================================================================================
-#include "gemm_tn.hpp"
-#include "train_kernels.hpp"
-
 static int transpose_into(const float* src, long lds_, int rows, int cols, float* dst, long ldd, hipStream_t st) {
   hipLaunchKernelGGL(k_transpose, dim3(nblk(cols, 32), nblk(rows, 32)), dim3(256), 0, st, src, lds_, rows, cols, dst,
                      ldd);
@@ -1055,7 +1111,10 @@ struct MlpTrainWs {
   double *S1, *S2;  // also forward column sum / sumsq
   float *cs, *p, *q, *G[2], *WT, *part;
   size_t part_floats;
+  ColScr colscr;
+  StatScr statscr;
 };
+static const long MLP_STATS_ROWS = 1024;
 
 static bool mlp_train_ws_carve(const pn_mlp* m, int rows, Bump& bp, MlpTrainWs& w) {
   int hmax = 0;
@@ -1076,6 +1135,8 @@ static bool mlp_train_ws_carve(const pn_mlp* m, int rows, Bump& bp, MlpTrainWs& 
   w.WT = bp.take<float>(wmax);
   w.part_floats = wmax * 8 < TN_PART_FLOATS_MAX ? wmax * 8 : TN_PART_FLOATS_MAX;
   w.part = bp.take<float>(w.part_floats);
+  colscr_carve(bp, rows, hmax, w.colscr);
+  statscr_carve(bp, rows, MLP_STATS_ROWS, hmax, w.statscr);
   return bp.ok;
 }
 
@@ -1125,9 +1186,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
     p.A = in; p.lda = ldin; p.W = m->w[l]; p.ldw = m->dims[l];
     p.C = last ? y : sv.Y[l]; p.ldc = N;
     if (!last) {
-      HIP_OK(hipMemsetAsync(w.S1, 0, N * sizeof(double), st));
-      HIP_OK(hipMemsetAsync(w.S2, 0, N * sizeof(double), st));
-      p.col_sum = w.S1; p.col_sumsq = w.S2;
+      p.col_sum = w.S1; p.col_sumsq = w.S2; p.col_part = w.colscr.part; p.col_red = w.colscr.red;
     }
     if (l == 0) {
       PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(N), st)));
@@ -1166,15 +1225,15 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
     const bool last = (l == n - 1);
     // For the last layer G = dY (plain).  For hidden layers G = d(relu(bn(Y_l))) and dY_l is generated.
     if (!last) {
-      HIP_OK(hipMemsetAsync(w.S1, 0, N * sizeof(double), st));
-      HIP_OK(hipMemsetAsync(w.S2, 0, N * sizeof(double), st));
       StatsParams sp;
       memset(&sp, 0, sizeof(sp));
-      sp.R = rows; sp.C = N; sp.rows_per_block = 1024;
+      sp.R = rows; sp.C = N; sp.rows_per_block = MLP_STATS_ROWS;
       sp.Z = sv.Y[l]; sp.ldz = N; sp.G = G; sp.ldg = ldg;
       sp.s = sv.s[l]; sp.t = sv.t[l]; sp.mean = sv.mean[l]; sp.invstd = sv.invstd[l];
-      sp.S1 = w.S1; sp.S2 = w.S2; sp.pairB = 1;
-      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(N, 1024), nblk(rows, 1024)), dim3(256), 0, st, sp);
+      sp.part = w.statscr.part; sp.pairB = 1;
+      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(N, 1024), nblk(rows, MLP_STATS_ROWS)), dim3(256), 0, st, sp);
+      PN_OK(reduce_parts<double>(w.statscr.part, nblk(rows, MLP_STATS_ROWS), 2 * N, N, w.S1, w.S2, nullptr,
+                                 w.statscr.red, st));
       hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(N, 256)), dim3(256), 0, st, (const double*)w.S1,
                          (const double*)w.S2, (const double*)nullptr, (double)rows, N, m->bn[l].weight,
                          (const float*)sv.s[l], (const float*)sv.mean[l], (const float*)sv.invstd[l],
@@ -1254,7 +1313,11 @@ struct PairTrainWs {
   double *sumA, *sqA, *sumB, *sqB, *S1, *S2, *dwacc, *scal;
   float *cs, *p, *q, *WT, *weff, *dweff, *part, *dA1, *dB1;
   size_t part_floats;
+  ColScr colscr;
+  StatScr statscr;
 };
+static const long PAIR_STATS_ROWS = 4096;
+static const int SUM_BLOCKS = 1024;
 
 static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, PairTrainWs& w) {
   const int h = hd->h, d = hd->d;
@@ -1265,7 +1328,7 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.S1 = bp.take<double>(h);
   w.S2 = bp.take<double>(h);
   w.dwacc = bp.take<double>(h);
-  w.scal = bp.take<double>(4);
+  w.scal = bp.take<double>(4 + SUM_BLOCKS);  // [0] result, [4..) per-workgroup partials of k_sum
   w.cs = bp.take<float>(h);
   w.p = bp.take<float>(h);
   w.q = bp.take<float>(h);
@@ -1277,6 +1340,8 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.part = bp.take<float>(w.part_floats);
   w.dA1 = bp.take<float>((size_t)B * h);
   w.dB1 = bp.take<float>((size_t)NL * h);
+  colscr_carve(bp, (long)B * NL, h, w.colscr);
+  statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
   return bp.ok;
 }
 
@@ -1350,12 +1415,11 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
   }
   const bool prod = hd->fusion == 2;
   if (prod) ldw1 = hd->in_dim;
-  HIP_OK(hipMemsetAsync(w.sumA, 0, 4 * al256(h * sizeof(double)), st));  // sumA, sqA, sumB, sqB are contiguous
   {
     GemmParams p = gp_zero();
     p.M = B; p.N = h; p.Nstore = h; p.Kseg = d;
     p.A = P_e; p.lda = d; p.W = w1; p.ldw = ldw1; p.C = sv.A1; p.ldc = h;
-    p.col_sum = w.sumA; p.col_sumsq = w.sqA;
+    p.col_sum = w.sumA; p.col_sumsq = w.sqA; p.col_part = w.colscr.part; p.col_red = w.colscr.red;
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
     p.M = NL; p.A = L_e; p.W = w1 + d; p.C = sv.B1; p.col_sum = w.sumB; p.col_sumsq = w.sqB;
     PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
@@ -1374,14 +1438,13 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
   } else {
     // concatenation_prod: z1 = A1[i] + B1[j] + (P_e[i] (.) L_e[j]) W1c^T is not separable -> one more pair GEMM
     // whose output is stored, with BatchNorm statistics taken directly over the grid
-    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
-    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
     GemmParams p = gp_zero();
     p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = d;
     p.A = P_e; p.lda = d; p.A2 = L_e; p.lda2 = d; p.pairB = B;
     p.W = hd->w[0] + 2 * d; p.ldw = hd->in_dim;
     p.padd1 = sv.A1; p.ldp1 = h; p.padd2 = sv.B1; p.ldp2 = h;
     p.C = sv.zbuf[0] + (size_t)S * h; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
+    p.col_part = w.colscr.part; p.col_red = w.colscr.red;
     PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
     if (hd->bn[0].weight == nullptr) fold_nobn(0);
     else
@@ -1393,11 +1456,10 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
 
   for (int l = 1; l < n; ++l) {
     float* z = sv.zbuf[l] + (size_t)S * h;
-    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
-    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
     GemmParams p = gp_zero();
     p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
     p.W = hd->w[l]; p.ldw = h; p.C = z; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
+    p.col_part = w.colscr.part; p.col_red = w.colscr.red;
     if (l == 1 && !prod) {
       p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
       PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
@@ -1436,32 +1498,31 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   if (!pair_train_ws_carve(hd, B, NL, bw, w)) return fail("pairhead bwd: workspace too small");
 
   // d b_out = sum_r dl[r]
-  HIP_OK(hipMemsetAsync(w.scal, 0, 4 * sizeof(double), st));
-  hipLaunchKernelGGL(k_sum, dim3(1024), dim3(256), 0, st, dl_pairs, R, w.scal);
+  hipLaunchKernelGGL(k_sum, dim3(SUM_BLOCKS), dim3(256), 0, st, dl_pairs, R, w.scal + 4);
+  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(w.scal + 4), SUM_BLOCKS, w.scal);
   hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)w.scal, gr->db_out, 1, 1.f);
   HIP_OK(hipGetLastError());
 
   const float* G = nullptr;  // gradient wrt relu(bn(z_l)) for the layer being processed (rows [0,R) of a zbuf)
-  const long stats_rows = 4096;
+  const long stats_rows = PAIR_STATS_ROWS;
   for (int l = n - 1; l >= 1; --l) {
     const bool top = (l == n - 1);
     float* z = sv.zbuf[l] + (size_t)S * h;
-    HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
-    HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
-    HIP_OK(hipMemsetAsync(w.dwacc, 0, h * sizeof(double), st));
     StatsParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.R = R; sp.C = h; sp.rows_per_block = stats_rows; sp.pairB = 1;
     sp.Z = z; sp.ldz = h;
     sp.s = sv.s[l]; sp.t = sv.t[l]; sp.mean = sv.mean[l]; sp.invstd = sv.invstd[l];
-    sp.S1 = w.S1; sp.S2 = w.S2; sp.dw = w.dwacc;
+    sp.part = w.statscr.part;
     const dim3 sg(nblk(h, 1024), nblk(R, stats_rows));
     if (top) {
       sp.gvec = dl_pairs; sp.w = hd->w_out;
       hipLaunchKernelGGL((k_bn_bwd_stats<1, 0>), sg, dim3(256), 0, st, sp);
+      PN_OK(reduce_parts<double>(w.statscr.part, sg.y, 3 * h, h, w.S1, w.S2, w.dwacc, w.statscr.red, st));
     } else {
       sp.G = G; sp.ldg = h;
       hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), sg, dim3(256), 0, st, sp);
+      PN_OK(reduce_parts<double>(w.statscr.part, sg.y, 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
     }
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)(top ? w.dwacc : nullptr), (double)R, h,
@@ -1519,8 +1580,6 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   }
 
   // ---- layer 0: upstream gradient G = dh_0 over the pair grid ----
-  HIP_OK(hipMemsetAsync(w.S1, 0, h * sizeof(double), st));
-  HIP_OK(hipMemsetAsync(w.S2, 0, h * sizeof(double), st));
   const bool prod = hd->fusion == 2;
   float* dQ = nullptr;  // concatenation_prod: gradient wrt the P (.) L block, [R][d]
   if (!prod) {
@@ -1530,8 +1589,9 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     sp.R = R; sp.C = h; sp.rows_per_block = stats_rows;
     sp.G = G; sp.ldg = h; sp.A = sv.A1; sp.lda = h; sp.B2 = sv.B1; sp.ldb2 = h; sp.pairB = B;
     sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
-    sp.S1 = w.S1; sp.S2 = w.S2;
+    sp.part = w.statscr.part;
     hipLaunchKernelGGL((k_bn_bwd_stats<0, 1>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+    PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
@@ -1554,8 +1614,9 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     sp.R = R; sp.C = h; sp.rows_per_block = stats_rows; sp.pairB = 1;
     sp.Z = z0; sp.ldz = h; sp.G = G; sp.ldg = h;
     sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
-    sp.S1 = w.S1; sp.S2 = w.S2;
+    sp.part = w.statscr.part;
     hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+    PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
@@ -1629,26 +1690,32 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
 // ------------------------------------------------------------------------------------------------
 // loss + metrics, optimiser, layout helpers
 // ------------------------------------------------------------------------------------------------
+extern "C" size_t pn_loss_ws_bytes(int B, int N) {
+  return al256(512 + (size_t)B * sizeof(float)) + al256((size_t)nblk(N, 256) * nblk(B, 32) * sizeof(double));
+}
+
 extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B,
                                int N, int kind, float pos_weight, float gamma, float alpha, float smoothing,
                                float threshold, float* loss_out, float* dlogits, float* tp, float* fn, float* fp,
                                int weight_mode, const float* label_weights, float rgd_temperature, void* ws,
                                size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (ws_bytes < 512 + (size_t)B * sizeof(float)) return fail("loss: workspace too small (need 512 + 4*B bytes)");
+  if (ws_bytes < pn_loss_ws_bytes(B, N)) return fail("loss: workspace too small (need pn_loss_ws_bytes(B, N))");
   if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("loss: pass exactly one target array");
   if (weight_mode < 0 || weight_mode > 2) return fail("loss: weight_mode must be 0, 1 (batch) or 2 (label weights)");
   if (weight_mode == 2 && label_weights == nullptr) return fail("loss: weight_mode 2 needs label_weights");
-  double* acc = (double*)ws;               // [0] loss sum, [1] number of positives
+  double* acc = (double*)ws;               // [0] loss sum, [1] number of positives (integer-valued: order-free)
   float* posneg = (float*)((char*)ws + 256);
   float* row_w = (float*)((char*)ws + 512);
+  const dim3 lgrid(nblk(N, 256), nblk(B, 32));
+  double* lpart = (double*)((char*)ws + al256(512 + (size_t)B * sizeof(float)));  // one loss partial per workgroup
   HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
   LossParams p;
   memset(&p, 0, sizeof(p));
   p.logits = logits; p.tf = targets_f32; p.ti = targets_i64; p.B = B; p.N = N; p.kind = kind;
   p.pos_weight = pos_weight; p.gamma = gamma; p.alpha = alpha; p.smoothing = smoothing; p.threshold = threshold;
   p.grad_scale = 1.f / ((float)B * (float)N);
-  p.dlogits = dlogits; p.loss_sum = acc; p.tp = tp; p.fn = fn; p.fp = fp;
+  p.dlogits = dlogits; p.loss_part = lpart; p.tp = tp; p.fn = fn; p.fp = fp;
   p.rows_per_block = 32;
   if (weight_mode != 0) {
     hipLaunchKernelGGL(k_target_weights, dim3(nblk(B, 4)), dim3(256), 0, st, targets_f32, targets_i64, B, N,
@@ -1662,7 +1729,8 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
       p.row_w = row_w;
     }
   }
-  hipLaunchKernelGGL(k_loss, dim3(nblk(N, 256), nblk(B, 32)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_loss, lgrid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)lpart, (int)(lgrid.x * lgrid.y), acc);
   if (rgd_temperature >= 0.f)
     hipLaunchKernelGGL(k_rgd_scale, dim3(dlogits ? 1024 : 1), dim3(256), 0, st, (const double*)acc,
                        1.0 / ((double)B * (double)N), rgd_temperature, dlogits, (long)B * N, loss_out);
@@ -1690,11 +1758,11 @@ extern "C" int pn_clip_adam_step(float* w, const float* g, float* m, float* v, l
                                  float beta1, float beta2, float eps, float weight_decay, int step, float* norm_out,
                                  void* ws, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (ws_bytes < 256) return fail("adam: workspace too small");
+  if (ws_bytes < PN_ADAM_WS_BYTES) return fail("adam: workspace too small (need %d bytes)", PN_ADAM_WS_BYTES);
   if (step < 1) return fail("adam: step must be >= 1");
-  double* acc = (double*)ws;
-  HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), st));
-  hipLaunchKernelGGL(k_sumsq, dim3(2048), dim3(256), 0, st, g, n, acc);
+  double* acc = (double*)ws;  // [0] sum of squares, [32..) one partial per workgroup of k_sumsq
+  hipLaunchKernelGGL(k_sumsq, dim3(2048), dim3(256), 0, st, g, n, acc + 32);
+  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(acc + 32), 2048, acc);
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(k_adam, dim3(2048), dim3(256), 0, st, w, g, m, v, n, (const double*)acc, max_norm, lr, beta1,
@@ -1904,6 +1972,89 @@ extern "C" int pn_additive_attention(const float* hidden, const int64_t* attenti
   return 0;
 }
 
+// Backward of the pooling wrt the scorer (training with LABEL_EMBEDDING_POOLING_METHOD: all, ProtNote.py:89-91,154-166):
+// with a = softmax(s), out = sum_t a_t h_t and upstream gradient g = d out:
+//   da_t = g . h_t,   ds_t = a_t (da_t - sum_u a_u da_u),   dw = sum_{n,t} ds_t h_t,   db = sum_{n,t} ds_t
+// One workgroup per label writes its [d] partial of dw (slot d: its db partial); the partials are added in a fixed
+// order afterwards.  The token embeddings are inputs (frozen label encoder): no gradient wrt h is produced.
+__global__ __launch_bounds__(256) void k_additive_attention_bwd(const float* __restrict__ hid,
+                                                                const int64_t* __restrict__ mask,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const float* __restrict__ dout, int T, int d, int ldp,
+                                                                float* __restrict__ part) {
+  extern __shared__ float sc[];  // [T] scores -> ds, [T] da
+  float* da = sc + T;
+  const int n = blockIdx.x;
+  const float* hn = hid + (long)n * T * d;
+  const float* gn = dout + (long)n * d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < T; t += 4) {
+    float a = 0.f, g = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float hv = hn[(long)t * d + c];
+      a = fmaf(hv, w[c], a);
+      g = fmaf(hv, gn[c], g);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      g += __shfl_xor(g, o);
+    }
+    if (lane == 0) {
+      sc[t] = mask[(long)n * T + t] != 0 ? a + b[0] : -INFINITY;
+      da[t] = g;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+  float den = 0.f, dot = 0.f;
+  for (int t = 0; t < T; ++t) den += expf(sc[t] - mx);
+  for (int t = 0; t < T; ++t) dot = fmaf(expf(sc[t] - mx) / den, da[t], dot);
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 256) sc[t] = (expf(sc[t] - mx) / den) * (da[t] - dot);  // ds_t (0 where masked)
+  __syncthreads();
+  float* pn_ = part + (long)n * ldp;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = fmaf(sc[t], hn[(long)t * d + c], acc);
+    pn_[c] = acc;
+  }
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += sc[t];
+    pn_[d] = acc;
+    for (int c = d + 1; c < ldp; ++c) pn_[c] = 0.f;
+  }
+}
+
+extern "C" size_t pn_additive_attention_bwd_ws_bytes(int N, int d) {
+  const int ldp = ld4(d + 1);
+  return al256((size_t)N * ldp * sizeof(float)) + al256((size_t)RED_CHUNKS * ldp * sizeof(double)) +
+         al256((size_t)ldp * sizeof(double)) + 256;
+}
+
+extern "C" int pn_additive_attention_bwd(const float* hidden, const int64_t* attention_mask, const float* w,
+                                         const float* b, const float* dout, int N, int T, int d, float* dw, float* db,
+                                         void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (T <= 0 || T > 8192) return fail("additive_attention bwd: unsupported token count %d", T);
+  if (N <= 0) return fail("additive_attention bwd: no labels");
+  const int ldp = ld4(d + 1);
+  Bump bp(ws, ws_bytes);
+  float* part = bp.take<float>((size_t)N * ldp);
+  double* red = bp.take<double>((size_t)RED_CHUNKS * ldp);
+  double* tot = bp.take<double>(ldp);
+  if (!bp.ok) return fail("additive_attention bwd: workspace too small");
+  hipLaunchKernelGGL(k_additive_attention_bwd, dim3(N), dim3(256), 2 * T * sizeof(float), st, hidden, attention_mask, w,
+                     b, dout, T, d, ldp, part);
+  HIP_OK(hipGetLastError());
+  PN_OK(reduce_parts<float>(part, N, ldp, ldp, tot, nullptr, nullptr, red, st));
+  hipLaunchKernelGGL(k_d2f, dim3(nblk(d, 256)), dim3(256), 0, st, (const double*)tot, dw, d, 1.f);
+  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)(tot + d), db, 1, 1.f);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // device-side batch assembly: ragged uint8 residue ids -> padded f32 one-hots [B][A][Lmax] + lengths.
 // The host ships B*L bytes instead of B*A*L*4 (80x less PCIe traffic than the reference's collated one-hots).
@@ -1940,7 +2091,9 @@ struct EncBwdWs {
   float *g, *T1, *T2, *cs, *p, *q, *WbT, *WtA, *dWpk, *part;
   double *S1, *S2, *col;
   size_t part_floats;
+  StatScr statscr;
 };
+static const long ENC_STATS_ROWS = 1024;
 
 static bool enc_bwd_carve(const pn_encoder* e, int B, int L, Bump& bp, EncBwdWs& w) {
   const long P = (long)B * L;
@@ -1962,6 +2115,7 @@ static bool enc_bwd_carve(const pn_encoder* e, int B, int L, Bump& bp, EncBwdWs&
   w.S1 = bp.take<double>(ldc);
   w.S2 = bp.take<double>(ldc);
   w.col = bp.take<double>(ldc);
+  statscr_carve(bp, P, ENC_STATS_ROWS, ldc, w.statscr);
   return bp.ok;
 }
 
@@ -1987,9 +2141,9 @@ extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* de
   const int ldc = ld4(C), ldb = ld4(Cb), ldi = ld4(e->Cin);
 
   auto colsum_to = [&](const float* X, int ld, int cols, float* dst) -> int {  // bias gradient
-    HIP_OK(hipMemsetAsync(w.col, 0, (size_t)ldc * sizeof(double), st));
     hipLaunchKernelGGL(k_colsum, dim3(nblk(cols, 256), nblk(P, 2048)), dim3(256), 0, st, X, (long)ld, P, cols, 2048L,
-                       w.col);
+                       w.statscr.part);
+    PN_OK(reduce_parts<double>(w.statscr.part, nblk(P, 2048), cols, cols, w.col, nullptr, nullptr, w.statscr.red, st));
     hipLaunchKernelGGL(k_d2f, dim3(nblk(cols, 256)), dim3(256), 0, st, (const double*)w.col, dst, cols, 1.f);
     HIP_OK(hipGetLastError());
     return 0;
@@ -2005,10 +2159,12 @@ extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* de
     HIP_OK(hipMemsetAsync(w.q, 0, (size_t)ldc * sizeof(float), st));
     StatsParams sp;
     memset(&sp, 0, sizeof(sp));
-    sp.R = P; sp.C = ld; sp.rows_per_block = 1024; sp.pairB = 1;
+    sp.R = P; sp.C = ld; sp.rows_per_block = ENC_STATS_ROWS; sp.pairB = 1;
     sp.Z = Zin; sp.ldz = ld; sp.G = G; sp.ldg = ld; sp.s = s; sp.t = t; sp.mean = mean; sp.invstd = invstd;
-    sp.S1 = w.S1; sp.S2 = w.S2;
-    hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(ld, 1024), nblk(P, 1024)), dim3(256), 0, st, sp);
+    sp.part = w.statscr.part;
+    hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(ld, 1024), nblk(P, ENC_STATS_ROWS)), dim3(256), 0, st, sp);
+    PN_OK(reduce_parts<double>(w.statscr.part, nblk(P, ENC_STATS_ROWS), 2 * ld, ld, w.S1, w.S2, nullptr, w.statscr.red,
+                               st));
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(cols, 256)), dim3(256), 0, st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)nullptr, (double)P, cols, bn.weight, s, mean, invstd,
                        (const float*)nullptr, w.cs, w.p, w.q, dgamma, dbeta, (float*)nullptr);

@@ -1,11 +1,66 @@
 // HBM-bound passes of the training path (gfx950): BatchNorm-backward column statistics over stored
 // pre-activations, the layer-1 pair-grid reductions, the logits row-dot, loss + metrics, clip + Adam.
 // All are streaming kernels: 16-byte coalesced loads (one wave = 1 KiB of one row), per-thread register
-// accumulation, f64 atomics only once per thread at the end.
+// accumulation.  Cross-workgroup sums never use floating-point atomics: every workgroup writes its partial to its own
+// slot and k_part_reduce / k_part_final (or k_scalar_final) add the slots in a fixed order, so a training step is
+// bit-reproducible run to run.
 #pragma once
 #include "gemm_engine.hpp"
 
 namespace pn {
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-order reduction of per-workgroup partials.  part[nparts][width] (float or double) ->
+//   level 1 (k_part_reduce): out[chunk][width] = sum of `per_chunk` consecutive partial rows, sequentially, in f64
+//   level 2 (k_part_final):  dst_{c / seg}[c % seg] = sum over the chunks, sequentially
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_part_reduce(const T* __restrict__ part, long nparts, int width, long per_chunk,
+                                                     double* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  const long p0 = (long)blockIdx.y * per_chunk;
+  long p1 = p0 + per_chunk;
+  if (p1 > nparts) p1 = nparts;
+  double a = 0;
+#pragma unroll 8
+  for (long q = p0; q < p1; ++q) a += (double)part[q * width + c];
+  out[(long)blockIdx.y * width + c] = a;
+}
+
+__global__ void k_part_final(const double* __restrict__ in, int nchunk, int width, int seg, double* d0, double* d1,
+                             double* d2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  double a = 0;
+  for (int k = 0; k < nchunk; ++k) a += in[(long)k * width + c];
+  const int which = c / seg;
+  double* dst = which == 0 ? d0 : (which == 1 ? d1 : d2);
+  dst[c - which * seg] = a;
+}
+
+// one workgroup: out[0] = sum part[0..n) in a fixed order (strided per-thread sums, then a fixed LDS tree)
+__global__ __launch_bounds__(256) void k_scalar_final(const double* __restrict__ part, int n, double* out) {
+  __shared__ double sh[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// sum of a 256-thread workgroup's per-thread doubles in a fixed order -> valid in thread 0
+__device__ __forceinline__ double block_sum_256(double a) {
+  __shared__ double wsum[4];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
+  __syncthreads();
+  return ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+}
 
 // ------------------------------------------------------------------------------------------------
 // BN-backward statistics for one layer.  With u = s*z + t, mask = u > 0, xhat = (z - mean)*invstd:
@@ -30,7 +85,7 @@ struct StatsParams {
   const float* B2;
   long ldb2;
   int pairB;
-  double *S1, *S2, *dw;
+  double* part;  // [gridDim.y][NST][C] per-workgroup partials (NST = 3 for the row-scalar form: S1, S2, dw; else 2)
 };
 
 template <int ROWG, int ZK>
@@ -89,11 +144,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const StatsParams p) {
       dw[k] += aw[k];
     }
   }
+  constexpr int NST = ROWG ? 3 : 2;
+  double* o = p.part + (long)blockIdx.y * NST * p.C + c;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    atomicAdd(&p.S1[c + k], d1[k]);
-    atomicAdd(&p.S2[c + k], d2[k]);
-    if constexpr (ROWG) atomicAdd(&p.dw[c + k], dw[k]);
+    o[k] = d1[k];
+    o[p.C + k] = d2[k];
+    if constexpr (ROWG) o[2 * p.C + k] = dw[k];
   }
 }
 
@@ -165,8 +222,8 @@ __global__ void k_pool_bwd(const float* __restrict__ demb, int ld_emb, const int
   g[i] = (c < C && t < len) ? demb[(long)b * ld_emb + c] / (float)len : 0.f;
 }
 
-// column sums of X[P][ld] (bias gradients): out[c] += sum_p X[p][c]; grid (ld/256 cols, row chunks)
-__global__ void k_colsum(const float* __restrict__ X, long ld, long P, int C, long rows_per_block, double* out) {
+// column sums of X[P][ld] (bias gradients): part[blockIdx.y][c] = sum over this block's rows; grid (C/256, row chunks)
+__global__ void k_colsum(const float* __restrict__ X, long ld, long P, int C, long rows_per_block, double* part) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const long r0 = (long)blockIdx.y * rows_per_block;
@@ -174,7 +231,7 @@ __global__ void k_colsum(const float* __restrict__ X, long ld, long P, int C, lo
   if (r1 > P) r1 = P;
   double a = 0;
   for (long r = r0; r < r1; ++r) a += X[r * ld + c];
-  atomicAdd(&out[c], a);
+  part[(long)blockIdx.y * C + c] = a;
 }
 
 // forward-packed conv weight [Cout][k][ld4(Cin)] -> data-gradient weight [Cin][k][ld4(Cout)] with the taps reversed:
@@ -391,12 +448,12 @@ __global__ void k_transpose(const float* __restrict__ src, long lds_, int rows, 
   }
 }
 
-// double accumulate of a float vector: out[0] += sum(x)
-__global__ void k_sum(const float* __restrict__ x, long n, double* out) {
+// f64 sum of a float vector: part[blockIdx.x] = this workgroup's share (256 threads; k_scalar_final adds them up)
+__global__ __launch_bounds__(256) void k_sum(const float* __restrict__ x, long n, double* part) {
   double a = 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a += x[i];
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
+  a = block_sum_256(a);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
 __global__ void k_d2f(const double* in, float* out, int n, float scale) {
@@ -421,7 +478,7 @@ struct LossParams {
   float threshold;     // on the probability
   float grad_scale;    // 1/(B*N)
   float* dlogits;      // [B][N] or null
-  double* loss_sum;    // scalar accumulator
+  double* loss_part;   // [gridDim.y * gridDim.x] per-workgroup loss sums
   float *tp, *fn, *fp; // [N] accumulators (+=) or null
   int rows_per_block;
   const float* row_w;   // [B] element weight of row i (WeightedBCE / CBLoss, losses.py:214-241) or null
@@ -539,8 +596,8 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
       atomicAdd(&p.fp[j], fp);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.loss_sum, lsum);
+  lsum = block_sum_256(lsum);
+  if (threadIdx.x == 0) p.loss_part[(long)blockIdx.y * gridDim.x + blockIdx.x] = lsum;
 }
 
 // calculate_tp_fn_fp on probabilities (ProtNoteTrainer.py:61-83): counts are integers held in f32
@@ -569,7 +626,7 @@ __global__ __launch_bounds__(256) void k_tp_fn_fp(const float* __restrict__ prob
 // ------------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam (ProtNoteTrainer.py:745-755) on flat f32 buffers
 // ------------------------------------------------------------------------------------------------
-__global__ void k_sumsq(const float* __restrict__ g, long n, double* out) {
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, long n, double* part) {
   double a = 0;
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -580,8 +637,8 @@ __global__ void k_sumsq(const float* __restrict__ g, long n, double* out) {
       for (long k = i; k < n; ++k) a += (double)g[k] * g[k];
     }
   }
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
+  a = block_sum_256(a);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
 // coef = min(max_norm / (sqrt(sumsq) + 1e-6), 1)  (torch.nn.utils.clip_grad_norm_); max_norm <= 0: no clipping

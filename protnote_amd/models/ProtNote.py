@@ -295,11 +295,17 @@ class ProtNote(nn.Module):
         else:
             raise ValueError("Incompatible label parameters passed to forward method.")
         L.require_hip(L_f)
-        if self.label_embedding_pooling_method == "all":
-            if self.training:
-                raise NotImplementedError("training raw_attn_scorer (LABEL_EMBEDDING_POOLING_METHOD='all') is not "
-                                          "implemented; inference is")
-            L_f = self.additive_attention(L_f, tokenized_labels["attention_mask"])
+        pool_all = self.label_embedding_pooling_method == "all"
+        attn_mask = None
+        if pool_all:
+            # token embeddings [N, T, d] + tokenized_labels["attention_mask"] (ProtNote.py:266-267).  In a training
+            # forward the pooling happens inside forward_train (after the label noise, as in the reference, and inside
+            # the autograd graph so raw_attn_scorer is trained).
+            if tokenized_labels is None or "attention_mask" not in tokenized_labels:
+                raise ValueError("LABEL_EMBEDDING_POOLING_METHOD='all' needs tokenized_labels['attention_mask']")
+            attn_mask = tokenized_labels["attention_mask"]
+            if not (self.training and torch.is_grad_enabled()):
+                L_f = self.additive_attention(L_f, attn_mask)
         if save_embeddings and (self.training or not self.feature_fusion.startswith("concatenation")):
             raise NotImplementedError("save_embeddings=True is implemented for inference with the concatenation heads")
 
@@ -308,7 +314,7 @@ class ProtNote(nn.Module):
                 from .train_path import forward_train
 
                 logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
-                                       label_token_counts)
+                                       label_token_counts, attn_mask)
                 return logits, {"output_layer_embeddings": [], "joint_embeddings": []}
 
             with torch.no_grad():

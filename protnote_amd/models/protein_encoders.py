@@ -156,7 +156,7 @@ class ProteInfer(torch.nn.Module):
         out = torch.empty(feats.shape[0], w.shape[0], dtype=torch.float32, device=feats.device)
         L.check(L.lib().pn_gemm_nt(L.ptr(feats), feats.shape[1], L.ptr(w.detach()), w.shape[1], L.ptr(out),
                                    out.shape[1], feats.shape[0], w.shape[0], w.shape[1], L.ptr(b.detach()),
-                                   None, None, None, None, -1, L.stream_ptr()))
+                                   None, None, None, None, -1, None, 0, L.stream_ptr()))
         return out
 
     @classmethod

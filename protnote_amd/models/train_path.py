@@ -179,14 +179,15 @@ class _HeadsTrainFn(torch.autograd.Function):
                                         L.ptr(sv), sv.numel(), L.ptr(w), w.numel(), st))
 
         dP_f = torch.empty_like(P_f) if ctx.needs_input_grad[1] else None  # TRAIN_SEQUENCE_ENCODER: True
+        dL_f = torch.empty_like(L_f) if ctx.needs_input_grad[2] else None  # attention-pooled labels: scorer is trained
         mlp_bwd(model.W_p, P_f, dP_e, "W_p", dP_f)
-        mlp_bwd(model.W_l, L_f, dL_e, "W_l")
+        mlp_bwd(model.W_l, L_f, dL_e, "W_l", dL_f)
 
         outs = []
         for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]):
             outs.append(grads.get(id(p)) if need else None)
         ctx.model = None
-        return (None, dP_f, None, *outs)
+        return (None, dP_f, dL_f, *outs)
 
 
 def head_parameters(model):
@@ -198,12 +199,53 @@ def head_parameters(model):
     return ps
 
 
-def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths, L_f, label_token_counts):
+def trainable_parameters(model):
+    """Every parameter the reference's optimiser would hold for this model besides the encoders
+    (ProtNoteTrainer.py:204-231): the heads, plus raw_attn_scorer with LABEL_EMBEDDING_POOLING_METHOD: all."""
+    ps = head_parameters(model)
+    if getattr(model, "label_embedding_pooling_method", "mean") == "all":
+        ps = ps + [model.raw_attn_scorer.weight, model.raw_attn_scorer.bias]
+    return ps
+
+
+class _AttnPoolFn(torch.autograd.Function):
+    """Differentiable ProtNote.additive_attention (reference ProtNote.py:154-166) wrt the scorer's weight and bias; the
+    token embeddings come from the frozen label encoder (cached), so no gradient flows into them."""
+
+    @staticmethod
+    def forward(ctx, model, hidden, mask, weight, bias):
+        out = model.additive_attention(hidden, mask)
+        ctx.model = model
+        ctx.save_for_backward(hidden, mask.to(device=hidden.device, dtype=torch.int64).contiguous(), weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hidden, mask, weight, bias = ctx.saved_tensors
+        lib = L.lib()
+        N, T, d = hidden.shape
+        dout = dout.contiguous().float()
+        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        db = torch.empty_like(bias)
+        ws = L.workspace(lib.pn_additive_attention_bwd_ws_bytes(N, d), hidden.device, "attn")
+        L.check(lib.pn_additive_attention_bwd(L.ptr(hidden), L.ptr(mask), L.ptr(weight.detach()), L.ptr(bias.detach()),
+                                              L.ptr(dout), N, T, d, L.ptr(dw), L.ptr(db), L.ptr(ws), ws.numel(),
+                                              L.stream_ptr()))
+        return None, None, None, dw, db
+
+
+def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths, L_f, label_token_counts,
+                  attention_mask=None):
     """Reference ProtNote.forward in training mode (ProtNote.py:219-309)."""
     with torch.no_grad():
         L_f = L_f.detach().float().contiguous()
         if label_token_counts is not None and model.label_embedding_noising_alpha > 0:
+            # (for [N, T, d] token embeddings the reference's scale is alpha / sqrt(L_f.shape[1]) = alpha / sqrt(T),
+            #  ProtNote.py:227-230 - _noised reads shape[1] the same way)
             L_f = model._noised(L_f, torch.rand_like(L_f))
+    if attention_mask is not None:  # LABEL_EMBEDDING_POOLING_METHOD: all - pooling after the noise (:266-267)
+        sc = model.raw_attn_scorer
+        L_f = _AttnPoolFn.apply(model, L_f, attention_mask, sc.weight, sc.bias)
     P_f = None
     if sequence_embeddings is not None and not model.train_sequence_encoder:
         P_f = sequence_embeddings.detach().float().contiguous()
@@ -218,6 +260,7 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
     else:
         raise ValueError("Incompatible sequence parameters passed to forward method.")
     L.require_hip(P_f, L_f)
+    L_f = L_f.contiguous()
     # SEQUENCE_EMBEDDING_DROPOUT / LABEL_EMBEDDING_DROPOUT (ProtNote.py:83-86): Bernoulli masks on the [B, 1100] and
     # [N_L, 1024] input rows (after the label noise, as the wrapped W_l sees them); torch's device RNG, like the noise
     from .ProtNote import input_dropout_p

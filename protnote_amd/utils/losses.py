@@ -28,7 +28,7 @@ class _FusedLossFn(torch.autograd.Function):
             tf = target.detach().float().contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
-        ws = L.workspace(512 + 4 * B, x.device, "loss")
+        ws = L.workspace(L.lib().pn_loss_ws_bytes(B, N), x.device, "loss")
         lw = None
         if label_weights is not None:
             lw = label_weights.detach().to(device=x.device, dtype=torch.float32).contiguous()

@@ -55,7 +55,7 @@ class FusedClipAdam:
                                    "was moved / cast / re-assigned after the optimiser was built); rebuild the "
                                    "optimiser, or call repack()")
         self.step_count += 1
-        ws = L.workspace(256, self.flat_w.device, "adam")
+        ws = L.workspace(L.PN_ADAM_WS_BYTES, self.flat_w.device, "adam")
         max_norm = -1.0 if self.max_norm is None else float(self.max_norm)
         L.check(L.lib().pn_clip_adam_step(L.ptr(self.flat_w), L.ptr(self.flat_g), L.ptr(self.flat_m),
                                           L.ptr(self.flat_v), self.flat_w.numel(), max_norm, float(self.lr),

@@ -542,6 +542,80 @@ def golden_tf_weights():
     print("tf_weights_small.pkl + expected", len(out))
 
 
+def golden_attention_pooling():
+    """LABEL_EMBEDDING_POOLING_METHOD: all (ProtNote.py:89-91,154-166,266-267): cached TOKEN embeddings [N, T, d] +
+    attention mask -> additive-attention pooled label embeddings (eval), and one train step in which raw_attn_scorer
+    is trained (label noise included: for 3-D label embeddings its scale is alpha / sqrt(T), ProtNote.py:227-230)."""
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.losses import get_loss
+    import protnote.models.ProtNote as PN
+
+    enc_cfg = dict(num_labels=7, input_channels=20, output_channels=28, kernel_size=9,
+                   dilation_base=3, num_resnet_blocks=2, bottleneck_factor=0.5)
+    head_cfg = dict(protein_embedding_dim=28, label_embedding_dim=24, latent_dim=16,
+                    output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                    outout_mlp_add_batchnorm=True, projection_head_num_layers=4,
+                    projection_head_hidden_dim_scale_factor=3, dropout=0.0,
+                    label_embedding_noising_alpha=20.0, temperature=0.07,
+                    label_embedding_pooling_method="all")
+    g = torch.Generator().manual_seed(4242)
+    torch.manual_seed(3)
+
+    def build():
+        m = ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg), label_encoder=None,
+                     feature_fusion="concatenation", inference_descriptions_per_label=1, **head_cfg)
+        for n, p in m.named_parameters():
+            if n.startswith("sequence_encoder"):
+                p.requires_grad = False
+        return m
+
+    model = build()
+    randomize_(model, g)
+    lens = [50, 3, 21, 50, 17, 44]
+    x, _ = onehots(g, lens, 50)
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    N, T, d = 9, 11, 24
+    hidden = torch.randn(N, T, d, generator=g)
+    ntok = torch.tensor([11, 1, 5, 11, 2, 7, 3, 9, 4])
+    mask = (torch.arange(T)[None, :] < ntok[:, None]).to(torch.int64)
+    y = (torch.rand(len(lens), N, generator=g) < 0.3).to(torch.int64)
+    out = {"fusion": np.array("concatenation")}
+    out.update({"enc_cfg_" + k: np.array(v) for k, v in enc_cfg.items()})
+    out.update({"head_cfg_" + k: np.array(v) for k, v in head_cfg.items()})
+    out.update(sd_np(model, "sd/"))
+    out.update(x=x.numpy(), lens=lens_t.numpy(), hidden=hidden.numpy(), attention_mask=mask.numpy(),
+               token_counts=ntok.numpy(), multihots=y.numpy())
+    tok = {"attention_mask": mask}
+    model.eval()
+    with torch.no_grad():
+        out["eval/pooled"] = model.additive_attention(hidden, mask).numpy()
+        lg, _ = model(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=hidden, tokenized_labels=tok)
+        out["eval/logits"] = lg.numpy()
+    u = torch.rand(hidden.shape, generator=g)
+    out["train/noise_u"] = u.numpy()
+    real_rand_like = torch.rand_like
+    PN.torch.rand_like = lambda t, *a, **k: u.clone()
+    try:
+        m2 = build()
+        m2.load_state_dict(model.state_dict())
+        m2.train()
+        loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+        inputs = dict(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=hidden, tokenized_labels=tok,
+                      label_token_counts=ntok)
+        logits, loss, grads, gnorm = _train_step(m2, loss_fn, inputs, y)
+        out["train_BCE/logits"] = logits
+        out["train_BCE/loss"] = np.array(loss, dtype=np.float32)
+        out["train_BCE/grad_norm"] = np.array(gnorm, dtype=np.float32)
+        for k, v in grads.items():
+            out["train_BCE/grad/" + k] = v
+        out.update(sd_np(m2, "train_BCE/sd_after/"))
+    finally:
+        PN.torch.rand_like = real_rand_like
+    np.savez_compressed(os.path.join(OUT, "protnote_small_attention.npz"), **out)
+    print("protnote_small_attention.npz", sorted(k for k in out if "raw_attn" in k))
+
+
 def golden_samplers():
     """Index streams of protnote/data/samplers.py::DistributedWeightedSampler (torch.multinomial + randperm on a
     generator seeded with the epoch, rank-strided) for 2 ranks x 2 epochs, with and without replacement."""
@@ -573,7 +647,7 @@ if __name__ == "__main__":
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
-            "samplers": golden_samplers}
+            "samplers": golden_samplers, "attention": golden_attention_pooling}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

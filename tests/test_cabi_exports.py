@@ -70,7 +70,7 @@ def test_error_convention(built_lib):
     from protnote_amd import _lib
 
     lib = _lib.lib()
-    rc = lib.pn_gemm_nt(None, 6, None, 6, None, 8, 4, 8, 6, None, None, None, None, None, 0, None)  # K % 4 != 0
+    rc = lib.pn_gemm_nt(None, 6, None, 6, None, 8, 4, 8, 6, None, None, None, None, None, 0, None, 0, None)  # K % 4 != 0
     assert rc != 0 and b"multiples of 4" in lib.pn_last_error()
     rc = lib.pn_ensemble_logit(None, 4, 10, 3, 0, None, None)  # NL not divisible by ndesc
     assert rc != 0 and b"divisible" in lib.pn_last_error()

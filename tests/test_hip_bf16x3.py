@@ -29,7 +29,7 @@ def _gemm_nt(A, W, scale=None, shift=None):
     N = W.shape[0]
     out = torch.empty(M, N, device=DEV)
     _lib.check(_lib.lib().pn_gemm_nt(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(out), N, M, N, K, None,
-                                     _lib.ptr(scale), _lib.ptr(shift), None, None, 0, _lib.stream_ptr()))
+                                     _lib.ptr(scale), _lib.ptr(shift), None, None, 0, None, 0, _lib.stream_ptr()))
     torch.cuda.synchronize()
     return out
 

@@ -32,11 +32,19 @@ def test_gemm_nt(M, N, K, variant):
     ref = A.double() @ W.double().T + bias.double()
     Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
     Cd = torch.full((M, N), float("nan"), device=DEV)
-    cs = torch.zeros(N, dtype=torch.float64, device=DEV)
-    cq = torch.zeros(N, dtype=torch.float64, device=DEV)
-    L.check(L.lib().pn_gemm_nt(L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(Cd), N, M, N, K, L.ptr(bd), None, None, L.ptr(cs),
-                               L.ptr(cq), variant, L.stream_ptr()))
-    torch.cuda.synchronize()
+    cs = torch.full((N,), float("nan"), dtype=torch.float64, device=DEV)  # written, not accumulated
+    cq = torch.full((N,), float("nan"), dtype=torch.float64, device=DEV)
+    ws = torch.empty(L.lib().pn_gemm_nt_stats_ws_bytes(M, N), dtype=torch.uint8, device=DEV)
+
+    def run():
+        L.check(L.lib().pn_gemm_nt(L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(Cd), N, M, N, K, L.ptr(bd), None, None,
+                                   L.ptr(cs), L.ptr(cq), variant, L.ptr(ws), ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return cs.clone(), cq.clone()
+
+    first = run()
+    again = run()
+    assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])  # fixed-order reduction: same bits
     out = Cd.cpu().double()
     scale = ref.abs().max().item()
     assert (out - ref).abs().max().item() <= 2e-6 * scale * max(1, K ** 0.5)
@@ -55,7 +63,7 @@ def test_gemm_nt_affine_relu():
     Cd = torch.empty(M, N, device=DEV)
     Ad, Wd, sd_, td = A.to(DEV), W.to(DEV), s.to(DEV), t.to(DEV)  # keep alive across the async launch
     L.check(L.lib().pn_gemm_nt(L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(Cd), N, M, N, K, None,
-                               L.ptr(sd_), L.ptr(td), None, None, 0, L.stream_ptr()))
+                               L.ptr(sd_), L.ptr(td), None, None, 0, None, 0, L.stream_ptr()))
     torch.cuda.synchronize()
     assert (Cd.cpu().double() - ref).abs().max().item() < 2e-5
 

@@ -74,8 +74,8 @@ def test_fused_loss_and_metrics_golden(golden_dir):
 
 def _assert_adam_close(got, ref, name, lr=3e-4, steps=1, atol=3e-5, rtol=2e-4, frac=0.995):
     """Post-Adam parameters.  Adam's update lr*m/(sqrt(v)+eps) is sign-like for gradients at f32-noise level
-    (|g| ~ 1e-8): such an element moves by +-lr per step whichever way the last-bit noise points (CPU vs GPU,
-    and run to run on the GPU because the f64 statistics atomics commit in arbitrary order).  Hence: every element
+    (|g| ~ 1e-8): such an element moves by +-lr per step whichever way the last-bit noise points (CPU vs GPU
+    summation order; the GPU itself is bit-reproducible, see test_train_step_bit_reproducible).  Hence: every element
     within the worst case 2*lr*steps, and at least `frac` of them within (atol, rtol)."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     diff = np.abs(got - ref)
@@ -182,7 +182,10 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
         nrm = max(ref.norm().item(), 1e-30)
         rel = (p.grad.cpu().double() - ref).norm().item() / nrm
         rel_cpu = (cpu32_grads[name].double() - ref).norm().item() / nrm
-        assert rel < max(8 * rel_cpu, 5e-4) and rel < 1e-2, (name, rel, rel_cpu)
+        # Measured (round 2, `pytest -s` prints): the GPU's error is 1.1x..2.9x the f32 CPU path's on every tensor and
+        # grid (e.g. 130x40: 1.5e-3 vs 8.4e-4; 8x9: 4.1e-6 vs 1.5e-6), deterministically - hence the factor 4.
+        print(f"grad-err {B}x{NL} {name}: gpu {rel:.2e} cpu32 {rel_cpu:.2e}")
+        assert rel < max(4 * rel_cpu, 1e-6) and rel < 4e-3, (name, rel, rel_cpu)
     # BN running statistics after the train-mode forward
     got = {k: v.cpu() for k, v in model.state_dict().items()}
     for k, v in work.items():
@@ -291,8 +294,8 @@ def test_full_size_train_step_properties():
     """BASELINE configs[2] size (B=256, L=512, N_L=32102, full-width model; the oracle cannot run it): a whole train
     forward+backward through size-independent identities -
       loss == BCE of the returned logits;  dL/db_out == sum(dL/dlogits);  every gradient finite and non-zero;
-      BatchNorm bookkeeping advanced by exactly one batch;  a second identical pass reproduces loss and gradients
-      (only the f64-atomic commit order differs run to run)."""
+      BatchNorm bookkeeping advanced by exactly one batch;  a second identical pass reproduces loss, logits and every
+      gradient BIT FOR BIT (8.2 M-row reductions included)."""
     from bench import build_model, synthetic_batch
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
@@ -325,14 +328,14 @@ def test_full_size_train_step_properties():
     for n, b in model.named_buffers():
         if n.endswith("num_batches_tracked"):
             assert int(b) == 2, n  # two train-mode forwards (encoder BN included - SURVEY 3.4-1)
-    loss1, g1, _ = results[1]
-    # the two passes differ only through the BN running buffers (not used in train mode) and atomic order
-    assert abs(loss1 - loss0) < 1e-6 * max(1.0, abs(loss0))
+    loss1, g1, lg1 = results[1]
+    # Bit-reproducible: no floating-point atomics anywhere (column statistics and scalar sums are per-workgroup
+    # partials added in a fixed order, weight gradients are split-K partial tiles summed in order), and the BN running
+    # buffers - the only state the first pass changed - are not read in train mode.
+    assert loss1 == loss0
+    assert torch.equal(lg1, lg)
     for n in g0:
-        rel = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30)
-        # last-bit differences in the f64 statistics flip ReLU masks of pre-activations at ~1e-8 of zero; over
-        # 2.5e10 activations that is a 1e-4..3e-3 relative perturbation of the deepest gradients
-        assert rel < 1e-2, (n, rel)
+        assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
 
 
 def test_trainer_learns_synthetic_task():
@@ -746,10 +749,9 @@ def test_second_forward_invalidates_pending_backward(golden_dir):
     with pytest.raises(RuntimeError, match="another train-mode forward"):
         l1.backward()
     l2.backward()  # the latest forward is intact
-    with torch.no_grad():  # forwards that keep nothing do not invalidate anything
-        l3 = loss_fn(m(**kw)[0], b["label_multihots"])
-    m.eval()
-    m(**kw)
+    m.eval()  # a forward that keeps nothing does not invalidate anything
+    with torch.no_grad():
+        m(**kw)
     m.train()
     l3 = loss_fn(m(**kw)[0], b["label_multihots"])
     l3.backward()
@@ -788,7 +790,7 @@ def test_optimizer_state_interchange_with_torch_adam(golden_dir):
         np.testing.assert_allclose(sd_f["state"][i]["exp_avg"].cpu().numpy(), sd_t["state"][i]["exp_avg"].numpy(),
                                    rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(sd_f["state"][i]["exp_avg_sq"].cpu().numpy(), sd_t["state"][i]["exp_avg_sq"].numpy(),
-                                   rtol=1e-5, atol=1e-8)
+                                   rtol=1e-4, atol=1e-8)
     # torch -> fused: a fresh fused optimiser resumed from torch's state continues like torch does
     ps_r = [torch.nn.Parameter(p.detach().to(DEV).clone()) for p in ps_t]
     resumed = FusedClipAdam(ps_r, lr=123.0, max_norm=None)
@@ -809,3 +811,95 @@ def test_optimizer_state_interchange_with_torch_adam(golden_dir):
         resumed.step()
     resumed.repack()
     resumed.step()
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_prod", "similarity"])
+def test_train_step_bit_reproducible(golden_dir, fusion, math_mode):
+    """Two optimisation steps from identical state give bit-identical loss, gradient norm, parameters, Adam moments and
+    BN buffers, in both arithmetic modes: every cross-workgroup sum is a fixed-order reduction of per-workgroup
+    partials (train-mode BN statistics, BN-backward S1/S2, loss mean, gradient norm, split-K weight gradients)."""
+    import protnote_amd
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    g = _g(golden_dir, f"protnote_small_{fusion}.npz")
+    batch = _small_batch(g)
+    loss_fn = get_loss({"params": {"LOSS_FN": "FocalLoss", "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1,
+                                   "LABEL_SMOOTHING": 0.0}}, bce_pos_weight=torch.tensor(1.0))
+
+    def run():
+        m, _ = make_protnote(g, DEV)
+        m.label_embedding_noising_alpha = 0.0
+        for n, p in m.named_parameters():
+            p.requires_grad = True  # trainable encoder too: its backward reductions are covered as well
+        m.train_sequence_encoder = True
+        m.train()
+        opt = FusedClipAdam(head_parameters(m) + list(m.sequence_encoder.trunk_parameters()), lr=3e-4, max_norm=1.0)
+        out = []
+        for _ in range(2):
+            loss = train_step(m, loss_fn, opt, batch)
+            out += [loss.clone(), opt.last_grad_norm.clone()]
+        bufs = torch.cat([b.detach().float().reshape(-1) for b in m.buffers()])
+        return out + [opt.flat_w.clone(), opt.flat_m.clone(), opt.flat_v.clone(), bufs]
+
+    protnote_amd.set_math_mode(math_mode)
+    try:
+        a, b = run(), run()
+    finally:
+        protnote_amd.set_math_mode("f32")
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (i, (x - y).abs().max().item())
+
+
+def test_attention_pooling_golden(golden_dir, monkeypatch):
+    """LABEL_EMBEDDING_POOLING_METHOD: all against the reference-generated vectors (ProtNote.py:89-91,154-166,266-267):
+    inference pooling + logits, and one train step in which raw_attn_scorer is trained - its gradient comes from
+    pn_additive_attention_bwd fed by the W_l input gradient; label noise scaled by alpha / sqrt(T) as in the reference."""
+    from protnote_amd.models.train_path import trainable_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    g = _g(golden_dir, "protnote_small_attention.npz")
+    model, _ = make_protnote(g, DEV)
+    _freeze_encoder(model)
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    hidden, mask = torch.from_numpy(g["hidden"]).to(DEV), torch.from_numpy(g["attention_mask"]).to(DEV)
+    tok = {"attention_mask": mask}
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model.additive_attention(hidden, mask).cpu().numpy(), g["eval/pooled"], atol=2e-5,
+                                   rtol=1e-4)
+        lg, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=hidden, tokenized_labels=tok)
+    np.testing.assert_allclose(lg.cpu().numpy(), g["eval/logits"], atol=5e-4, rtol=1e-4)
+
+    model.train()
+    u = torch.from_numpy(g["train/noise_u"]).to(DEV)
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    params = trainable_parameters(model)
+    assert any(p is model.raw_attn_scorer.weight for p in params)
+    opt = FusedClipAdam(params, lr=3e-4, max_norm=1.0)
+    logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=hidden, tokenized_labels=tok,
+                      label_token_counts=torch.from_numpy(g["token_counts"]).to(DEV))
+    l = loss_fn(logits, torch.from_numpy(g["multihots"]).to(DEV).float())
+    l.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["train_BCE/logits"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(l.item(), float(g["train_BCE/loss"]), rtol=1e-4)
+    named = dict(model.named_parameters())
+    checked = 0
+    for k in g.files:
+        if k.startswith("train_BCE/grad/"):
+            name = k[len("train_BCE/grad/"):]
+            ref = g[k]
+            np.testing.assert_allclose(named[name].grad.cpu().numpy(), ref, atol=2e-5 + 2e-4 * np.abs(ref).max(),
+                                       err_msg=name)
+            checked += name.startswith("raw_attn_scorer")
+    assert checked == 2 and np.abs(g["train_BCE/grad/raw_attn_scorer.weight"]).max() > 1e-4
+    opt.step()
+    np.testing.assert_allclose(opt.last_grad_norm.item(), float(g["train_BCE/grad_norm"]), rtol=2e-4)
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for name in ("raw_attn_scorer.weight", "raw_attn_scorer.bias", "W_l.0.weight", "output_layer.11.weight"):
+        _assert_adam_close(got[name], g["train_BCE/sd_after/" + name], name)

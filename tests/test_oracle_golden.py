@@ -165,3 +165,31 @@ def test_protnote_train_encoder_grads(golden_dir):
         name = k[len("train_enc_BCE/grad/"):]
         ref = g[k]
         np.testing.assert_allclose(grads[name].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=name)
+
+
+def test_attention_pooling_eval_and_train(golden_dir):
+    """LABEL_EMBEDDING_POOLING_METHOD: all - the oracle's additive attention, the eval logits and one train step in
+    which raw_attn_scorer gets a gradient, against the reference-generated vectors (noise scale alpha / sqrt(T))."""
+    g = _load(golden_dir, "protnote_small_attention.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    hidden, mask = torch.from_numpy(g["hidden"]), torch.from_numpy(g["attention_mask"])
+    np.testing.assert_allclose(O.additive_attention(sd, hidden, mask).numpy(), g["eval/pooled"], atol=2e-6, rtol=1e-5)
+    lg = O.protnote_forward(sd, x, lens, hidden, attention_mask=mask)
+    np.testing.assert_allclose(lg.numpy(), g["eval/logits"], atol=1e-4, rtol=1e-5)
+    logits, l, grads, gn = O.train_step(
+        sd, x, lens, hidden, torch.from_numpy(g["multihots"]), loss="BCE",
+        noise_alpha=float(g["head_cfg_label_embedding_noising_alpha"]), noise_u=torch.from_numpy(g["train/noise_u"]),
+        label_token_counts=torch.from_numpy(g["token_counts"]), attention_mask=mask)
+    np.testing.assert_allclose(logits.numpy(), g["train_BCE/logits"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(float(l), float(g["train_BCE/loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(gn), float(g["train_BCE/grad_norm"]), rtol=1e-4)
+    assert "raw_attn_scorer.weight" in grads and "train_BCE/grad/raw_attn_scorer.weight" in g.files
+    for k in g.files:
+        if k.startswith("train_BCE/grad/"):
+            name = k[len("train_BCE/grad/"):]
+            np.testing.assert_allclose(grads[name].numpy(), g[k], atol=1e-5 + 1e-4 * np.abs(g[k]).max(), err_msg=name)
+    for k in g.files:
+        if k.startswith("train_BCE/sd_after/"):
+            name = k[len("train_BCE/sd_after/"):]
+            np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
