@@ -287,6 +287,11 @@ int pn_binned_auprc(unsigned long long* pos_hist, unsigned long long* all_hist, 
 int pn_set_math_mode(int mode);
 int pn_get_math_mode(void);
 
+/* Operand staging of the f32 pair-grid GEMMs: 1 (default; env PN_F32_DMA) = LDS-DMA (global_load_lds, gemm_dma.hpp),
+ * 0 = the register-staged engine (gemm_engine.hpp).  Same arithmetic in the same order: results are bit-identical;
+ * the switch exists for A/B timing and for the test that asserts exactly that. */
+int pn_set_f32_dma(int on);
+
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
  * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller

@@ -142,6 +142,7 @@ _SIGS = {
                                   C.c_void_p]),
     "pn_set_math_mode": (C.c_int, [C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
+    "pn_set_f32_dma": (C.c_int, [C.c_int]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),

@@ -2,12 +2,14 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/protnote_hip.h"
 #include "common.hpp"
 #include "gemm_engine.hpp"
 #include "gemm_bf16x3.hpp"
+#include "gemm_dma.hpp"
 #include "train_kernels.hpp"
 
 using namespace pn;
@@ -275,6 +277,51 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   return finish_col_stats(p, tm, st);
 }
 
+// f32 pair-grid GEMMs with LDS-DMA operand staging (gemm_dma.hpp); PN_F32_DMA=0 selects the register-staged engine
+static int g_f32_dma = -1;
+static bool use_f32_dma() {
+  if (g_f32_dma < 0) {
+    const char* e = getenv("PN_F32_DMA");
+    g_f32_dma = (e == nullptr || atoi(e) != 0) ? 1 : 0;
+  }
+  return g_f32_dma == 1;
+}
+
+extern "C" int pn_set_f32_dma(int on) {
+  g_f32_dma = on ? 1 : 0;
+  return 0;
+}
+
+template <int AK, int EK>
+static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
+  auto kern = gemm_nt_dma_kernel<AK, EK>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_DMA_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  const long tm = (p.M + 255) / 256, tn = p.N / 256;
+  GemmParams pp = p;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  if (AK == A_PAIRSUM_RELU && pp.xcd_bc && tm >= 64) pp.xcd_bc = 1;  // W panel resident in one XCD's L2 (see launch_gemm_cfg)
+  pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
+  long grid = tm * tn;
+  if (pp.xcd_bc) {
+    const long nblk_ = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk_ + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  {
+    ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), GEMM_DMA_LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return finish_col_stats(p, tm, st);
+}
+
 static int rowdot_nparts(int n);
 // variant 0: 128x128 tile (2x2 waves of 64x64); variant 1: 128x64 tile (4x1 waves of 32x64);
 // variant 2: 256x256 tile (4x2 waves of 64x128, one workgroup per CU) - half the operand traffic per flop
@@ -295,6 +342,11 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
     if constexpr (AK == A_CONV && EK == E_CONV) {  // encoder convolutions, 256x192 tiles
       if (variant == 3) return launch_gemm_bf16x3<AK, EK, 2, 3, true>(p, st);
     }
+  }
+  if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
+    if (PN_BIG && use_f32_dma() && (variant == 0 || EK == E_ROWDOT) && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 &&
+        p.N % 256 == 0 && p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0)
+      return launch_gemm_dma<AK, EK>(p, st);
   }
   if constexpr ((EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) ||
                 (EK == E_PAIRADD && AK == A_PAIRPROD)) {

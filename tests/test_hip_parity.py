@@ -437,3 +437,37 @@ def test_device_batch_assembly_matches_cpu_collator(golden_dir):
                 assert dev[k].dtype == v.dtype and dev[k].shape == v.shape and torch.equal(dev[k].cpu(), v), k
             else:
                 assert dev[k] == v
+
+
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 32), (70001, 512, 96), (66000, 3072, 3072)])
+def test_gemm_nt_lds_dma_vs_f64_and_register_engine(M, N, K, affine):
+    """The LDS-DMA kernel (gemm_dma.hpp; tall pair-grid shapes: M >= 65536, N % 256 == 0, K % 32 == 0) against an f64
+    reference, and against the register-staged engine of gemm_engine.hpp: the same products accumulate in the same
+    order, so the two must agree BIT FOR BIT (ragged last row tile included)."""
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) + torch.arange(N)[:, None] * 1e-3).to(DEV)  # asymmetric
+    s = (torch.rand(K, generator=g) + 0.5).to(DEV) if affine else None
+    t = torch.randn(K, generator=g).to(DEV) if affine else None
+    act = torch.relu(A.double() * s.double() + t.double()) if affine else A.double()
+    ref = act @ W.double().T
+
+    def run(dma):
+        L.check(L.lib().pn_set_f32_dma(dma))
+        out = torch.full((M, N), float("nan"), device=DEV)
+        L.check(L.lib().pn_gemm_nt(L.ptr(A), K, L.ptr(W), K, L.ptr(out), N, M, N, K, None, L.ptr(s), L.ptr(t), None, None,
+                                   0, None, 0, L.stream_ptr()))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        got, old = run(1), run(0)
+    finally:
+        L.lib().pn_set_f32_dma(1)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() <= 2e-6 * scale * max(1, K ** 0.5)
+    assert torch.equal(got, old)
+    assert torch.equal(run(1), got)  # and run to run
