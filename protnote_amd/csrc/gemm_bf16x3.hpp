@@ -328,7 +328,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   // every global load has a full slab to land.
   using std::integral_constant;
   auto weave = [&](auto nvalu_c) {
-#if !defined(PN_B3_NOWEAVE)
     constexpr int NV = decltype(nvalu_c)::value;
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);  // all fragment reads of the k-step first
 #pragma unroll
@@ -337,7 +336,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
       __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU of the staging path
       if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS writes: 8 per region
     }
-#endif
   };
   fetch_a(0);
   fetch_b(0);
@@ -586,7 +584,6 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   using std::false_type;
   using std::true_type;
   auto weave = [&](auto nvalu_c) {
-#if !defined(PN_B3_NOWEAVE)
     constexpr int NV = decltype(nvalu_c)::value;
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);
 #pragma unroll
@@ -595,7 +592,6 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
       __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
       if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
-#endif
   };
   // slab t covers rows [r_begin + 32 t, +32); slabs 0 .. nf-1 are full, slab nf (if any) is the ragged tail.
   // Same two-region pipeline as the NT kernel: region 1 = k-step 0 x staging of A(t+1), then issue A(t+2);

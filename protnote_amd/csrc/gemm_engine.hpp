@@ -491,47 +491,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   fetch(0);
   pin_fetched();
   commit(0);
-#if !defined(PN_F32_PIPE1) && !defined(PN_ABL)
   fetch(nslab > 1 ? 1 : 0);
-#endif
   __syncthreads();
-  // (PN_F32_PIPE1 selects the earlier single-region loop: all loads of slab s+1 issued at the top of slab s and waited
-  //  for in its middle.  Measured on the train step: 7.34 s vs 7.19 s with the two-region loop below.)
-#if defined(PN_ABL) && PN_ABL == 1  // ablation: MFMA + LDS fragment reads only
-  for (int s = 0; s + 1 < nslab; ++s)
-    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
-#elif defined(PN_ABL) && PN_ABL == 2  // ablation: operand streaming only
-  for (int s = 0; s + 1 < nslab; ++s) {
-    fetch(s + 1);
-    pin_fetched();
-    commit((s & 1) ^ 1);
-    __syncthreads();
-  }
-#elif defined(PN_ABL) && PN_ABL == 4  // ablation: global loads + MFMA, no transform / ds_write
-  for (int s = 0; s + 1 < nslab; ++s) {
-    fetch(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
-    __builtin_amdgcn_sched_barrier(0);
-    pin_fetched();
-    __syncthreads();
-  }
-#elif defined(PN_ABL) && PN_ABL == 5  // ablation: transform + ds_write + MFMA, no global loads
-  for (int s = 0; s + 1 < nslab; ++s) {
-    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
-    __builtin_amdgcn_sched_barrier(0);
-    pin_fetched();
-    commit((s & 1) ^ 1);
-    __syncthreads();
-  }
-#elif defined(PN_ABL) && PN_ABL == 6  // ablation: MFMA + barrier only
-  for (int s = 0; s + 1 < nslab; ++s) {
-    compute(s & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
-    __syncthreads();
-  }
-#elif !defined(PN_F32_PIPE1)
   // two-region pipeline (as in gemm_bf16x3.hpp): A(s+1) staged under the first half of the MFMAs, B(s+1) under the
-  // second; the loads of slab s+2 are issued as soon as their registers are free - a full slab to land
+  // second; the loads of slab s+2 are issued as soon as their registers are free - a full slab to land.  (Ablations
+  // of this loop - MFMA + fragment reads only, loads only, no LDS writes, the earlier single-region loop - are
+  // recorded with their numbers in DESIGN.md section 4.1; the switches are no longer compiled in.)
   for (int s = 0; s + 1 < nslab; ++s) {
     const int cur = s & 1;
     const int nxt = s + 2 < nslab ? s + 2 : s + 1;
@@ -552,24 +517,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-#else
-  for (int s = 0; s + 1 < nslab; ++s) {
-    const int cur = s & 1;
-    fetch(s + 1);  // global loads of the next slab are issued first ...
-    __builtin_amdgcn_sched_barrier(0);
-    // ... stay in flight under the first half of this slab's MFMAs ...
-    compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 16>{});
-    __builtin_amdgcn_sched_barrier(0);
-    pin_fetched();  // ... are waited for here (the pin keeps hipcc from floating the consumer math and its
-                    // s_waitcnt vmcnt above this point) ...
-    // ... and the operand transform + LDS stores share one scheduling region with the second half's MFMAs
-    compute(cur, integral_constant<int, BK / 16>{}, integral_constant<int, BK / 8>{});
-    commit(cur ^ 1);
-#if !defined(PN_ABL) || PN_ABL != 3
-    __syncthreads();
-#endif
-  }
-#endif
   compute((nslab - 1) & 1, integral_constant<int, 0>{}, integral_constant<int, BK / 8>{});
   __syncthreads();
 

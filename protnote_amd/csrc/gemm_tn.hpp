@@ -48,14 +48,32 @@ struct TnParams {
   long ldc;
 };
 
+// one LDS-DMA wave-instruction (global_load_lds_dwordx4): lane l copies 16 bytes from its own global address to
+// LDS[lds_base + 16 l]; issued from inline asm, so its completion is the kernel's own business (s_waitcnt vmcnt)
+__device__ __forceinline__ void tn_glds16(const float* gsrc, unsigned lds_base_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base_uniform)
+      : "memory");
+}
+
 // BIG = false: 128x128 output tile, 4 waves (2x2, each 64x64), 2 workgroups/CU.
 // BIG = true : 256x256 output tile, 8 waves (4x2, each 64x128), 1 workgroup/CU - half the operand traffic per flop.
-template <int TA, int TB, bool BIG>
+// ADMA (BIG, TA_PLAIN, every split a whole number of slabs): the plain A operand (the materialised dz) goes global ->
+// LDS by LDS-DMA, one 1 KiB tile row per wave-instruction, instead of through registers; the generated B operand keeps
+// the register path.  A(t+1) is issued at the top of slab t into the idle buffer and waited for (together with the
+// B(t+1) registers) in the middle of the slab; the barrier at the end of the slab publishes it.
+template <int TA, int TB, bool BIG, bool ADMA = false>
 __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnParams p) {
+  static_assert(!ADMA || (BIG && TA == TA_PLAIN), "LDS-DMA staging is for the plain A operand of the big tile");
   constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128, BK = 32;
   constexpr int NGN = BIG ? 2 : 1;        // 64-column groups per wave along n
   constexpr int C4 = BM / 4;              // float4 per tile row (BM == BN)
-  constexpr int LDM = BM + 4, LDN = BN + 4;
+  // (an LDS-DMA row must be contiguous: no padding - the 8-byte fragment reads and the 16-byte row-contiguous
+  //  writes are conflict-free either way)
+  constexpr int LDM = ADMA ? BM : BM + 4, LDN = ADMA ? BN : BN + 4;
   constexpr int STAGE = BK * (LDM + LDN);
   constexpr int NQ = 4;  // (BK rows * C4 float4 per row) / threads
 
@@ -296,73 +314,69 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   // the last 8; the loads of slab t+2 go out as soon as their registers are free (rows past r_end are clamped and
   // masked, so over-fetching one slab at the end is harmless).
   using std::integral_constant;
+  // ADMA: wave w stages tile rows w, w + 8, w + 16, w + 24 of a slab; lane l the columns 4 l .. 4 l + 3
+  const unsigned tn_lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem;
+  auto issue_a_dma = [&](long k0_, int buf) {
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const long r = k0_ + w + 8 * q;
+      tn_glds16(p.A + r * p.lda + m0 + 4 * lane,
+                __builtin_amdgcn_readfirstlane(tn_lds0 + (unsigned)(buf * STAGE + (w + 8 * q) * LDM) * 4u));
+    }
+  };
   if (r_begin < r_end) {
-    fetch_a(r_begin);
-    fetch_b(r_begin);
-    commit_a(0);
-    commit_b(0);
-    fetch_a(r_begin + BK);
-    fetch_b(r_begin + BK);
-    __syncthreads();
+    if constexpr (ADMA) {
+      issue_a_dma(r_begin, 0);
+      fetch_b(r_begin);
+      commit_b(0);
+      fetch_b(r_begin + BK);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      fetch_a(r_begin);
+      fetch_b(r_begin);
+      commit_a(0);
+      commit_b(0);
+      fetch_a(r_begin + BK);
+      fetch_b(r_begin + BK);
+      __syncthreads();
+    }
     int cur = 0;
     long k0 = r_begin;
-#if defined(PN_TN_ABL) && PN_TN_ABL == 1  // ablation: MFMA + LDS fragment reads only
-    for (; k0 + BK < r_end; k0 += BK) compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
-#elif defined(PN_TN_ABL) && PN_TN_ABL == 2  // ablation: MFMA + operand transform + LDS writes + barrier, no global loads
-    for (; k0 + BK < r_end; k0 += BK) {
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
-      commit_a(cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
-      commit_b(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-#elif defined(PN_TN_ABL) && PN_TN_ABL == 3  // ablation: MFMA + global loads + barrier, no transform / LDS writes
-    for (; k0 + BK < r_end; k0 += BK) {
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
-      fetch_a(k0 + 2 * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
-      fetch_b(k0 + 2 * BK);
-      for (int q = 0; q < NQ; ++q) { pin4(ra[q]); pin4(rb[q]); }
-      __syncthreads();
-    }
-#elif defined(PN_TN_ABL) && PN_TN_ABL == 5  // ablation: the real two-region loop without operand transform / LDS writes
-    for (; k0 + BK < r_end; k0 += BK) {
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
-      for (int q = 0; q < NQ; ++q) pin4(ra[q]);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_a(k0 + 2 * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
-      for (int q = 0; q < NQ; ++q) pin4(rb[q]);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_b(k0 + 2 * BK);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-#elif defined(PN_TN_ABL) && PN_TN_ABL == 4  // ablation: MFMA + barrier only
-    for (; k0 + BK < r_end; k0 += BK) {
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
-      __syncthreads();
-    }
-#endif
-    for (; k0 + BK < r_end; k0 += BK) {
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
-      commit_a(cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_a(k0 + 2 * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
-      commit_b(cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_b(k0 + 2 * BK);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur ^= 1;
+    if constexpr (!ADMA) {
+      for (; k0 + BK < r_end; k0 += BK) {
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+        commit_a(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_a(k0 + 2 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+        commit_b(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_b(k0 + 2 * BK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
+    } else {
+      for (; k0 + BK < r_end; k0 += BK) {
+        issue_a_dma(k0 + BK, cur ^ 1);  // the idle buffer was last read in the previous slab (barrier passed)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // everything in flight is at least half a slab (~8k cycles) old: the B(t+1) registers and this wave's share of
+        // the A(t+1) DMA.  The explicit wait (the DMA is invisible to hipcc) precedes the barrier that publishes it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        compute(cur, integral_constant<int, BK / 4>{}, integral_constant<int, BK / 2>{});
+        commit_b(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_b(k0 + 2 * BK);  // stays in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
     }
     compute(cur, integral_constant<int, 0>{}, integral_constant<int, BK / 2>{});
   }

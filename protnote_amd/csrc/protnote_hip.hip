@@ -1038,9 +1038,9 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile,
   return (int)ns;
 }
 
-template <int TA, int TB, bool BIG>
+template <int TA, int TB, bool BIG, bool ADMA = false>
 static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_kernel<TA, TB, BIG>;
+  auto kern = gemm_tn_kernel<TA, TB, BIG, ADMA>;
   constexpr int TILE = BIG ? 256 : 128;
   constexpr int LDS = BIG ? TN_LDS_BYTES_BIG : TN_LDS_BYTES;
   static bool attr_done[64] = {false};
@@ -1124,7 +1124,12 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
         (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0))
       return launch_tn_bf16x3<TB>(p, dst, ldd, part, part_cap_floats, st);
   }
-  // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction)
+  // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction); a plain A operand (the
+  // materialised dz) is staged by LDS-DMA when every split is a whole number of 32-row slabs
+  if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
+    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 && p.R % 32 == 0 && p.lda % 4 == 0)
+      return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
+  }
   if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536)
     return launch_tn_cfg<TA, TB, true>(p, dst, ldd, part, part_cap_floats, st);
   return launch_tn_cfg<TA, TB, false>(p, dst, ldd, part, part_cap_floats, st);

@@ -942,3 +942,31 @@ def test_lds_dma_engine_bit_identical_train_step():
     assert float(a[0].std()) > 0.1
     for i, (x, z) in enumerate(zip(a, b)):
         assert torch.equal(x, z), (i, (x - z).abs().max().item())
+
+
+@pytest.mark.parametrize("R,M,N", [(65536, 256, 256), (131072 + 64, 512, 256), (70016, 256, 768)])
+def test_gemm_tn_lds_dma_vs_f64_and_register_engine(R, M, N):
+    """Weight-gradient contraction with the A operand staged by LDS-DMA (gemm_tn.hpp, ADMA: big tiles, R % 32 == 0)
+    against f64 and, bit for bit, against the register-staged kernel (same products in the same order)."""
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(R + M)
+    A = torch.randn(R, M, generator=g).to(DEV)
+    Bm = (torch.randn(R, N, generator=g) + torch.arange(N) * 0.01).to(DEV)
+    ref = A.double().T @ Bm.double()
+    ws = torch.empty(16 * M * N * 4 + 1024, dtype=torch.uint8, device=DEV)
+
+    def run(dma):
+        L.check(L.lib().pn_set_f32_dma(dma))
+        out = torch.full((M, N), float("nan"), device=DEV)
+        L.check(L.lib().pn_gemm_tn(L.ptr(A), M, L.ptr(Bm), N, L.ptr(out), N, R, M, N, L.ptr(ws), ws.numel(),
+                                   L.stream_ptr()))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        got, old = run(1), run(0)
+    finally:
+        L.lib().pn_set_f32_dma(1)
+    assert (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() * R ** 0.5 / 8
+    assert torch.equal(got, old) and torch.equal(run(1), got)
