@@ -291,6 +291,9 @@ int pn_get_math_mode(void);
  * 0 = the register-staged engine (gemm_engine.hpp).  Same arithmetic in the same order: results are bit-identical;
  * the switch exists for A/B timing and for the test that asserts exactly that. */
 int pn_set_f32_dma(int on);
+/* Same switch for the bf16x3 pair-grid GEMMs (weight operand pre-split into bf16 hi / lo planes and staged by LDS-DMA;
+ * env PN_B3_DMA). */
+int pn_set_b3_dma(int on);
 
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind

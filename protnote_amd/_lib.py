@@ -143,6 +143,7 @@ _SIGS = {
     "pn_set_math_mode": (C.c_int, [C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
+    "pn_set_b3_dma": (C.c_int, [C.c_int]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),

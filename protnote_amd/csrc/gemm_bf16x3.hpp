@@ -57,8 +57,17 @@ __device__ __forceinline__ HiLo split4(float4 v) {
 // GEN = false: the pair-grid fast path (one K segment, K % 32 == 0, N % BN == 0: no masks anywhere).
 // GEN = true : segmented K with a ragged tail, ragged N, the dilated-conv tap gather (A_CONV) - the encoder's convs
 //              and the row MLPs; invalid operand quads are zeroed by selects, loads stay unconditional.
-template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, bool GEN = false>
+// BDMA (pair-grid fast path only): the weight operand arrives PRE-SPLIT as two bf16 planes [N][K] (p.w_hi / p.w_lo,
+//              written once per launch by k_split_planes) and goes global -> LDS by LDS-DMA (global_load_lds_dwordx4,
+//              16 tile rows of one plane per wave-instruction): no VGPR round trip, no split, no ds_write for half of
+//              the staged data.  Its LDS image is [plane][row][4 granules of 8 k] (64 B rows, unpadded - a DMA
+//              destination is contiguous) with granule g of row r at position g ^ ((r >> 2) & 3): conflict-free for the
+//              16-lane groups of ds_read_b128.  W is L2-resident (3 MB per column tile), so one region of lead time is
+//              enough: B(s+1) is issued at the top of slab s and waited for (vmcnt(0), the only VMEM in flight at that
+//              point) between the A commit and the A prefetch; the barrier at the end of the slab publishes it.
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, bool GEN = false, bool BDMA = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) void gemm_nt_bf16x3_kernel(const GemmParams p) {
+  static_assert(!BDMA || (!GEN && WAVES_M * WAVES_N == 8 && WAVES_N * WN * 32 == 256), "BDMA: 256-column pair-grid tiles");
   constexpr int BK = 32;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;
@@ -72,7 +81,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   static_assert(AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU || AK == A_CONV,
                 "operand kind not built for bf16x3");
   static_assert(AK != A_CONV || GEN, "the conv gather needs the general path");
-  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int BPLANE = BN * 16;                              // floats per B plane of a stage (BN rows x 64 B)
+  constexpr int STAGE = BDMA ? BM * LDK + 2 * BPLANE : (BM + BN) * LDK;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -86,6 +96,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   if (!tile_coords<BM, BN>(p, tile_m, tile_n)) return;
   const int row0 = tile_m * BM;
   const int col0 = tile_n * BN;
+
+  // ---- BDMA: wave w issues chunks c = 4 w + q (q < 4) of a stage: plane c / 16, tile rows 16 (c % 16) .. + 15;
+  //      lane l: row + l / 4, LDS granule position l % 4 <- source granule (l % 4) ^ ((row >> 2) & 3)
+  const uint16_t* bsrc[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned bdst[4] = {0, 0, 0, 0};
+  if constexpr (BDMA) {
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * w + q;
+      const int r = 16 * (c & 15) + (lane >> 2);
+      const int g = (lane & 3) ^ ((r >> 2) & 3);
+      bsrc[q] = ((c >> 4) ? p.w_lo : p.w_hi) + (long)(col0 + r) * p.Kseg + 8 * g;
+      bdst[q] = (unsigned)(BM * LDK + (c >> 4) * BPLANE + 16 * (c & 15) * 16) * 4u;
+    }
+  }
+  const unsigned lds0_b = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem;
+  auto issue_b_dma = [&](int s_, int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      tn_glds16(reinterpret_cast<const float*>(bsrc[q] + s_ * BK),
+                __builtin_amdgcn_readfirstlane(lds0_b + (unsigned)(buf * STAGE) * 4u + bdst[q]));
+  };
 
   const int kv = tid % KV;
   const int r_in = tid / KV;
@@ -297,17 +330,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   auto compute = [&](int buf, auto ks_c) {
     constexpr int KS = decltype(ks_c)::value;
     const float* As = smem + buf * STAGE + (wm * WM * 32 + frag_row) * LDK + (2 * KS + frag_g) * 8;
-    const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + (2 * KS + frag_g) * 8;
     bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK);
       al[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK + 4);
     }
+    if constexpr (BDMA) {
+      // row r of plane P: P + 16 r floats; k-group g at granule position g ^ ((r >> 2) & 3), (r >> 2) & 3 is the
+      // lane's own (frag_row >> 2) & 3 for every tile of the wave
+      const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * 16 +
+                        4 * ((2 * KS + frag_g) ^ ((frag_row >> 2) & 3));
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      bh[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK);
-      bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK + 4);
+      for (int j = 0; j < WN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 16);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 16 + BPLANE);
+      }
+    } else {
+      const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + (2 * KS + frag_g) * 8;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK);
+        bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK + 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -337,6 +382,40 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
       if (i % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // LDS writes: 8 per region
     }
   };
+  if constexpr (BDMA) {
+    issue_b_dma(0, 0);
+    fetch_a(0);
+    pin_a();
+    commit_a(0);
+    fetch_a(nslab > 1 ? 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s + 1 < nslab; ++s) {
+      const int cur = s & 1;
+      const int nxt = s + 2 < nslab ? s + 2 : s + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      pin_a();  // (first: hipcc's counted waits for the A registers must not see the DMA as younger traffic)
+      issue_b_dma(s + 1, cur ^ 1);  // the idle buffer was last read in slab s-1 (barrier passed)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, 0>{});
+      commit_a(cur ^ 1);
+      weave(integral_constant<int, (AK == A_PLAIN ? PN_B3_VALU : PN_B3_VALU + 1)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // only the DMA of B(s+1) is in flight here (the A registers were consumed above): wait for this wave's share,
+      // then prefetch A(s+2) so that it stays in flight across the barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fetch_a(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    compute((nslab - 1) & 1, integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    compute((nslab - 1) & 1, integral_constant<int, 1>{});
+    __syncthreads();
+  } else {
   fetch_a(0);
   fetch_b(0);
   pin_a();
@@ -369,6 +448,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   __builtin_amdgcn_sched_barrier(0);
   compute((nslab - 1) & 1, integral_constant<int, 1>{});
   __syncthreads();
+  }
 
   gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
 }
@@ -650,6 +730,22 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
         out[(long)m * p.ldc + n] = acc[i][j][e];
       }
     }
+}
+
+// W [N][ldw] f32 -> hi / lo bf16 planes [N][K] (row stride K), the pre-split weight operand of the BDMA kernels.
+// Inside every 32-k block the planes are stored in MFMA k-group order: the register-staged A operand puts
+// k = {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3} into k-group g (see the file header), so plane position 8 g + e holds
+// k = 4 g + e (e < 4) or 16 + 4 g + e - 4 (e >= 4) - both operands must agree on which 8 k meet in one MFMA lane.
+__global__ void k_split_planes(const float* __restrict__ W, long ldw, int N, int K, uint16_t* __restrict__ hi,
+                               uint16_t* __restrict__ lo) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;  // output position (4 consecutive plane slots)
+  if (i >= (long)N * K) return;
+  const long n = i / K;
+  const int pos = (int)(i - n * K);
+  const int blk = pos >> 5, in = pos & 31, g = in >> 3, half = (in >> 2) & 1;
+  const HiLo s = split4(ld4(W + n * ldw + blk * 32 + half * 16 + 4 * g));
+  *reinterpret_cast<bf16x4*>(hi + i) = s.hi;
+  *reinterpret_cast<bf16x4*>(lo + i) = s.lo;
 }
 
 }  // namespace pn

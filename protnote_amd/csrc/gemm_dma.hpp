@@ -20,6 +20,10 @@
 #pragma once
 #include "gemm_engine.hpp"
 
+#ifndef PN_DMA_LATE
+#define PN_DMA_LATE 0
+#endif
+
 namespace pn {
 
 // one LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS[lds_base + 16 l]
@@ -210,11 +214,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     // branch-free: the last slab re-stages itself into the idle buffer (nobody reads it) instead of taking a
     // different path - a conditional fetch makes hipcc wait for the loads right where they are issued
     const int nxt = s + 1 < nslab ? s + 1 : s;
-    issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
     if constexpr (A_DMA) {
+      // the first k-step's fragment reads and MFMAs go first (the matrix pipe has work right after the barrier),
+      // the DMA of slab s+1 is issued under them: it still has three quarters of a slab to land
+      if (PN_DMA_LATE) compute(cur, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
       issue_a(nxt, cur ^ 1);
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, 4>{});
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, integral_constant<int, PN_DMA_LATE ? 1 : 0>{}, integral_constant<int, 4>{});
     } else {
+      issue_b(nxt, cur ^ 1);
       fetch_a(nxt);
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, integral_constant<int, 0>{}, integral_constant<int, 2>{});

@@ -83,6 +83,9 @@ struct GemmParams {
   long ldp1;
   const float* padd2;
   long ldp2;
+  uint16_t* wsplit;      // optional scratch, 2 * N * Kseg bf16: bf16x3 mode pre-splits W into hi / lo planes there and
+  const uint16_t* w_hi;  // stages them by LDS-DMA (set by the launcher from wsplit)
+  const uint16_t* w_lo;
   int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
 };
 

@@ -241,15 +241,34 @@ extern "C" int pn_set_math_mode(int mode) {
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
 
-template <int AK, int EK, int WAVES_N, int WN, bool GEN>
+// bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; PN_B3_DMA=0 keeps the register path
+static int g_b3_dma = -1;
+static bool use_b3_dma() {
+  if (g_b3_dma < 0) {
+    const char* e = getenv("PN_B3_DMA");
+    g_b3_dma = (e == nullptr || atoi(e) != 0) ? 1 : 0;
+  }
+  return g_b3_dma == 1;
+}
+extern "C" int pn_set_b3_dma(int on) {
+  g_b3_dma = on ? 1 : 0;
+  return 0;
+}
+
+template <int AK, int EK, int WAVES_N, int WN, bool GEN, bool BDMA = false>
 static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   using Cfg = GemmCfg<4, WAVES_N, 2, WN, 32>;
-  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN>;
+  if constexpr (!GEN && !BDMA && WAVES_N * WN * 32 == 256) {
+    if (p.wsplit != nullptr && use_b3_dma() && p.Nstore == p.N)
+      return launch_gemm_bf16x3<AK, EK, WAVES_N, WN, GEN, true>(p, st);
+  }
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
+  constexpr int LDS_BYTES = BDMA ? 2 * (256 * 36 + 2 * 256 * 16) * (int)sizeof(float) : Cfg::LDS_BYTES;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
   if (p.M <= 0 || p.Nstore <= 0) return 0;
@@ -269,9 +288,15 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
     grid = ((nblk + 7) / 8) * 8 * 32;
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  if constexpr (BDMA) {  // W -> hi / lo bf16 planes [N][K], once per launch (37 MB for 3072 x 3072: ~20 us)
+    pp.w_hi = p.wsplit;
+    pp.w_lo = p.wsplit + (size_t)p.N * p.Kseg;
+    hipLaunchKernelGGL(k_split_planes, dim3(nblk((long)p.N * p.Kseg / 4, 256)), dim3(256), 0, st, p.W, p.ldw, p.N, p.Kseg,
+                       p.wsplit, p.wsplit + (size_t)p.N * p.Kseg);
+  }
   {
     ProfScope ps(1000 + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, pp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
   return finish_col_stats(p, tm, st);
@@ -803,6 +828,7 @@ extern "C" int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, in
 // ------------------------------------------------------------------------------------------------
 struct PairWs {
   float *A1, *B1, *weff, *z[2], *partials, *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS];
+  uint16_t* wsplit;  // bf16x3 mode: hi / lo planes of the layer's weight (h x h x 4 bytes)
   int nparts;
 };
 
@@ -823,6 +849,7 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
     w.s[i] = bp.take<float>(h);
     w.t[i] = bp.take<float>(h);
   }
+  w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
   return bp.ok;
 }
 
@@ -908,7 +935,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
       const bool from_pairs = (li == 1) && !prod;
       GemmParams p = gp_zero();
       p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
-      p.W = hd->w[li]; p.ldw = h;
+      p.W = hd->w[li]; p.ldw = h; p.wsplit = w.wsplit;
       if (from_pairs) {
         p.A = w.A1; p.lda = h; p.A2 = w.B1 + (long)j0 * h; p.lda2 = h; p.pairB = B;
       } else {
@@ -1372,6 +1399,7 @@ struct PairTrainWs {
   size_t part_floats;
   ColScr colscr;
   StatScr statscr;
+  uint16_t* wsplit;  // bf16x3 mode: hi / lo planes of the weight operand of the current pair-grid GEMM
 };
 static const long PAIR_STATS_ROWS = 4096;
 static const int SUM_BLOCKS = 1024;
@@ -1399,6 +1427,7 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.dB1 = bp.take<float>((size_t)NL * h);
   colscr_carve(bp, (long)B * NL, h, w.colscr);
   statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
+  w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
   return bp.ok;
 }
 
@@ -1516,7 +1545,7 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     GemmParams p = gp_zero();
     p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
     p.W = hd->w[l]; p.ldw = h; p.C = z; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
-    p.col_part = w.colscr.part; p.col_red = w.colscr.red;
+    p.col_part = w.colscr.part; p.col_red = w.colscr.red; p.wsplit = w.wsplit;
     if (l == 1 && !prod) {
       p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
       PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
@@ -1629,7 +1658,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       GemmParams p = gp_zero();
       p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
       p.A = dz + (size_t)r0 * h; p.lda = h;
-      p.W = w.WT; p.ldw = h;
+      p.W = w.WT; p.ldw = h; p.wsplit = w.wsplit;
       p.C = sv.zbuf[l] + (size_t)r0 * h; p.ldc = h;
       PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
     }

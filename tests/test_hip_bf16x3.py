@@ -328,3 +328,48 @@ def test_bf16x3_map_parity(bf16x3):
     ma_ref = MO.macro_mean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)])
     assert 0.2 < mi_ref < 0.99
     assert abs(m["map_micro"] - mi_ref) < 1e-4 and abs(m["map_macro"] - ma_ref) < 2e-4, (m, mi_ref, ma_ref)
+
+
+def test_bf16x3_weight_dma_bit_identical_train_step():
+    """bf16x3 mode, 64 x 1040 pair grid at full width: staging the pre-split weight planes by LDS-DMA
+    (pn_set_b3_dma(1), default) gives bit-identical logits and gradients to the register-staged kernels - the same
+    hi / lo values meet the same products in the same order; only the path into the LDS differs."""
+    import protnote_amd
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+    from tests.helpers import random_head_sd
+
+    gen = torch.Generator().manual_seed(78)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1040
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+
+    def run(dma):
+        L.check(L.lib().pn_set_b3_dma(dma))
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        return [logits.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+
+    protnote_amd.set_math_mode("bf16x3")
+    try:
+        a, b = run(1), run(0)
+        model.eval()
+        with torch.no_grad():
+            e1 = model(sequence_embeddings=P_f, label_embeddings=lab)[0]
+            L.check(L.lib().pn_set_b3_dma(1))
+            e2 = model(sequence_embeddings=P_f, label_embeddings=lab)[0]
+    finally:
+        L.lib().pn_set_b3_dma(1)
+        protnote_amd.set_math_mode("f32")
+    assert float(a[0].std()) > 0.1 and torch.equal(e1, e2)
+    for i, (x, z) in enumerate(zip(a, b)):
+        assert torch.equal(x, z), (i, (x - z).abs().max().item())
