@@ -78,6 +78,12 @@ typedef struct pn_mlp {
   const float* bias[PN_MAX_LAYERS]; /* or NULL */
   pn_bn bn[PN_MAX_LAYERS];          /* BN after layer i for i < nlayers-1 (weight==NULL: no BN) */
   float bn_eps, bn_momentum;
+  /* training only: Dropout(p) after every hidden ReLU AND after the last Linear (torchvision.ops.MLP, reference
+   * ProtNote.py:63-81 with dropout=OUTPUT_MLP_DROPOUT).  Masks are a counter-based hash of (dropout_seed, layer, row,
+   * column): the caller draws a fresh seed per forward and passes the SAME seed to the backward. */
+  float dropout_p;
+  unsigned dropout_seed;
+  int dropout_stream; /* base of this stack's mask streams: 100 for W_p, 200 for W_l (pn_dropout_mask) */
 } pn_mlp;
 
 size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows);
@@ -100,6 +106,10 @@ typedef struct pn_pairhead {
   const float* w_out; /* [h] */
   const float* b_out; /* [1] */
   float bn_eps, bn_momentum;
+  /* training only: Dropout(p) after the ReLU of every hidden layer except the last (get_mlp, ProtNote.py:369-371);
+   * generated inside the operand loaders of the next GEMM and regenerated in the backward from the same seed */
+  float dropout_p;
+  unsigned dropout_seed;
 } pn_pairhead;
 
 size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);
@@ -294,6 +304,11 @@ int pn_set_f32_dma(int on);
 /* Same switch for the bf16x3 pair-grid GEMMs (weight operand pre-split into bf16 hi / lo planes and staged by LDS-DMA;
  * env PN_B3_DMA). */
 int pn_set_b3_dma(int on);
+
+/* The dropout keep-mask the kernels generate for (seed, stream, rows x cols): out[r][c] = 1.0 (kept) or 0.0, so a
+ * test can hand the oracle the very same masks.  stream: row MLP hidden layer l -> base + l, its output -> base + 99
+ * (base 100 for W_p, 200 for W_l); pair-head hidden layer l -> 300 + l.  A pair-grid row is r = j * B + i. */
+int pn_dropout_mask(unsigned seed, int stream, float p, long rows, int cols, float* out, void* stream_);
 
 /* ---- measurement hook (bench.py `roofline`): between begin and end every GEMM-engine launch is bracketed
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind

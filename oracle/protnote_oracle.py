@@ -100,19 +100,26 @@ def _linear_indices(sd: SD, prefix: str):
     return idx
 
 
-def mlp_rows(sd: SD, prefix: str, x: Tensor, training: bool) -> Tensor:
+def mlp_rows(sd: SD, prefix: str, x: Tensor, training: bool, masks: Optional[dict] = None) -> Tensor:
     """torchvision.ops.MLP as built at ProtNote.py:63-81: (Linear no-bias, BN(eps 1e-5, mom 0.1), ReLU,
-    Dropout(0)) x (n-1), Linear no-bias, Dropout(0)."""
+    Dropout(p)) x (n-1), Linear no-bias, Dropout(p).  `masks` (training with dropout > 0): the Dropout draws as
+    multiplicative tensors keep / (1 - p), keyed f"{prefix}{n}" for hidden layer n and f"{prefix}out" for the output."""
     lin = _linear_indices(sd, prefix)
     for n, i in enumerate(lin):
         x = F.linear(x, sd[f"{prefix}{i}.weight"], sd.get(f"{prefix}{i}.bias"))
         if n < len(lin) - 1:
             x = F.relu(_bn(x, sd, f"{prefix}{i + 1}.", training, 1e-5, 0.1))
+            if masks is not None:
+                x = x * masks[f"{prefix}{n}"]
+        elif masks is not None:
+            x = x * masks[f"{prefix}out"]
     return x
 
 
-def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool) -> Tensor:
-    """get_mlp ProtNote.py:337-378 with batch_norm=True: (Linear no-bias, BN, ReLU[, Dropout]) x n, Linear(h,1)."""
+def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool, masks: Optional[dict] = None) -> Tensor:
+    """get_mlp ProtNote.py:337-378 with batch_norm=True: (Linear no-bias, BN, ReLU[, Dropout]) x n, Linear(h,1); the
+    Dropout follows every hidden layer except the last (:369-371).  `masks`: keep / (1 - p) tensors keyed
+    f"{prefix}{n}" with rows in the joint tensor's protein-major order."""
     lin = _linear_indices(sd, prefix)
     for n, i in enumerate(lin):
         x = F.linear(x, sd[f"{prefix}{i}.weight"], sd.get(f"{prefix}{i}.bias"))
@@ -120,6 +127,8 @@ def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool) -> Tensor:
             if f"{prefix}{i + 1}.running_mean" in sd:
                 x = _bn(x, sd, f"{prefix}{i + 1}.", training, 1e-5, 0.1)
             x = F.relu(x)
+            if masks is not None and n < len(lin) - 2:
+                x = x * masks[f"{prefix}{n}"]
     return x
 
 
@@ -155,7 +164,7 @@ def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], 
                      noise_u: Optional[Tensor] = None, label_token_counts: Optional[Tensor] = None,
                      dilation_base: int = 3, sequence_embeddings: Optional[Tensor] = None,
                      aux: Optional[dict] = None, train_sequence_encoder: bool = False,
-                     attention_mask: Optional[Tensor] = None) -> Tensor:
+                     attention_mask: Optional[Tensor] = None, dropout_masks: Optional[dict] = None) -> Tensor:
     """ProtNote.forward (ProtNote.py:168-334), cached-label-embedding path; the encoder runs under no_grad unless
     train_sequence_encoder and training (ProtNote.py:248-260).  `attention_mask` given = LABEL_EMBEDDING_POOLING_METHOD
     'all': label_embeddings are token embeddings [N, T, d], pooled AFTER the noise (ProtNote.py:266-267)."""
@@ -171,15 +180,15 @@ def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], 
     else:
         with torch.no_grad():
             P_f = proteinfer_get_embeddings(sd, onehots, lens, training, dilation_base, "sequence_encoder.")
-    P_e = mlp_rows(sd, "W_p.", P_f, training)
-    L_e = mlp_rows(sd, "W_l.", L_f, training)
+    P_e = mlp_rows(sd, "W_p.", P_f, training, dropout_masks)
+    L_e = mlp_rows(sd, "W_l.", L_f, training, dropout_masks)
     if aux is not None:
         aux.update(P_f=P_f, P_e=P_e, L_e=L_e)
     b, n = P_e.shape[0], L_e.shape[0]
     if fusion == "similarity":
         logits = torch.mm(F.normalize(P_e, dim=-1, p=2), F.normalize(L_e, dim=-1, p=2).t()) / temperature
     elif fusion.startswith("concatenation"):
-        logits = output_mlp(sd, "output_layer.", joint_embeddings(P_e, L_e, fusion), training)
+        logits = output_mlp(sd, "output_layer.", joint_embeddings(P_e, L_e, fusion), training, dropout_masks)
     else:
         raise ValueError("feature fusion method not implemented")
     if training or descriptions_per_label == 1:
@@ -289,7 +298,7 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                clip: Optional[float] = 1.0, lr: float = 3e-4, dilation_base: int = 3,
                adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
                train_sequence_encoder: bool = False, attention_mask: Optional[Tensor] = None,
-               **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+               dropout_masks: Optional[dict] = None, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
     """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU).
 
     Updates `sd` in place (params by Adam, BN buffers by the train-mode forward).
@@ -301,7 +310,8 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
     logits = protnote_forward(work, onehots, lens, label_embeddings, fusion=fusion, training=True,
                               noise_alpha=noise_alpha, noise_u=noise_u, temperature=temperature,
                               label_token_counts=label_token_counts, dilation_base=dilation_base,
-                              train_sequence_encoder=train_sequence_encoder, attention_mask=attention_mask)
+                              train_sequence_encoder=train_sequence_encoder, attention_mask=attention_mask,
+                              dropout_masks=dropout_masks)
     y = multihots.float()
     l = bce_loss(logits, y, **loss_kw) if loss == "BCE" else focal_loss(logits, y, **loss_kw)
     grads_t = torch.autograd.grad(l, [leaves[k] for k in names], allow_unused=True)

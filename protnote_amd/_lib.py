@@ -35,14 +35,15 @@ class pn_encoder(C.Structure):
 class pn_mlp(C.Structure):
     _fields_ = [("nlayers", C.c_int), ("dims", C.c_int * (PN_MAX_LAYERS + 1)),
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
-                ("bn", pn_bn * PN_MAX_LAYERS), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+                ("bn", pn_bn * PN_MAX_LAYERS), ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint), ("dropout_stream", C.c_int)]
 
 
 class pn_pairhead(C.Structure):
     _fields_ = [("d", C.c_int), ("in_dim", C.c_int), ("fusion", C.c_int), ("nlayers", C.c_int), ("h", C.c_int),
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
-                ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint)]
 
 
 class pn_res_block_grads(C.Structure):
@@ -140,6 +141,7 @@ _SIGS = {
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pn_binned_auprc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_void_p]),
+    "pn_dropout_mask": (C.c_int, [C.c_uint, C.c_int, C.c_float, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_set_math_mode": (C.c_int, [C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),

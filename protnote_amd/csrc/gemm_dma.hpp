@@ -40,8 +40,9 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
 
-template <int AK, int EK>
+template <int AK, int EK, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p) {
+  static_assert(!DROP || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "dropout applies to the hidden activations");
   constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, WN = 4, BK = 32;
   constexpr int BM = 256, BN = 256;
   constexpr bool A_DMA = (AK == A_PLAIN);
@@ -95,12 +96,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   const float* arow[NQA];
   const float* arow2[NQA];
   int aoff[NQA];
+  uint32_t a_key[NQA];  // DROP: per-row key of the dropout hash (gemm_engine.hpp)
+  int a_col = 0;
   if constexpr (!A_DMA) {
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       const int rl = r_in + q * RPP;
       int r = row0 + rl;
       if (r > p.M - 1) r = p.M - 1;
+      a_key[q] = DROP ? drop_rowkey(p.drop_seed, (uint32_t)r) : 0u;
       if constexpr (AK == A_PAIRSUM_RELU) {
         const int j = r / p.pairB;
         const int i = r - j * p.pairB;
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   float4 rsc = make_float4(0, 0, 0, 0), rsh = rsc;
   auto fetch_a = [&](int s) {
     const int c = s * BK;
+    if constexpr (DROP) a_col = c + 4 * kv;
 #pragma unroll
     for (int q = 0; q < NQA; ++q) {
       ra[q] = ld4(arow[q] + c);
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
         v.z = relu(v.z + ra2[q].z);
         v.w = relu(v.w + ra2[q].w);
       }
+      if constexpr (DROP) v = drop4(v, a_key[q], (uint32_t)a_col, p.drop_thresh, p.drop_scale);
       *reinterpret_cast<float4*>(As + aoff[q]) = v;
     }
   };

@@ -83,6 +83,11 @@ struct GemmParams {
   long ldp1;
   const float* padd2;
   long ldp2;
+  // ---- inter-layer dropout of the A operand (training with OUTPUT_MLP_DROPOUT > 0; DROP kernels only):
+  //      A[r][k] *= keep(drop_seed, r, k) ? drop_scale : 0, a counter-based hash of (seed, row, column) - the
+  //      backward regenerates the same mask from the same seed (nothing is stored)
+  uint32_t drop_seed, drop_thresh;  // thresh = round(p * 2^32); 0 = no dropout
+  float drop_scale;                 // 1 / (1 - p)
   uint16_t* wsplit;      // optional scratch, 2 * N * Kseg bf16: bf16x3 mode pre-splits W into hi / lo planes there and
   const uint16_t* w_hi;  // stages them by LDS-DMA (set by the launcher from wsplit)
   const uint16_t* w_lo;
@@ -91,6 +96,31 @@ struct GemmParams {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+
+// ---- dropout masks: a pure function of (seed, row, column), so forward, backward and the tests (pn_dropout_mask)
+// all see the same Bernoulli(1 - p) draw.  lowbias32 (a well-mixed 32-bit integer hash) of the row with the seed
+// gives a per-row key; hashing key + column * golden-ratio gives the element's uniform 32-bit draw.
+__host__ __device__ __forceinline__ uint32_t pn_lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed, uint32_t row) {
+  return pn_lowbias32(row ^ seed) + seed;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {
+  return pn_lowbias32(rowkey + col * 0x9E3779B1U) >= thresh;
+}
+__device__ __forceinline__ float4 drop4(float4 v, uint32_t rowkey, uint32_t col, uint32_t thresh, float scale) {
+  v.x = drop_keep(rowkey, col, thresh) ? v.x * scale : 0.f;
+  v.y = drop_keep(rowkey, col + 1, thresh) ? v.y * scale : 0.f;
+  v.z = drop_keep(rowkey, col + 2, thresh) ? v.z * scale : 0.f;
+  v.w = drop_keep(rowkey, col + 3, thresh) ? v.w * scale : 0.f;
+  return v;
+}
 
 // Make a fetched register quad opaque at this point of the program: the transform math that consumes it
 // cannot be hoisted above (DAG linearisation otherwise floats it in front of the MFMA block, dragging the
@@ -246,8 +276,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   }
 }
 
-template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool DROP = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel(const GemmParams p) {
+  static_assert(!DROP || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "dropout applies to the hidden activations");
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;
   constexpr int BN = WAVES_N * WN * 32;
@@ -280,10 +311,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
   const float* arow2[NQA];
   int a_t[NQA], a_len[NQA];
   float a_g[NQA];
+  uint32_t a_key[NQA];  // DROP: per-row key of the dropout hash
+  int a_col = 0;        // DROP: column of the quad being staged
 #pragma unroll
   for (int q = 0; q < NQA; ++q) {
     int r = row0 + r_in + q * RPP;
     if (r > p.M - 1) r = p.M - 1;  // clamp: duplicates are discarded by the epilogue
+    a_key[q] = DROP ? drop_rowkey(p.drop_seed, (uint32_t)r) : 0u;
     if constexpr (AK == A_PAIRSUM_RELU || AK == A_PAIRPROD) {
       const int j = r / p.pairB;
       const int i = r - j * p.pairB;
@@ -331,6 +365,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
     const int c = (s - seg * spt) * BK + 4 * kv;
     const bool kok = c < p.Kseg;
     const int cc = kok ? c : 0;
+    if constexpr (DROP) a_col = cc;
     avalid = 0;
     if constexpr (AK == A_CONV) {
       const int sh = (seg - p.nseg / 2) * p.dil;
@@ -438,6 +473,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, PN_MINW) void gemm_nt_kernel
           v.w = relu(fmaf(v.w, rsc.w, rsh.w));
         }
       }
+      if constexpr (DROP) v = drop4(v, a_key[q], (uint32_t)a_col, p.drop_thresh, p.drop_scale);
       *reinterpret_cast<float4*>(As + (r_in + q * RPP) * LDK + 4 * kv) = sel4(ok, v);
     }
   };

@@ -43,6 +43,9 @@ struct TnParams {
   const int* lens;  // TB_CONVTAP: int32 sequence lengths
   int L;            //             positions per sequence
   int shift;        //             (tap - k/2) * dilation
+  // ---- inter-layer dropout of the B operand (DROP kernels; same hash as GemmParams::drop_*): B[r][n] *= keep ? scale : 0
+  uint32_t drop_seed, drop_thresh;
+  float drop_scale;
   // ---- output ----
   float* Cpart;  // [nsplit][M][ldc]
   long ldc;
@@ -65,9 +68,10 @@ __device__ __forceinline__ void tn_glds16(const float* gsrc, unsigned lds_base_u
 // LDS by LDS-DMA, one 1 KiB tile row per wave-instruction, instead of through registers; the generated B operand keeps
 // the register path.  A(t+1) is issued at the top of slab t into the idle buffer and waited for (together with the
 // B(t+1) registers) in the middle of the slab; the barrier at the end of the slab publishes it.
-template <int TA, int TB, bool BIG, bool ADMA = false>
+template <int TA, int TB, bool BIG, bool ADMA = false, bool DROP = false>
 __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnParams p) {
   static_assert(!ADMA || (BIG && TA == TA_PLAIN), "LDS-DMA staging is for the plain A operand of the big tile");
+  static_assert(!DROP || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "dropout applies to the hidden activations");
   constexpr int BM = BIG ? 256 : 128, BN = BIG ? 256 : 128, BK = 32;
   constexpr int NGN = BIG ? 2 : 1;        // 64-column groups per wave along n
   constexpr int C4 = BM / 4;              // float4 per tile row (BM == BN)
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
 
   float4 ra[NQ], rg[NQ], rb[NQ], rb2[NQ];
   unsigned rowok = 0, rowok_b = 0, tapok = 0;
+  uint32_t b_key[NQ];  // DROP: per-row keys of the rows being staged
 
   // branch-free fetch: rows past the split end are clamped to the split's first row and zeroed by selects in
   // commit().  The pair-grid decode (i = r % B, j = r / B) of the thread's first row is carried incrementally
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
       const bool ok = r < r_end;
       rowok_b |= (ok ? 1u : 0u) << q;
       r = ok ? r : r_begin;
+      if constexpr (DROP) b_key[q] = drop_rowkey(p.drop_seed, (uint32_t)r);
       if constexpr (TB == TB_PAIRSUM_RELU || TB == TB_PAIRPROD) {
         unsigned i = pi0 + 8 * q, j = pj0;
         while (i >= pB) {  // at most one iteration when B >= 24
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
         b.z = relu(b.z + rb2[q].z);
         b.w = relu(b.w + rb2[q].w);
       }
+      if constexpr (DROP) b = drop4(b, b_key[q], (uint32_t)bn, p.drop_thresh, p.drop_scale);
       *reinterpret_cast<float4*>(Bs + (rr + 8 * q) * LDN + 4 * c4) = sel4(bok, b);
     }
   };

@@ -190,12 +190,48 @@ static int finish_col_stats(const GemmParams& p, long tm, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// inter-layer dropout (training): mask = hash(seed ^ stream, row, column), see gemm_engine.hpp
+// ------------------------------------------------------------------------------------------------
+struct DropSpec {
+  uint32_t seed, thresh;
+  float scale;
+};
+static DropSpec drop_spec(float p, unsigned base_seed, int stream) {
+  DropSpec d = {0u, 0u, 1.f};
+  if (p <= 0.f) return d;
+  d.seed = base_seed ^ ((uint32_t)stream * 0x9E3779B9u);
+  double th = (double)p * 4294967296.0 + 0.5;
+  d.thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+  if (d.thresh == 0) d.thresh = 1;  // p > 0 must keep the "dropout on" meaning of a non-zero threshold
+  d.scale = 1.f / (1.f - p);
+  return d;
+}
+enum { DROP_STREAM_WP = 100, DROP_STREAM_WL = 200, DROP_STREAM_PAIR = 300, DROP_STREAM_OUT = 99 };
+
+template <int MODE>
+static int launch_dropout(const float* X, long ldx, float* out, long ldo, long R, int C, const float* s, const float* t,
+                          const DropSpec& d, hipStream_t st) {
+  if (C % 4) return fail("dropout: width %d not a multiple of 4", C);
+  const long rpb = 256;
+  hipLaunchKernelGGL((k_dropout<MODE>), dim3(nblk(C, 1024), nblk(R, rpb)), dim3(256), 0, st, X, ldx, out, ldo, R, C, s, t,
+                     d.seed, d.thresh, d.scale, rpb);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_dropout_mask(unsigned seed, int stream, float p, long rows, int cols, float* out, void* stream_) {
+  if (p <= 0.f || p >= 1.f) return fail("dropout_mask: p must be in (0, 1)");
+  return launch_dropout<2>(nullptr, 0, out, cols, rows, cols, nullptr, nullptr, drop_spec(p, seed, stream),
+                           (hipStream_t)stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
 // GEMM launch
 // ------------------------------------------------------------------------------------------------
-template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK>
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool DROP = false>
 static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   using Cfg = GemmCfg<WAVES_M, WAVES_N, WM, WN, BK>;
-  auto kern = gemm_nt_kernel<AK, EK, WAVES_M, WAVES_N, WM, WN, BK>;
+  auto kern = gemm_nt_kernel<AK, EK, WAVES_M, WAVES_N, WM, WN, BK, DROP>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -317,9 +353,9 @@ extern "C" int pn_set_f32_dma(int on) {
   return 0;
 }
 
-template <int AK, int EK>
+template <int AK, int EK, bool DROP = false>
 static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_nt_dma_kernel<AK, EK>;
+  auto kern = gemm_nt_dma_kernel<AK, EK, DROP>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -355,6 +391,16 @@ static int rowdot_nparts(int n);
 #endif
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
+  if (p.drop_thresh != 0) {  // dropped hidden activations (training): f32 engines with the mask in the A loader
+    if constexpr ((AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && EK == E_STORE) {
+      if (PN_BIG && use_f32_dma() && variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 &&
+          p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0)
+        return launch_gemm_dma<AK, EK, true>(p, st);
+      return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK, true>(p, st);
+    } else {
+      return fail("gemm: dropout is not defined for operand kind %d / epilogue %d", AK, EK);
+    }
+  }
   if (g_math_mode == 1 && PN_BIG) {  // opt-in bf16x3 arithmetic (gemm_bf16x3.hpp)
     if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
       // pair-grid shapes: no masks needed
@@ -1065,9 +1111,9 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile,
   return (int)ns;
 }
 
-template <int TA, int TB, bool BIG, bool ADMA = false>
+template <int TA, int TB, bool BIG, bool ADMA = false, bool DROP = false>
 static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_kernel<TA, TB, BIG, ADMA>;
+  auto kern = gemm_tn_kernel<TA, TB, BIG, ADMA, DROP>;
   constexpr int TILE = BIG ? 256 : 128;
   constexpr int LDS = BIG ? TN_LDS_BYTES_BIG : TN_LDS_BYTES;
   static bool attr_done[64] = {false};
@@ -1146,6 +1192,15 @@ template <int TA, int TB>
 static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   if (p.M % 4 || p.N % 4) return fail("gemm_tn: M and N must be multiples of 4");
   if (p.R <= 0) return fail("gemm_tn: empty contraction");
+  if (p.drop_thresh != 0) {  // dropped hidden activations as the B operand (training): f32 kernels, mask in the loader
+    if constexpr (TA == TA_PLAIN && (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
+      if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 && p.R % 32 == 0 && p.lda % 4 == 0)
+        return launch_tn_cfg<TA, TB, true, true, true>(p, dst, ldd, part, part_cap_floats, st);
+      return launch_tn_cfg<TA, TB, false, false, true>(p, dst, ldd, part, part_cap_floats, st);
+    } else {
+      return fail("gemm_tn: dropout is not defined for operand kinds %d x %d", TA, TB);
+    }
+  }
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
     if (g_math_mode == 1 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
         (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0))
@@ -1176,6 +1231,7 @@ static const size_t TN_PART_FLOATS_MAX = (size_t)16 * 3072 * 3072;
 // ------------------------------------------------------------------------------------------------
 struct MlpSave {
   float* Y[PN_MAX_LAYERS];
+  float* H[PN_MAX_LAYERS];  // dropout > 0: the dropped activations relu(bn(Y_l)) * mask, materialised (small tensors)
   float *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS], *mean[PN_MAX_LAYERS], *invstd[PN_MAX_LAYERS];
 };
 
@@ -1183,6 +1239,7 @@ static bool mlp_save_carve(const pn_mlp* m, int rows, Bump& bp, MlpSave& s) {
   for (int l = 0; l + 1 < m->nlayers; ++l) {
     const int h = m->dims[l + 1];
     s.Y[l] = bp.take<float>((size_t)rows * h);
+    s.H[l] = m->dropout_p > 0.f ? bp.take<float>((size_t)rows * h) : nullptr;
     s.s[l] = bp.take<float>(h);
     s.t[l] = bp.take<float>(h);
     s.mean[l] = bp.take<float>(h);
@@ -1208,6 +1265,7 @@ static bool mlp_train_ws_carve(const pn_mlp* m, int rows, Bump& bp, MlpTrainWs& 
     const size_t e = (size_t)m->dims[l] * m->dims[l + 1];
     if (e > wmax) wmax = e;
   }
+  if (m->dropout_p > 0.f && m->dims[m->nlayers] > hmax) hmax = m->dims[m->nlayers];  // dy * mask scratch
   if (hmax == 0) hmax = 4;
   w.S1 = bp.take<double>(hmax);
   w.S2 = bp.take<double>(hmax);
@@ -1240,6 +1298,7 @@ extern "C" size_t pn_mlp_rows_train_ws_bytes(const pn_mlp* m, int rows) {
 
 static int mlp_check(const pn_mlp* m, int ldx) {
   if (m->nlayers < 1 || m->nlayers > PN_MAX_LAYERS) return fail("mlp: bad layer count %d", m->nlayers);
+  if (m->dropout_p < 0.f || m->dropout_p >= 1.f) return fail("mlp: dropout_p %g outside [0, 1)", m->dropout_p);
   for (int i = 0; i <= m->nlayers; ++i)
     if (m->dims[i] % 4 != 0) return fail("mlp: dims[%d]=%d not a multiple of 4", i, m->dims[i]);
   if (ldx % 4 != 0) return fail("mlp: ldx %% 4 != 0");
@@ -1262,6 +1321,8 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
   if (!mlp_train_ws_carve(m, rows, bw, w)) return fail("mlp train: workspace too small");
   const float* in = x;
   long ldin = ldx;
+  const bool drop = m->dropout_p > 0.f;
+  bool in_is_act = false;  // `in` already holds activations (dropout path) instead of pre-activations
   for (int l = 0; l < m->nlayers; ++l) {
     const bool last = (l + 1 == m->nlayers);
     const int N = m->dims[l + 1];
@@ -1272,7 +1333,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
     if (!last) {
       p.col_sum = w.S1; p.col_sumsq = w.S2; p.col_part = w.colscr.part; p.col_red = w.colscr.red;
     }
-    if (l == 0) {
+    if (l == 0 || in_is_act) {
       PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(N), st)));
     } else {
       p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
@@ -1283,8 +1344,18 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
                          (const double*)w.S2, (double)rows, m->bn_eps, m->bn_momentum, N, N, sv.s[l], sv.t[l],
                          sv.mean[l], sv.invstd[l]);
       HIP_OK(hipGetLastError());
-      in = sv.Y[l];
+      if (drop) {  // H_l = relu(bn(Y_l)) * mask / (1 - p), the next layer's plain operand
+        PN_OK(launch_dropout<1>(sv.Y[l], N, sv.H[l], N, rows, N, sv.s[l], sv.t[l],
+                                drop_spec(m->dropout_p, m->dropout_seed, m->dropout_stream + l), st));
+        in = sv.H[l];
+        in_is_act = true;
+      } else {
+        in = sv.Y[l];
+      }
       ldin = N;
+    } else if (drop) {  // Dropout after the last Linear (torchvision.ops.MLP)
+      PN_OK(launch_dropout<0>(y, N, y, N, rows, N, nullptr, nullptr,
+                              drop_spec(m->dropout_p, m->dropout_seed, m->dropout_stream + DROP_STREAM_OUT), st));
     }
   }
   return 0;
@@ -1304,10 +1375,20 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
   const float* G = dy;  // gradient wrt the OUTPUT of layer l's Linear ... see below
   long ldg = m->dims[n];
   int gsel = 0;
+  const bool drop = m->dropout_p > 0.f;
+  if (drop) {  // Dropout after the last Linear: dY = dy * mask (into scratch: dy is the caller's)
+    PN_OK(launch_dropout<0>(dy, ldg, w.G[gsel], ldg, rows, m->dims[n], nullptr, nullptr,
+                            drop_spec(m->dropout_p, m->dropout_seed, m->dropout_stream + DROP_STREAM_OUT), st));
+    G = w.G[gsel];
+    gsel ^= 1;
+  }
   for (int l = n - 1; l >= 0; --l) {
     const int K = m->dims[l], N = m->dims[l + 1];
     const bool last = (l == n - 1);
     // For the last layer G = dY (plain).  For hidden layers G = d(relu(bn(Y_l))) and dY_l is generated.
+    if (!last && drop)  // G is the gradient wrt the DROPPED activation: through the mask first (in place, our scratch)
+      PN_OK(launch_dropout<0>(G, ldg, const_cast<float*>(G), ldg, rows, N, nullptr, nullptr,
+                              drop_spec(m->dropout_p, m->dropout_seed, m->dropout_stream + l), st));
     if (!last) {
       StatsParams sp;
       memset(&sp, 0, sizeof(sp));
@@ -1333,8 +1414,8 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
       tp.A = sv.Y[l]; tp.lda = N; tp.G = G; tp.ldg = ldg;
       tp.m_s = sv.s[l]; tp.m_t = sv.t[l]; tp.m_cs = w.cs; tp.m_p = w.p; tp.m_q = w.q;
     }
-    if (l == 0) {
-      tp.B = x; tp.ldb = ldx;
+    if (l == 0 || drop) {  // plain B operand: the input rows, or the materialised dropped activation H_{l-1}
+      tp.B = l == 0 ? x : sv.H[l - 1]; tp.ldb = l == 0 ? ldx : K;
       if (last) PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
       else PN_OK((launch_tn<TA_DZ_ELEM, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
     } else {
@@ -1456,6 +1537,7 @@ static int pair_check(const pn_pairhead* hd, int B, int NL) {
   if (hd->fusion < 0 || hd->fusion > 2) return fail("pairhead: fusion %d not implemented", hd->fusion);
   if (hd->d % 4 || hd->h % 4) return fail("pairhead: d and h must be multiples of 4");
   if ((long)B * NL > 0x7fffffffL) return fail("pairhead: pair grid too large");
+  if (hd->dropout_p < 0.f || hd->dropout_p >= 1.f) return fail("pairhead: dropout_p %g outside [0, 1)", hd->dropout_p);
   for (int l = 0; l < hd->nlayers; ++l) {
     if (hd->bn[l].weight != nullptr && hd->bias[l] != nullptr)
       return fail("pairhead: Linear bias together with BatchNorm is not supported");
@@ -1546,6 +1628,10 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
     p.W = hd->w[l]; p.ldw = h; p.C = z; p.ldc = h; p.col_sum = w.S1; p.col_sumsq = w.S2;
     p.col_part = w.colscr.part; p.col_red = w.colscr.red; p.wsplit = w.wsplit;
+    {  // the input h_{l-1} of this layer went through Dropout (get_mlp: after every hidden ReLU but the last)
+      const DropSpec ds = drop_spec(hd->dropout_p, hd->dropout_seed, DROP_STREAM_PAIR + (l - 1));
+      p.drop_seed = ds.seed; p.drop_thresh = ds.thresh; p.drop_scale = ds.scale;
+    }
     if (l == 1 && !prod) {
       p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
       PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
@@ -1636,10 +1722,12 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       HIP_OK(hipGetLastError());
     }
 
-    // dW_l = dz_l^T h_{l-1}
+    // dW_l = dz_l^T h_{l-1}   (h_{l-1} = dropped activation: the B loader regenerates the mask)
     TnParams tp = tn_zero();
     tp.R = R; tp.M = h; tp.N = h;
     tp.A = dz; tp.lda = h;
+    const DropSpec ds_in = drop_spec(hd->dropout_p, hd->dropout_seed, DROP_STREAM_PAIR + (l - 1));
+    tp.drop_seed = ds_in.seed; tp.drop_thresh = ds_in.thresh; tp.drop_scale = ds_in.scale;
     if (l == 1 && hd->fusion != 2) {
       tp.B = sv.Ap; tp.ldb = h; tp.B2 = sv.Bp; tp.ldb2 = h; tp.pairB = B;
       PN_OK((launch_tn<TA_PLAIN, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
@@ -1663,6 +1751,8 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
     }
     G = sv.zbuf[l];
+    if (hd->dropout_p > 0.f)  // G = gradient wrt the DROPPED h_{l-1}: through the mask (one streaming pass, in place)
+      PN_OK(launch_dropout<0>(G, h, sv.zbuf[l], h, R, h, nullptr, nullptr, ds_in, st));
   }
 
   // ---- layer 0: upstream gradient G = dh_0 over the pair grid ----

@@ -209,6 +209,41 @@ __global__ __launch_bounds__(256) void k_dz_apply(const DzParams P) {
   }
 }
 
+// ---------------- inter-layer dropout (OUTPUT_MLP_DROPOUT > 0 in training; reference ProtNote.py:63-81,369-371) -------
+// The mask is the counter-based hash of gemm_engine.hpp (drop_rowkey / drop_keep): nothing is stored, every consumer
+// regenerates it from (seed, row, column).
+// MODE 0: X[r][c] *= mask(r, c) * scale in place        (upstream gradient of a dropped activation; output dropout)
+// MODE 1: out[r][c] = relu(s[c] * X[r][c] + t[c]) * mask * scale   (materialised dropped activation of a row MLP)
+// MODE 2: out[r][c] = mask(r, c) ? 1 : 0                (pn_dropout_mask: what the tests hand to the oracle)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dropout(const float* __restrict__ X, long ldx, float* __restrict__ out, long ldo,
+                                                 long R, int C, const float* __restrict__ s, const float* __restrict__ t,
+                                                 uint32_t seed, uint32_t thresh, float scale, long rows_per_block) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  float4 sv = make_float4(1, 1, 1, 1), tv = make_float4(0, 0, 0, 0);
+  if constexpr (MODE == 1) {
+    sv = ld4(s + c);
+    tv = ld4(t + c);
+  }
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+#pragma unroll 4
+  for (long r = r0; r < r1; ++r) {
+    const uint32_t key = drop_rowkey(seed, (uint32_t)r);
+    float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (MODE != 2) v = ld4(X + r * ldx + c);
+    if constexpr (MODE == 1) {
+      v.x = relu(fmaf(v.x, sv.x, tv.x));
+      v.y = relu(fmaf(v.y, sv.y, tv.y));
+      v.z = relu(fmaf(v.z, sv.z, tv.z));
+      v.w = relu(fmaf(v.w, sv.w, tv.w));
+    }
+    *reinterpret_cast<float4*>(out + r * ldo + c) = drop4(v, key, (uint32_t)c, thresh, MODE == 2 ? 1.f : scale);
+  }
+}
+
 // ---------------- encoder backward helpers (TRAIN_SEQUENCE_ENCODER) ----------------
 // gradient of the masked mean-pool (protein_encoders.py:114-117): g[p][c] = t < len ? demb[b][c] / len : 0
 __global__ void k_pool_bwd(const float* __restrict__ demb, int ld_emb, const int* __restrict__ lens, int L, int C,

@@ -81,11 +81,10 @@ def _split_layers(seq):
             out.append([m, None])
         elif isinstance(m, nn.BatchNorm1d):
             out[-1][1] = m
-        elif isinstance(m, nn.Dropout) and m.p > 0 and m.training and out:
-            # (a Dropout in FRONT of the first Linear is the embedding dropout of reference ProtNote.py:83-86; the
-            # train path applies it to the input rows, see input_dropout_p)
-            raise NotImplementedError("dropout > 0 between the layers of an MLP (OUTPUT_MLP_DROPOUT) is not "
-                                      "implemented in protnote_amd")
+        # nn.Dropout entries are containers only: a Dropout in FRONT of the first Linear is the embedding dropout of
+        # reference ProtNote.py:83-86 (applied to the input rows by the train path, see input_dropout_p); the ones
+        # BETWEEN the layers (OUTPUT_MLP_DROPOUT) are generated inside the kernels from ProtNote.mlp_dropout and a
+        # per-forward seed (pn_mlp.dropout_* / pn_pairhead.dropout_*)
     return out
 
 
@@ -118,6 +117,10 @@ class ProtNote(nn.Module):
         self.latent_dim = latent_dim
         self.label_embedding_noising_alpha = label_embedding_noising_alpha
         self.residual_connection = residual_connection
+        # OUTPUT_MLP_DROPOUT (bin/main.py:421 -> `dropout`): p of the Dropout layers inside W_p, W_l and output_layer
+        self.mlp_dropout = float(dropout)
+        if not 0.0 <= self.mlp_dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
 
         hidden = [latent_dim * projection_head_hidden_dim_scale_factor] * (projection_head_num_layers - 1) + [latent_dim]
         self.W_p = _row_mlp(protein_embedding_dim, hidden, bias=False, dropout=dropout)
@@ -144,7 +147,9 @@ class ProtNote(nn.Module):
         return dim[self.feature_fusion]
 
     # ------------------------------------------------------------------ descriptors
-    def _mlp_desc(self, seq):
+    def _mlp_desc(self, seq, drop_seed=None, drop_stream=0):
+        """`drop_seed` (training forward / its backward): enables the in-kernel Dropout(self.mlp_dropout) of this stack
+        with that seed; eval descriptors leave it off."""
         layers = _split_layers(seq)
         if len(layers) > L.PN_MAX_LAYERS:
             raise ValueError("too many projection layers")
@@ -160,9 +165,11 @@ class ProtNote(nn.Module):
             if bn is not None:
                 eps, mom = bn.eps, bn.momentum
         m.bn_eps, m.bn_momentum = eps, mom
+        if drop_seed is not None and self.mlp_dropout > 0:
+            m.dropout_p, m.dropout_seed, m.dropout_stream = self.mlp_dropout, int(drop_seed), int(drop_stream)
         return m, layers
 
-    def _pair_desc(self):
+    def _pair_desc(self, drop_seed=None):
         layers = _split_layers(self.output_layer)
         hidden, out = layers[:-1], layers[-1][0]
         hd = L.pn_pairhead()
@@ -183,6 +190,8 @@ class ProtNote(nn.Module):
         hd.w_out = out.weight.data_ptr()
         hd.b_out = out.bias.data_ptr()
         hd.bn_eps, hd.bn_momentum = eps, mom
+        if drop_seed is not None and self.mlp_dropout > 0:
+            hd.dropout_p, hd.dropout_seed = self.mlp_dropout, int(drop_seed)
         return hd, layers
 
     # ------------------------------------------------------------------ HIP stages (eval)

@@ -64,8 +64,12 @@ class _HeadsTrainFn(torch.autograd.Function):
         # exist), so a forward invalidates the previous forward's backward.  Stamp it; backward checks the stamp.
         ctx.generation = model.__dict__["_pn_train_generation"] = model.__dict__.get("_pn_train_generation", 0) + 1
         B, NL = P_f.shape[0], L_f.shape[0]
-        mp, lp = model._mlp_desc(model.W_p)
-        ml, ll = model._mlp_desc(model.W_l)
+        # OUTPUT_MLP_DROPOUT: one fresh seed per forward (host RNG: follows torch.manual_seed, no device sync); the
+        # backward regenerates the same masks from it
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model.mlp_dropout > 0 else None
+        ctx.drop_seed = seed
+        mp, lp = model._mlp_desc(model.W_p, seed, 100)
+        ml, ll = model._mlp_desc(model.W_l, seed, 200)
         ctx.P_f, ctx.L_f = P_f, L_f
 
         def mlp_fwd(m, x, tag):
@@ -86,7 +90,7 @@ class _HeadsTrainFn(torch.autograd.Function):
 
         if model.feature_fusion == "similarity":
             return model._similarity(P_e, L_e)
-        hd, hl = model._pair_desc()
+        hd, hl = model._pair_desc(seed)
         chunk = model._train_chunk(B, NL)
         ctx.chunk = chunk
         save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev)
@@ -139,7 +143,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         L.check(lib.pn_transpose(L.ptr(dlogits), NL, B, NL, L.ptr(dl_pairs), B, st))
 
         # ---- pair head ----
-        hd, hl = model._pair_desc()
+        hd, hl = model._pair_desc(ctx.drop_seed)
         hidden, out = hl[:-1], hl[-1][0]
         gr = L.pn_pairhead_grads()
         for i, (lin, bn) in enumerate(hidden):
@@ -165,7 +169,7 @@ class _HeadsTrainFn(torch.autograd.Function):
     def _finish(ctx, model, lib, st, dev, P_f, L_f, dP_e, dL_e, grads, gbuf):
         # ---- projection heads ----
         def mlp_bwd(seq, x, dy, tag, dx=None):
-            m, layers = model._mlp_desc(seq)
+            m, layers = model._mlp_desc(seq, ctx.drop_seed, 100 if tag == "W_p" else 200)
             g = L.pn_mlp_grads()
             for i, (lin, bn) in enumerate(layers):
                 g.dw[i] = gbuf(lin.weight)

@@ -970,3 +970,126 @@ def test_gemm_tn_lds_dma_vs_f64_and_register_engine(R, M, N):
         L.lib().pn_set_f32_dma(1)
     assert (got.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item() * R ** 0.5 / 8
     assert torch.equal(got, old) and torch.equal(run(1), got)
+
+
+def _dropout_masks(L, seed, p, B, NL, mlp_dims, pair_h, n_pair):
+    """The masks the kernels generate (pn_dropout_mask), scaled by 1 / (1 - p), in the oracle's key / row convention."""
+    def mask(stream, rows, cols):
+        out = torch.empty(rows, cols, dtype=torch.float32, device=DEV)
+        L.check(L.lib().pn_dropout_mask(seed, stream, p, rows, cols, L.ptr(out), L.stream_ptr()))
+        return out.cpu() / (1.0 - p)
+
+    masks = {}
+    for prefix, base, rows in (("W_p.", 100, B), ("W_l.", 200, NL)):
+        for n, h in enumerate(mlp_dims[:-1]):
+            masks[f"{prefix}{n}"] = mask(base + n, rows, h)
+        masks[f"{prefix}out"] = mask(base + 99, rows, mlp_dims[-1])
+    for n in range(n_pair - 1):  # label-major pair rows r = j * B + i -> the joint tensor's protein-major i * NL + j
+        m = mask(300 + n, NL * B, pair_h)
+        masks[f"output_layer.{n}"] = m.view(NL, B, pair_h).permute(1, 0, 2).reshape(B * NL, pair_h).contiguous()
+    return masks
+
+
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_prod"])
+def test_mlp_dropout_train_step_vs_oracle(fusion):
+    """OUTPUT_MLP_DROPOUT > 0 in training (reference ProtNote.py:63-81 via torchvision MLP, :369-371 get_mlp): Dropout
+    after every hidden ReLU of W_p / W_l AND after their last Linear, and after every hidden layer of the output MLP but
+    the last.  The kernels draw their masks from a counter-based hash; pn_dropout_mask hands the SAME masks to the CPU
+    oracle, so logits and every gradient can be compared exactly (the RNG stream itself cannot match torch's)."""
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    p = 0.3
+    kw = dict(protein_embedding_dim=32, label_embedding_dim=16, latent_dim=16, output_mlp_hidden_dim_scale_factor=2,
+              output_mlp_num_layers=3, projection_head_num_layers=3, projection_head_hidden_dim_scale_factor=2,
+              feature_fusion=fusion)
+    torch.manual_seed(2)
+    model = ProtNote(dropout=p, **kw).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.3)
+    B, NL = 9, 21
+    P_f = torch.randn(B, 32, generator=g)
+    lab = torch.randn(NL, 16, generator=g)
+    y = (torch.rand(B, NL, generator=g) < 0.3).float()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    model.train()
+    torch.manual_seed(5)
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    BCEWithLogitsLoss()(logits, y.to(DEV)).backward()
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # the draw _HeadsTrainFn.forward made
+
+    masks = _dropout_masks(L, seed, p, B, NL, [32, 32, 16], 32, 3)
+    keep = torch.cat([m.flatten() for m in masks.values()])
+    assert abs(float((keep > 0).float().mean()) - (1 - p)) < 0.02            # Bernoulli(1 - p)
+    assert not torch.equal(masks["W_l.0"][:B], masks["W_p.0"])                # independent streams
+    names = O.trainable_names(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    ref = O.protnote_forward(work, None, None, lab, fusion=fusion, training=True, sequence_embeddings=P_f,
+                             dropout_masks=masks)
+    ref_loss = O.bce_loss(ref, y)
+    ref_grads = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-4)
+    for name, q in model.named_parameters():
+        r = ref_grads[name].numpy()
+        np.testing.assert_allclose(q.grad.cpu().numpy(), r, atol=1e-6 + 2e-4 * np.abs(r).max(), err_msg=name)
+
+    # a different seed gives different masks; eval ignores dropout altogether
+    torch.manual_seed(6)
+    logits2, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    assert (logits2 - logits).abs().max().item() > 1e-3
+    model.eval()
+    plain = ProtNote(dropout=0.0, **kw).to(DEV).eval()
+    plain.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        a, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+        b, _ = plain(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    assert torch.equal(a, b)
+
+
+def test_mlp_dropout_big_kernels_match_small_tiles():
+    """Full-width head, 64 x 1040 pair grid with dropout 0.1: the 256-tile LDS-DMA kernels with the mask in their
+    operand loaders (NT forward, TN weight gradient) against the 128-tile register-staged kernels on the same seed -
+    two tilings of the same masked arithmetic."""
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(79)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1040
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, dropout=0.1)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+
+    def run(dma):
+        L.check(L.lib().pn_set_f32_dma(dma))
+        for q in model.parameters():
+            q.grad = None
+        torch.manual_seed(123)
+        logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        return [logits.detach().clone()] + [q.grad.clone() for q in model.parameters()]
+
+    try:
+        a, b = run(1), run(0)
+    finally:
+        L.lib().pn_set_f32_dma(1)
+    model.mlp_dropout = 0.0
+    c = run(1)
+    assert (c[0] - a[0]).abs().max().item() > 1e-2  # dropout really changes the logits
+    for i, (x, z) in enumerate(zip(a, b)):  # different tilings / split-K groupings: f32 reassociation noise only
+        rel = (x - z).norm().item() / max(z.norm().item(), 1e-30)
+        assert rel < 2e-4, (i, rel)
