@@ -233,6 +233,13 @@ int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t
                     float* loss_out, float* dlogits, float* tp, float* fn, float* fp, int weight_mode,
                     const float* label_weights, float rgd_temperature, void* ws, size_t ws_bytes, void* stream);
 
+/* LOSS_FN: SupCon (utils/losses.py:7-56, one_way_supcon over the label axis; the reference marks it unused and never
+ * reads its temperature): loss = -mean_i [ sum_j y_ij log_softmax_j(x_i) / n_i ], rows without positives count 0 in the
+ * loss and - as in the reference's autograd - NaN in the gradient.  ws >= pn_supcon_ws_bytes(B). */
+size_t pn_supcon_ws_bytes(int B);
+int pn_supcon_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                      float* loss_out, float* dlogits, void* ws, size_t ws_bytes, void* stream);
+
 /* calculate_tp_fn_fp (ProtNoteTrainer.py:61-83) on probabilities; outputs are overwritten. */
 int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
                 float threshold, float* tp, float* fn, float* fp, void* stream);

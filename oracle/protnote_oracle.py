@@ -226,6 +226,16 @@ def rgd_bce_loss(logits: Tensor, target: Tensor, temperature: float) -> Tensor:
     return m * torch.exp(torch.clamp(m.detach(), max=temperature) / (temperature + 1))
 
 
+def supcon_loss(logits: Tensor, target: Tensor) -> Tensor:
+    """losses.py:7-56 SupCon = one_way_supcon(dim=1): mean over rows of the mean log-softmax of the positives; a row
+    without positives is 0/0 -> nan_to_num -> 0 in the value (its gradient stays NaN through autograd, as in the
+    reference).  The temperature argument of the reference class is never used in its forward."""
+    x = logits - logits.max(dim=1, keepdim=True)[0].detach()
+    log_prob = x - torch.log(torch.exp(x).sum(1, keepdim=True))
+    m = (target * log_prob).sum(1) / target.sum(1)
+    return -torch.nan_to_num(m, 0).mean()
+
+
 def batch_weights_v2(label_weights: Tensor, target: Tensor) -> Tensor:
     """losses.py:214-241: every element of row i weighs sum_j label_weights[j] * target[i, j]."""
     return (label_weights.float() * target).sum(dim=1, keepdim=True).expand_as(target)

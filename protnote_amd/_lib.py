@@ -122,6 +122,9 @@ _SIGS = {
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "pn_supcon_ws_bytes": (C.c_size_t, [C.c_int]),
+    "pn_supcon_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_tp_fn_fp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "pn_clip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float,

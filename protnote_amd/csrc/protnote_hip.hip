@@ -1917,6 +1917,23 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
   return 0;
 }
 
+extern "C" size_t pn_supcon_ws_bytes(int B) { return al256((size_t)B * sizeof(double)) + 256; }
+
+// LOSS_FN: SupCon (reference utils/losses.py:7-56).  loss_out [1]; dlogits [B][N] or NULL.
+extern "C" int pn_supcon_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                                 float* loss_out, float* dlogits, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("supcon: pass exactly one target array");
+  if (ws_bytes < pn_supcon_ws_bytes(B)) return fail("supcon: workspace too small");
+  double* acc = (double*)ws;
+  double* rows = (double*)((char*)ws + 256);
+  hipLaunchKernelGGL(k_supcon, dim3(B), dim3(256), 0, st, logits, targets_f32, targets_i64, B, N, dlogits, rows);
+  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)rows, B, acc);
+  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)acc, loss_out, 1, 1.f / (float)B);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
                            float threshold, float* tp, float* fn, float* fp, void* stream) {
   hipStream_t st = (hipStream_t)stream;

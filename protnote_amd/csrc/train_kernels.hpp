@@ -635,6 +635,61 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
   if (threadIdx.x == 0) p.loss_part[(long)blockIdx.y * gridDim.x + blockIdx.x] = lsum;
 }
 
+// SupCon (reference utils/losses.py:7-56; marked "not currently using" there): for each protein row the mean
+// log-softmax (over the label axis) of its positive labels; loss = -mean over rows.  One workgroup per row:
+//   lp_ij = x_ij - max_i - log sum_j exp(x_ij - max_i),  m_i = sum_j y_ij lp_ij / n_i  (0/0 -> 0 by nan_to_num),
+//   dL/dx_ij = -(1/B) (y_ij / n_i - softmax_ij).
+// Quirk kept: a row WITHOUT positives contributes 0 to the loss but NaN to the gradient - the reference's nan_to_num
+// zeroes the forward value while autograd still multiplies 0 by 1/n_i = inf.  row_loss[i] is summed in a fixed order.
+__global__ __launch_bounds__(256) void k_supcon(const float* __restrict__ logits, const float* __restrict__ tf,
+                                                const int64_t* __restrict__ ti, int B, int N, float* __restrict__ dlogits,
+                                                double* __restrict__ row_loss) {
+  __shared__ float sh[256];
+  __shared__ double shd[256];
+  const int i = blockIdx.x;
+  const float* x = logits + (long)i * N;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < N; j += 256) mx = fmaxf(mx, x[j]);
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  mx = sh[0];
+  __syncthreads();
+  double se = 0, syx = 0, n = 0;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float y = tf ? tf[(long)i * N + j] : (float)ti[(long)i * N + j];
+    se += (double)expf(x[j] - mx);
+    syx += (double)(y * (x[j] - mx));
+    n += (double)y;
+  }
+  double* acc[3] = {&se, &syx, &n};
+  double tot[3];
+  for (int k = 0; k < 3; ++k) {
+    shd[threadIdx.x] = *acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+      __syncthreads();
+    }
+    tot[k] = shd[0];
+    __syncthreads();
+  }
+  const float lse = logf((float)tot[0]);
+  const float npos = (float)tot[2];
+  if (threadIdx.x == 0) row_loss[i] = npos > 0.f ? -((double)((float)tot[1] / npos - lse)) : 0.0;
+  if (dlogits) {
+    const float invB = 1.f / (float)B;
+    for (int j = threadIdx.x; j < N; j += 256) {
+      const float y = tf ? tf[(long)i * N + j] : (float)ti[(long)i * N + j];
+      const float sm = expf(x[j] - mx - lse);
+      dlogits[(long)i * N + j] = npos > 0.f ? -invB * (y / npos - sm) : NAN;
+    }
+  }
+}
+
 // calculate_tp_fn_fp on probabilities (ProtNoteTrainer.py:61-83): counts are integers held in f32
 __global__ __launch_bounds__(256) void k_tp_fn_fp(const float* __restrict__ probs, const float* tf, const int64_t* ti,
                                                    int B, int N, float threshold, float* tp, float* fn, float* fp,

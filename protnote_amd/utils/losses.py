@@ -4,7 +4,7 @@ BCE (BCEWithLogitsLoss(reduction='mean', pos_weight), reference :275-276) and Fo
 the shipped default) run as ONE fused HIP pass over the [B, N_L] logits (pn_loss_fwd_bwd) that produces the
 mean loss and d loss / d logits together; backward just scales the cached gradient.  The reference's other
 BCE variants ride on the same pass: BatchWeightedBCE and WeightedBCE / CBLoss as element weights, RGDBCE as a
-rescale by a device-side scalar.  SupCon (unused in the reference) raises NotImplementedError."""
+rescale by a device-side scalar.  SupCon (unused in the reference) has its own row-softmax kernel (pn_supcon_fwd_bwd)."""
 import torch
 
 from .. import _lib as L
@@ -140,6 +140,48 @@ class CBLoss(WeightedBCE):
         self.beta = beta
 
 
+class _SupConFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        L.require_hip(logits, target)
+        if logits.dim() != 2 or target.shape != logits.shape:
+            raise ValueError("expected logits and targets of the same [B, N] shape")
+        x = logits.detach().float().contiguous()
+        B, N = x.shape
+        tf = ti = None
+        if target.dtype == torch.int64:
+            ti = target.contiguous()
+        else:
+            tf = target.detach().float().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dlog = torch.empty_like(x)
+        ws = L.workspace(L.lib().pn_supcon_ws_bytes(B), x.device, "loss")
+        L.check(L.lib().pn_supcon_fwd_bwd(L.ptr(x), L.ptr(tf), L.ptr(ti), B, N, L.ptr(loss), L.ptr(dlog), L.ptr(ws),
+                                          ws.numel(), L.stream_ptr()))
+        ctx.dlog = dlog
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.dlog * grad_out
+        ctx.dlog = None
+        return g, None
+
+
+class SupCon(torch.nn.Module):
+    """Reference losses.py:7-56 (marked "NOT CURRENTLY USING THIS" there): mean over proteins of the mean log-softmax
+    (over the label axis) of their positive labels.  Like the reference's forward it never reads `temperature`; a protein
+    without positives contributes 0 to the loss and NaN to the gradient (the reference's nan_to_num quirk)."""
+
+    def __init__(self, temperature: float, base_temperature=0.07):
+        super().__init__()
+        assert temperature is not None, "temperature must be provided and not None"
+        self.temperature, self.base_temperature = temperature, base_temperature
+
+    def forward(self, input, target):
+        return _SupConFn.apply(input, target)
+
+
 def get_loss(config: dict, label_weights: torch.Tensor = None, bce_pos_weight: torch.Tensor = None):
     name = config["params"]["LOSS_FN"]
     if name == "BCE":
@@ -156,5 +198,5 @@ def get_loss(config: dict, label_weights: torch.Tensor = None, bce_pos_weight: t
     if name == "RGDBCE":
         return RGDBCE(temperature=config["params"]["RGDBCE_TEMP"])
     if name == "SupCon":
-        raise NotImplementedError("LOSS_FN=SupCon (marked 'not currently using' in the reference) is not implemented")
+        return SupCon(temperature=config["params"]["SUPCON_TEMP"])
     raise ValueError(f"Unknown loss function {name}")

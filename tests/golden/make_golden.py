@@ -325,7 +325,9 @@ def golden_losses_extra():
              "RGDBCE_hot": ({"LOSS_FN": "RGDBCE", "RGDBCE_TEMP": 5.0}, None),
              "BatchWeightedBCE": ({"LOSS_FN": "BatchWeightedBCE"}, None),
              "WeightedBCE": ({"LOSS_FN": "WeightedBCE"}, label_weights),
-             "CBLoss": ({"LOSS_FN": "CBLoss"}, label_counts)}
+             "CBLoss": ({"LOSS_FN": "CBLoss"}, label_counts),
+             # row 3 has no positives: 0 in the loss, NaN in the gradient (losses.py:46-53 nan_to_num + autograd)
+             "SupCon": ({"LOSS_FN": "SupCon", "SUPCON_TEMP": 0.07}, None)}
     for name, (params, lw) in cases.items():
         fn = get_loss({"params": params}, label_weights=lw)
         lg = logits.clone().requires_grad_(True)

@@ -699,6 +699,16 @@ def test_extra_losses_golden(golden_dir):
                                        err_msg=name)
             pred = (torch.sigmoid(logits) >= 0.5).float()
             np.testing.assert_array_equal(counts[0].cpu().numpy(), (pred * y).sum(0).cpu().numpy())
+    # LOSS_FN: SupCon (losses.py:7-56): row-softmax loss; the protein without positives gives NaN gradients, as there
+    for tgt in (y.float(), y):
+        fn = get_loss({"params": {"LOSS_FN": "SupCon", "SUPCON_TEMP": 0.07}})
+        lg = logits.clone().requires_grad_(True)
+        l = fn(lg, tgt)
+        l.backward()
+        np.testing.assert_allclose(l.item(), float(g["SupCon/loss"]), rtol=2e-6)
+        ref = g["SupCon/dlogits"]
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), ref, atol=1e-9 + 2e-6 * np.nanmax(np.abs(ref)), rtol=2e-5,
+                                   equal_nan=True)
 
 
 def _small_batch(g):

@@ -138,13 +138,15 @@ def test_extra_losses(golden_dir):
     lw, lc = torch.from_numpy(g["label_weights"]), torch.from_numpy(g["label_counts"])
     fns = {"RGDBCE": lambda x: O.rgd_bce_loss(x, y, 0.12), "RGDBCE_hot": lambda x: O.rgd_bce_loss(x, y, 5.0),
            "BatchWeightedBCE": lambda x: O.batch_weighted_bce_loss(x, y),
-           "WeightedBCE": lambda x: O.weighted_bce_loss(x, y, lw), "CBLoss": lambda x: O.cb_loss(x, y, lc)}
+           "WeightedBCE": lambda x: O.weighted_bce_loss(x, y, lw), "CBLoss": lambda x: O.cb_loss(x, y, lc),
+           "SupCon": lambda x: O.supcon_loss(x, y)}
     for name, fn in fns.items():
         lg = logits.clone().requires_grad_(True)
         l = fn(lg)
         l.backward()
         np.testing.assert_allclose(float(l), float(g[name + "/loss"]), rtol=1e-6, err_msg=name)
         np.testing.assert_allclose(lg.grad.numpy(), g[name + "/dlogits"], atol=1e-9, rtol=1e-5, err_msg=name)
+    assert np.isnan(g["SupCon/dlogits"][3]).all() and np.isfinite(np.delete(g["SupCon/dlogits"], 3, 0)).all()
 
 
 def test_protnote_train_encoder_grads(golden_dir):
