@@ -1759,28 +1759,31 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   const bool prod = hd->fusion == 2;
   float* dQ = nullptr;  // concatenation_prod: gradient wrt the P (.) L block, [R][d]
   if (!prod) {
-    // separable: z1[i,j] = A1[i] + B1[j] is regenerated, never stored
-    StatsParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.R = R; sp.C = h; sp.rows_per_block = stats_rows;
-    sp.G = G; sp.ldg = h; sp.A = sv.A1; sp.lda = h; sp.B2 = sv.B1; sp.ldb2 = h; sp.pairB = B;
-    sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
-    sp.part = w.statscr.part;
-    hipLaunchKernelGGL((k_bn_bwd_stats<0, 1>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
-    PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
-                       (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
-                       (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
-                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr);
+    // separable: z1[i,j] = A1[i] + B1[j] is regenerated, never stored.  Two passes over G give M0 = sum_i du and
+    // M1 = sum_j du; the statistics, dgamma / dbeta and both table gradients follow from them (train_kernels.hpp)
     PairRedParams rp;
     memset(&rp, 0, sizeof(rp));
     rp.B = B; rp.NL = NL; rp.C = h; rp.DH = G; rp.ldh = h;
     rp.A = sv.A1; rp.lda = h; rp.Bm = sv.B1; rp.ldb = h;
-    rp.s = sv.s[0]; rp.t = sv.t[0]; rp.cs = w.cs; rp.p = w.p; rp.q = w.q;
+    rp.s = sv.s[0]; rp.t = sv.t[0];
     rp.out = w.dB1; rp.ldo = h;
-    hipLaunchKernelGGL((k_pair_reduce<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
+    hipLaunchKernelGGL((k_pair_mask_reduce<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
     rp.out = w.dA1;
-    hipLaunchKernelGGL((k_pair_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+    hipLaunchKernelGGL((k_pair_mask_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+    const int per_chunk = (NL + RED_CHUNKS - 1) / RED_CHUNKS;
+    const int nchunk = (NL + per_chunk - 1) / per_chunk;
+    hipLaunchKernelGGL(k_pair_colsums, dim3(nblk(h, 256), nchunk), dim3(256), 0, st, (const float*)w.dB1, (long)h,
+                       (const float*)sv.B1, (long)h, NL, h, per_chunk, w.statscr.red);
+    hipLaunchKernelGGL(k_pair_bn0_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.statscr.red, nchunk,
+                       (const float*)sv.A1, (long)h, (const float*)w.dA1, (long)h, B, NL, h, hd->bn[0].weight,
+                       (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], w.cs, w.p, w.q,
+                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2);
+    hipLaunchKernelGGL(k_pair_apply, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.dB1, (long)h,
+                       (const float*)sv.B1, (long)h, (long)NL, h, (const float*)w.cs, (const float*)w.p,
+                       (const float*)w.q, (const double*)w.S1, (double)B);
+    hipLaunchKernelGGL(k_pair_apply, dim3(nblk((long)B * h, 256)), dim3(256), 0, st, w.dA1, (long)h,
+                       (const float*)sv.A1, (long)h, (long)B, h, (const float*)w.cs, (const float*)w.p,
+                       (const float*)w.q, (const double*)w.S2, (double)NL);
     HIP_OK(hipGetLastError());
   } else {
     // concatenation_prod: z1 is stored; dz1 is materialised over G, then summed / contracted

@@ -356,9 +356,9 @@ __global__ void k_bn_fold_pair(pn_bn bn, const double* sumA, const double* sqA, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer-1 reductions of dz1 over the pair grid (dz1 = (mask ? s*dh : 0) + p + q*z1, z1 = A[i] + Bm[j]):
-//   MODE 0: dBm[j][c] = sum_i dz1[i,j,c]   grid (C/1024, NL)   rows of one label are contiguous
-//   MODE 1: dA[i][c]  = sum_j dz1[i,j,c]   grid (C/1024, B)    stride-B rows, 1 KiB per wave per row
+// layer-1 reductions over the pair grid (z1 = A[i] + Bm[j] regenerated from the two small tables):
+//   MODE 0: one label per workgroup row   grid (C/1024, NL)   rows of one label are contiguous
+//   MODE 1: one protein per workgroup row grid (C/1024, B)    stride-B rows, 1 KiB per wave per row
 // ------------------------------------------------------------------------------------------------
 struct PairRedParams {
   int B, NL, C;
@@ -373,14 +373,24 @@ struct PairRedParams {
   long ldo;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Layer-1 backward in TWO passes over the upstream gradient instead of three.  With du = (s*z1+t > 0 ? g : 0):
+//   M0[j][c] = sum_i du   (k_pair_mask_reduce<0>, rows of one label are contiguous)
+//   M1[i][c] = sum_j du   (k_pair_mask_reduce<1>)
+// everything BatchNorm-backward needs follows from these two small tables, because z1 = A[i] + Bm[j] is separable:
+//   S1 = sum du = sum_j M0[j],   sum du*z1 = sum_i A[i] M1[i] + sum_j Bm[j] M0[j],   S2 = invstd (sum du*z1 - mean S1)
+//   dBm[j] = sum_i dz1 = cs M0[j] + B p + q (sum_i A[i] + B Bm[j]),   dA[i] = cs M1[i] + NL p + q (NL A[i] + sum_j Bm[j])
+// (dz1 = cs du + p + q z1 with cs, p, q as in k_bn_bwd_finalize).  The separate statistics pass over the 101 GB
+// gradient is gone; the small-table work is k_pair_colsums -> k_pair_bn0_finalize -> k_pair_apply.
+// ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_pair_reduce(const PairRedParams P) {
+__global__ __launch_bounds__(256) void k_pair_mask_reduce(const PairRedParams P) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= P.C) return;
-  const float4 s = ld4(P.s + c), t = ld4(P.t + c), cs = ld4(P.cs + c), pp = ld4(P.p + c), q = ld4(P.q + c);
+  const float4 s = ld4(P.s + c), t = ld4(P.t + c);
   const int fixed = blockIdx.y;
   const int n = MODE == 0 ? P.B : P.NL;
-  float4 zf = MODE == 0 ? ld4(P.Bm + (long)fixed * P.ldb + c) : ld4(P.A + (long)fixed * P.lda + c);
+  const float4 zf = MODE == 0 ? ld4(P.Bm + (long)fixed * P.ldb + c) : ld4(P.A + (long)fixed * P.lda + c);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
   int cnt = 0;
@@ -389,11 +399,10 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const PairRedParams P) {
     const long r = MODE == 0 ? (long)fixed * P.B + k : (long)k * P.B + fixed;
     const float4 zv = MODE == 0 ? ld4(P.A + (long)k * P.lda + c) : ld4(P.Bm + (long)k * P.ldb + c);
     const float4 g = ld4(P.DH + r * P.ldh + c);
-    const float z0 = zf.x + zv.x, z1 = zf.y + zv.y, z2 = zf.z + zv.z, z3 = zf.w + zv.w;
-    a0 += (fmaf(z0, s.x, t.x) > 0.f ? g.x * cs.x : 0.f) + fmaf(q.x, z0, pp.x);
-    a1 += (fmaf(z1, s.y, t.y) > 0.f ? g.y * cs.y : 0.f) + fmaf(q.y, z1, pp.y);
-    a2 += (fmaf(z2, s.z, t.z) > 0.f ? g.z * cs.z : 0.f) + fmaf(q.z, z2, pp.z);
-    a3 += (fmaf(z3, s.w, t.w) > 0.f ? g.w * cs.w : 0.f) + fmaf(q.w, z3, pp.w);
+    a0 += fmaf(zf.x + zv.x, s.x, t.x) > 0.f ? g.x : 0.f;
+    a1 += fmaf(zf.y + zv.y, s.y, t.y) > 0.f ? g.y : 0.f;
+    a2 += fmaf(zf.z + zv.z, s.z, t.z) > 0.f ? g.z : 0.f;
+    a3 += fmaf(zf.w + zv.w, s.w, t.w) > 0.f ? g.w : 0.f;
     if (++cnt == 256) {
       d0 += a0; d1 += a1; d2 += a2; d3 += a3;
       a0 = a1 = a2 = a3 = 0.f;
@@ -403,6 +412,82 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const PairRedParams P) {
   d0 += a0; d1 += a1; d2 += a2; d3 += a3;
   *reinterpret_cast<float4*>(P.out + (long)fixed * P.ldo + c) =
       make_float4((float)d0, (float)d1, (float)d2, (float)d3);
+}
+
+// per column and label chunk: sum_j M0[j], sum_j Bm[j] M0[j], sum_j Bm[j]  -> out[chunk][3][C] (f64)
+__global__ __launch_bounds__(256) void k_pair_colsums(const float* __restrict__ M0, long ldm, const float* __restrict__ Bm,
+                                                      long ldb, int NL, int C, int per_chunk, double* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int j0 = blockIdx.y * per_chunk;
+  int j1 = j0 + per_chunk;
+  if (j1 > NL) j1 = NL;
+  double s1 = 0, sbm = 0, sb = 0;
+#pragma unroll 8
+  for (int j = j0; j < j1; ++j) {
+    const double m = M0[(long)j * ldm + c], b = Bm[(long)j * ldb + c];
+    s1 += m;
+    sbm += b * m;
+    sb += b;
+  }
+  double* o = out + (long)blockIdx.y * 3 * C + c;
+  o[0] = s1;
+  o[C] = sbm;
+  o[2 * C] = sb;
+}
+
+// S1, S2 of the separable layer from the chunk sums and the [B][C] tables; then cs, p, q, dgamma, dbeta exactly as
+// k_bn_bwd_finalize, plus sum_i A[i] and sum_j Bm[j] for k_pair_apply
+__global__ void k_pair_bn0_finalize(const double* __restrict__ chunks, int nchunk, const float* __restrict__ A, long lda,
+                                    const float* __restrict__ M1, long ldm1, int B, int NL, int C,
+                                    const float* gamma, const float* s, const float* mean, const float* invstd,
+                                    float* cs, float* pv, float* qv, float* dgamma, float* dbeta, double* sumA,
+                                    double* sumB) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S1 = 0, T = 0, sb = 0;
+  for (int k = 0; k < nchunk; ++k) {
+    S1 += chunks[(long)k * 3 * C + c];
+    T += chunks[(long)k * 3 * C + C + c];
+    sb += chunks[(long)k * 3 * C + 2 * C + c];
+  }
+  double sa = 0;
+  for (int i = 0; i < B; ++i) {
+    const double a = A[(long)i * lda + c];
+    sa += a;
+    T += a * (double)M1[(long)i * ldm1 + c];
+  }
+  sumA[c] = sa;
+  sumB[c] = sb;
+  const double count = (double)B * (double)NL;
+  if (gamma != nullptr) {
+    const double S2 = (double)invstd[c] * (T - (double)mean[c] * S1);
+    const float sc = s[c];
+    const float q = (float)(-(double)sc * (double)invstd[c] * (S2 / count));
+    cs[c] = sc;
+    qv[c] = q;
+    pv[c] = (float)(-(double)sc * (S1 / count) - (double)q * (double)mean[c]);
+    if (dgamma) dgamma[c] = (float)S2;
+    if (dbeta) dbeta[c] = (float)S1;
+  } else {  // no BatchNorm: dz1 = du, the slot carries the Linear-bias gradient
+    cs[c] = 1.f;
+    qv[c] = 0.f;
+    pv[c] = 0.f;
+    if (dbeta) dbeta[c] = (float)S1;
+  }
+}
+
+// in place: X[r][c] = cs M[r][c] + n_other p + q (sum_other + n_other Z[r][c]);  (M0, Bm, sum_i A, B) or (M1, A, sum_j Bm, NL)
+__global__ void k_pair_apply(float* __restrict__ M, long ldm, const float* __restrict__ Z, long ldz, long rows, int C,
+                             const float* __restrict__ cs, const float* __restrict__ pv, const float* __restrict__ qv,
+                             const double* __restrict__ sum_other, double n_other) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  const double v = (double)cs[c] * (double)M[r * ldm + c] + n_other * (double)pv[c] +
+                   (double)qv[c] * (sum_other[c] + n_other * (double)Z[r * ldz + c]);
+  M[r * ldm + c] = (float)v;
 }
 
 // plain reductions of a stored pair-grid matrix X[r = j*B + i][c] (concatenation_prod backward):
