@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Aggregate the rocprofv3 counter passes written by tools/profile_round.sh into per-kernel HBM-side traffic and
+matrix-pipe utilisation (run on the GPU box right after the passes; the CSVs are too large to travel).
+
+    python tools/pmc_traffic.py gpurun_out/prof_r02 r02  ->  gpurun_out/prof_r02/r02_hbm_traffic.json
+
+Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are reported in KB by the L2's
+fabric-side request counters (Infinity-Cache hits included); on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
+coalesced reads, i.e. HALF the bytes - it is doubled here.  Per launch: bytes = 2 * FETCH_SIZE + WRITE_SIZE.
+Matrix pipe: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / duration."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def read_pass(d):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    rows = defaultdict(lambda: defaultdict(float))   # (kernel, dispatch) -> counter -> value
+    dur = {}
+    for f in files:
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                key = (r["Kernel_Name"], r["Dispatch_Id"])
+                rows[key][r["Counter_Name"]] += float(r["Counter_Value"])
+                dur[key] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    return rows, dur
+
+
+def short(name):
+    name = name.replace("void pn::", "").replace("pn::", "")
+    return name[:name.index("(")] if "(" in name else name
+
+
+def main(out_dir, tag):
+    big = lambda k: ("gemm_nt" in k or "gemm_tn" in k)
+    res = {"per_kernel": {}, "note": __doc__.split("Conventions")[1].strip()}
+    fetch, _ = read_pass(os.path.join(out_dir, "pmc_FETCH_SIZE"))
+    write, _ = read_pass(os.path.join(out_dir, "pmc_WRITE_SIZE"))
+    agg = defaultdict(lambda: {"launches": 0, "fetch_kb": 0.0, "write_kb": 0.0})
+    for (k, _), c in fetch.items():
+        if big(k):
+            agg[short(k)]["launches"] += 1
+            agg[short(k)]["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
+    wl = defaultdict(int)
+    for (k, _), c in write.items():
+        if big(k):
+            agg[short(k)]["write_kb"] += c.get("WRITE_SIZE", 0.0)
+            wl[short(k)] += 1
+    sq, dur = read_pass(os.path.join(out_dir, "pmc_SQ"))
+    util = defaultdict(lambda: {"n": 0, "busy": 0.0, "gui": 0.0, "sec": 0.0, "valu": 0.0, "mfma": 0.0})
+    for key, c in sq.items():
+        k = key[0]
+        if big(k):
+            u = util[short(k)]
+            u["n"] += 1
+            u["busy"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            u["gui"] += c.get("GRBM_GUI_ACTIVE", 0.0)
+            u["valu"] += c.get("SQ_INSTS_VALU", 0.0)
+            u["mfma"] += c.get("SQ_INSTS_MFMA", 0.0)
+            u["sec"] += dur[key]
+    total_bytes = total_launch = 0
+    for k, a in sorted(agg.items()):
+        n = max(a["launches"], 1)
+        per = (2 * a["fetch_kb"] / n + a["write_kb"] / max(wl[k], 1)) * 1024.0
+        e = {"launches": a["launches"], "fetch_kb_per_launch": a["fetch_kb"] / n,
+             "write_kb_per_launch": a["write_kb"] / max(wl[k], 1), "hbm_side_bytes_per_launch": per}
+        u = util.get(k)
+        if u and u["gui"] > 0:
+            e["mfma_busy"] = u["busy"] / (u["gui"] / 8.0 * 1024.0)
+            e["clock_ghz"] = u["gui"] / 8.0 / u["sec"] / 1e9 if u["sec"] > 0 else None
+            e["valu_insts_per_mfma"] = u["valu"] / u["mfma"] if u["mfma"] > 0 else None
+            e["avg_ms"] = u["sec"] / u["n"] * 1e3
+        res["per_kernel"][k] = e
+        if per > 50e9 and "bf16x3" not in k:   # the full pair-grid f32 launches (top-layer dh chunks are smaller)
+            total_bytes += per * a["launches"]
+            total_launch += a["launches"]
+    res["bytes_per_launch"] = total_bytes / total_launch if total_launch else None
+    res["bytes_per_launch_definition"] = ("mean over the full-pair-grid f32 GEMM launches (> 50 GB each) of "
+                                          "2 * FETCH_SIZE + WRITE_SIZE; algorithmic bytes of such a launch: 202 GB")
+    path = os.path.join(out_dir, f"{tag}_hbm_traffic.json")
+    json.dump(res, open(path, "w"), indent=1)
+    print(path, res["bytes_per_launch"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02")
