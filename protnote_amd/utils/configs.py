@@ -89,16 +89,20 @@ def build_training(config: dict, model, world_size: int = 1):
     import torch
 
     from ..models.ProtNoteTrainer import Trainer
-    from ..models.train_path import head_parameters
+    from ..models.train_path import trainable_parameters
     from .losses import get_loss
     from .optim import FusedClipAdam
 
     p = config["params"]
+    if p.get("SYNC_BN", False) and world_size > 1:
+        # bin/main.py:449-450 converts to SyncBatchNorm; here the statistics of a GEMM are reduced inside one C call,
+        # per rank (the reference default) - say so instead of silently training something else
+        raise NotImplementedError("SYNC_BN: True is not implemented (BatchNorm statistics are per rank)")
     loss_fn = get_loss(config, bce_pos_weight=torch.tensor(float(p.get("BCE_POS_WEIGHT", 1))))
     name = p.get("OPTIMIZER", "Adam")
     if name not in ("Adam", "AdamW"):
         raise NotImplementedError(f"OPTIMIZER={name}: the fused optimiser implements Adam and AdamW")
-    params = list(head_parameters(model))
+    params = list(trainable_parameters(model))  # heads (+ raw_attn_scorer with LABEL_EMBEDDING_POOLING_METHOD: all)
     if p.get("TRAIN_SEQUENCE_ENCODER", False):
         params += list(model.sequence_encoder.trunk_parameters())
     clip = p.get("CLIP_VALUE", 1)

@@ -177,7 +177,7 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
         # ReLU masks of pre-activations within f32 rounding of 0 flip under any change of summation order (each
         # flip is a rank-1 O(dl*h) change) and every gradient inherits the ~1e-4 abs error of the f32 logits
         # through dl = sigmoid(x) - y, so element-wise 1e-4 is not meaningful for gradients on large pair grids
-        # (the reference's own f32 CPU path is 5e-4..2e-3 away from f64 at B >= 128; measured, tools/debug_grad.py).
+        # (the reference's own f32 CPU path is 5e-4..2e-3 away from f64 at B >= 128; printed by this test under -s).
         # Require the GPU's Frobenius error vs f64 to be of the same class as the f32 CPU path's.
         nrm = max(ref.norm().item(), 1e-30)
         rel = (p.grad.cpu().double() - ref).norm().item() / nrm
@@ -275,7 +275,7 @@ def test_config0_shape_one_epoch_vs_oracle():
             # features (dW[n,k] = sum_i dY[i,n] X[i,k] with sum_i dY = 0 after BatchNorm: for near-constant
             # columns X[:,k] the gradient is rounding noise, Adam turns it into +-lr, and |mean X[:,k]| ~ 10 turns
             # that into 1e-2 shifts of the batch mean - which the BatchNorm then removes again; measured with
-            # tools/debug_epoch.py).  Only the bulk is comparable.
+            # measured in round 1).  Only the bulk is comparable.
             d = (got[k] - v).abs()
             assert d.mean().item() < 2e-3 * max(v.abs().mean().item(), 1.0), k
         else:
@@ -477,7 +477,7 @@ def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
     within f32 rounding of zero flips its ReLU mask, which alone is a ~1/sqrt(N) ~ 1e-3 relative change of that
     layer's gradient and of everything upstream.  tools/relu_flip_probe.py reproduces exactly this with the f64
     oracle plus 1e-6 relative noise on the conv outputs (steps of 1e-3 .. 5e-3 from the last block towards conv1), and
-    tools/debug_enc.py shows the same staircase for the HIP path (1e-5 at the last block).  Hence a norm-wise 1e-2
+    The HIP path shows the same staircase (1e-5 at the last block, measured in round 1).  Hence a norm-wise 1e-2
     bound at full width.  (B >= 4: with B = 2 the batch-statistics BatchNorm in W_p is singular.)"""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.protein_encoders import ProteInfer
