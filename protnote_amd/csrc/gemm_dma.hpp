@@ -20,8 +20,8 @@
 #pragma once
 #include "gemm_engine.hpp"
 
-#ifndef PN_DMA_LATE
-#define PN_DMA_LATE 0
+#ifndef PN_DMA_ROT
+#define PN_DMA_ROT 1
 #endif
 
 namespace pn {
@@ -215,22 +215,65 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  auto read_frag = [&](int buf, int kk, float4 (&a)[WM], float4 (&b)[WN]) {
+    const float* As = smem + buf * STAGE + a_base + fo[kk];
+    const float* Bs = smem + buf * STAGE + b_base + fo[kk];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK);
+  };
+  auto mma = [&](const float4 (&a)[WM], const float4 (&b)[WN]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if constexpr (A_DMA && PN_DMA_ROT) {
+    // Rotated loop: the last k-step's 32 MFMAs of slab s are issued AFTER the barrier that publishes slab s+1, behind
+    // the fragment reads of slab s+1's first k-step - the matrix pipe has work while those reads are in flight, so
+    // no wave starts a slab waiting on the LDS.  (The fragment registers alternate between two sets.)  Measured on
+    // M = 524288, K = 6144: 144.0 -> 145.1 TFLOP/s; a static s_setprio for either half of the workgroup: 0 %.
+    float4 fa[WM], fb[WN], ga[WM], gb[WN];
+    read_frag(0, 0, fa, fb);
+    for (int s = 0; s < nslab; ++s) {
+      const int cur = s & 1;
+      const int nxt = s + 1 < nslab ? s + 1 : s;  // branch-free: the last slab re-stages itself into the idle buffer
+      issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
+      issue_a(nxt, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(cur, 1, ga, gb);
+      mma(fa, fb);
+      read_frag(cur, 2, fa, fb);
+      mma(ga, gb);
+      read_frag(cur, 3, ga, gb);
+      mma(fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frag(cur ^ 1, 0, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ga, gb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
   for (int s = 0; s < nslab; ++s) {
     const int cur = s & 1;
     // branch-free: the last slab re-stages itself into the idle buffer (nobody reads it) instead of taking a
     // different path - a conditional fetch makes hipcc wait for the loads right where they are issued
     const int nxt = s + 1 < nslab ? s + 1 : s;
+    issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
     if constexpr (A_DMA) {
-      // the first k-step's fragment reads and MFMAs go first (the matrix pipe has work right after the barrier),
-      // the DMA of slab s+1 is issued under them: it still has three quarters of a slab to land
-      if (PN_DMA_LATE) compute(cur, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
       issue_a(nxt, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, PN_DMA_LATE ? 1 : 0>{}, integral_constant<int, 4>{});
+      compute(cur, integral_constant<int, 0>{}, integral_constant<int, 4>{});
     } else {
-      issue_b(nxt, cur ^ 1);
       fetch_a(nxt);
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, integral_constant<int, 0>{}, integral_constant<int, 2>{});
@@ -244,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     // makes every wave's share visible (and frees buffer `cur` for the DMA of slab s+2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
   }
 
   gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
