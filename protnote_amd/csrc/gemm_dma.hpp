@@ -20,10 +20,6 @@
 #pragma once
 #include "gemm_engine.hpp"
 
-#ifndef PN_DMA_ROT
-#define PN_DMA_ROT 1
-#endif
-
 namespace pn {
 
 // one LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS[lds_base + 16 l]
@@ -235,11 +231,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
       }
   };
 
-  if constexpr (A_DMA && PN_DMA_ROT) {
+  if constexpr (A_DMA) {
     // Rotated loop: the last k-step's 32 MFMAs of slab s are issued AFTER the barrier that publishes slab s+1, behind
     // the fragment reads of slab s+1's first k-step - the matrix pipe has work while those reads are in flight, so
     // no wave starts a slab waiting on the LDS.  (The fragment registers alternate between two sets.)  Measured on
     // M = 524288, K = 6144: 144.0 -> 145.1 TFLOP/s; a static s_setprio for either half of the workgroup: 0 %.
+    // Ablations of this loop (same shape): without the DMA 150.4, without DMA and barrier 151.8 (the MFMA + fragment-read
+    // ceiling), without the barrier only 140.0 (desynchronised waves); spreading the 8 DMA instructions over the four
+    // k-steps instead of issuing them in one burst: 139.3.  The LDS-side cost of the operand stream (3.6 %) is what is left.
     float4 fa[WM], fb[WN], ga[WM], gb[WN];
     read_frag(0, 0, fa, fb);
     for (int s = 0; s < nslab; ++s) {
@@ -270,19 +269,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     // different path - a conditional fetch makes hipcc wait for the loads right where they are issued
     const int nxt = s + 1 < nslab ? s + 1 : s;
     issue_b(nxt, cur ^ 1);  // the other buffer was last read in slab s-1, which ended with a barrier
-    if constexpr (A_DMA) {
-      issue_a(nxt, cur ^ 1);
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, 4>{});
-    } else {
-      fetch_a(nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, integral_constant<int, 0>{}, integral_constant<int, 2>{});
-      __builtin_amdgcn_sched_barrier(0);
-      pin_a();  // the register operand has had half a slab (~8k cycles) to land
-      compute(cur, integral_constant<int, 2>{}, integral_constant<int, 4>{});
-      commit_a(cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    fetch_a(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    pin_a();  // the register operand has had half a slab (~8k cycles) to land
+    compute(cur, integral_constant<int, 2>{}, integral_constant<int, 4>{});
+    commit_a(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
     // DMA of slab s+1 complete for this wave, its LDS writes and this wave's fragment reads drained; then the barrier
     // makes every wave's share visible (and frees buffer `cur` for the DMA of slab s+2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
