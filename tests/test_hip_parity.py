@@ -471,3 +471,26 @@ def test_gemm_nt_lds_dma_vs_f64_and_register_engine(M, N, K, affine):
     assert (got.double() - ref).abs().max().item() <= 2e-6 * scale * max(1, K ** 0.5)
     assert torch.equal(got, old)
     assert torch.equal(run(1), got)  # and run to run
+
+
+def test_pairhead_eval_lds_dma_grid_vs_oracle():
+    """f32, full-width head on a 100 x 660 pair grid (66 000 rows: the LDS-DMA kernels' territory, an odd batch size so a
+    256-row tile spans several labels, and a ragged last row tile) against the oracle's materialised joint tensor - the
+    big kernels against the reference algorithm directly, not only against the register-staged engine."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(41)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 100, 660
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    model.pair_label_chunk = NL  # one chunk of 66 000 rows
+    with torch.no_grad():
+        out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    err = (out.cpu() - ref).abs().max().item()
+    assert ref.abs().max().item() > 0.5 and err < 5e-4, err

@@ -135,10 +135,12 @@ def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
                 _assert_adam_close(got[name], g[k], name)
 
 
-@pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 40, 7), (8, 9, None)])
+@pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 40, 7), (8, 9, None), (100, 660, 256)])
 def test_train_real_width_vs_oracle(B, NL, chunk):
     """d=1024 / h=3072 / 3 hidden layers / 4-layer projection heads: logits, loss and every gradient of one
-    train-mode step against the oracle's autograd on the same seeded inputs."""
+    train-mode step against the oracle's autograd on the same seeded inputs.  The 100 x 660 grid (66 000 pair rows,
+    odd batch, ragged last tile, three backward chunks) is the smallest that runs on the 256-tile LDS-DMA kernels
+    (forward NT, chunked dh NT, TN weight gradients), so those are held to the reference algorithm directly."""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
