@@ -124,23 +124,30 @@ class Trainer:
         return self._metrics(counts, loss_sum, n)
 
     @torch.no_grad()
-    def evaluate(self, loader, with_map=True, estimate_map=False, map_thresholds=50):
+    def evaluate(self, loader, with_map=True, estimate_map=False, map_thresholds=50, represented_label_mask=None):
         """`estimate_map` follows ESTIMATE_MAP (ProtNoteTrainer.py:477-489): False -> exact AUPRC, True -> binned
         AUPRC with `map_thresholds` thresholds; `with_map=False` is ESTIMATE_MAP: None.  Either way the scores never
-        leave the device (the reference moves every batch to the CPU, :540-543).  Leaves the model in train mode, as
-        the reference does (:671)."""
+        leave the device (the reference moves every batch to the CPU, :540-543).  `represented_label_mask` ([N_L] bool,
+        the dataset's represented_vocabulary_mask) is the reference's `only_represented_labels=True` (:469-472,517-519):
+        loss, counts and mAP are taken over those label columns only.  Leaves the model in train mode, as the reference
+        does (:671)."""
         from ..utils.evaluation import DeviceAveragePrecision, DeviceBinnedAUPRC
 
         self.model.eval()
         counts, loss_sum, n, ap = None, None, 0, None
+        keep = None
         for batch in loader:
             y = batch["label_multihots"]
-            if counts is None:
-                counts = torch.zeros(3, y.shape[1], dtype=torch.float32, device=y.device)
-                loss_sum = torch.zeros((), dtype=torch.float64, device=y.device)
             logits, _ = self.model(sequence_onehots=batch["sequence_onehots"],
                                    sequence_lengths=batch["sequence_lengths"],
                                    label_embeddings=batch["label_embeddings"])
+            if represented_label_mask is not None:
+                if keep is None:
+                    keep = torch.as_tensor(represented_label_mask, dtype=torch.bool, device=y.device).nonzero().flatten()
+                logits, y = logits.index_select(1, keep).contiguous(), y.index_select(1, keep).contiguous()
+            if counts is None:
+                counts = torch.zeros(3, y.shape[1], dtype=torch.float32, device=y.device)
+                loss_sum = torch.zeros((), dtype=torch.float64, device=y.device)
             if hasattr(self.loss_fn, "metric_counts"):
                 self.loss_fn.metric_counts, self.loss_fn.decision_threshold = counts, self.threshold
             loss_sum += self.loss_fn(logits, y).detach().double()
