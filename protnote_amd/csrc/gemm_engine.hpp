@@ -67,7 +67,9 @@ struct GemmParams {
   double* col_sumsq;     // (not accumulated) by the launcher from the per-row-tile partials below, in a fixed order
   float* col_part;       // [row tiles][2][N] f32 partials, one slot per workgroup - no atomics, bit-reproducible
   double* col_red;       // [64][2][N] scratch of the two-level reduction
-  const float* e_scale;  // E_ROWDOT: sum_n relu(acc*e_scale[n]+e_shift[n]) * e_w[n]
+  const float* e_scale;  // E_ROWDOT: sum_n relu(acc*e_scale[n]+e_shift[n]) * e_w[n];  E_STORE (eval, optional): the
+                         // stored value is relu(acc*e_scale[n]+e_shift[n]) - the next layer's BN+ReLU applied by the
+                         // producer, so that the next GEMM takes a plain (LDS-DMA staged) operand
   const float* e_shift;
   const float* e_w;
   float* rowdot_out;     // [n_col_tiles * WAVES_N][M] deterministic partials
@@ -173,6 +175,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   // [WAVES_M][2][BN] column partials, one slot per (wave row, column): plain stores, summed in wave-row order below
   float* red = smem;  // (LDS is free after the final barrier of the main loop)
 
+  // E_CONV: which of this lane's rows are real residues (row < M and position < len of its sequence) - decided once
+  // per row here, not per element inside the column loop (a lens[] load and an integer division behind a divergent
+  // branch per element made the epilogue a chain of ~100 dependent global loads)
+  unsigned live_mask[WM];
+  if constexpr (EK == E_CONV) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      live_mask[i] = 0u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        const int rc = row < p.M ? row : p.M - 1;
+        const int b = rc / p.L;
+        const bool live = (row < p.M) && (rc - b * p.L) < p.lens[b];
+        live_mask[i] |= (live ? 1u : 0u) << e;
+      }
+    }
+  }
+
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = col0 + (wn * WN + j) * 32 + cl;
@@ -189,7 +210,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         ew = p.e_w[col];
       }
     }
+    const bool store_act = (EK == E_STORE) && (p.e_scale != nullptr);
+    if constexpr (EK == E_STORE) {
+      if (store_act && cok) {
+        es = p.e_scale[col];
+        et = p.e_shift[col];
+      }
+    }
     if constexpr (EK == E_SCALE_RC) cs = cok ? p.col_scale[col] * p.alpha : 0.f;
+    if constexpr (EK == E_CONV) {
+      // residual: every load of this column strip issued back to back from clamped (always valid) addresses
+      const int cc = cok ? col : 0;
+      const bool has_res = p.resid != nullptr;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        float res[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+          const int rc = row < p.M ? row : p.M - 1;
+          res[e] = has_res ? p.resid[(long)rc * p.ldr + cc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+          const bool live = (live_mask[i] >> e) & 1u;
+          float v = acc[i][j][e];
+          v = (live && cok) ? (v + bj) + res[e] : 0.f;
+          if (row < p.M && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if constexpr (EK != E_CONV) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -208,32 +262,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           }
         } else if constexpr (EK == E_STORE) {
           v = cok ? v + bj : 0.f;
+          if (store_act) v = cok ? relu(fmaf(v, es, et)) : 0.f;
           if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
           if (rok) {
             s1 += v;
             s2 += v * v;
           }
-        } else if constexpr (EK == E_CONV) {
-          bool live = false;
-          if (rok) {
-            const int b = row / p.L;
-            live = (row - b * p.L) < p.lens[b];
-          }
-          if (live && cok) {
-            v += bj;
-            if (p.resid) v += p.resid[(long)row * p.ldr + col];
-          } else {
-            v = 0.f;
-          }
-          if (rok && col < p.Nstore) p.C[(long)row * p.ldc + col] = v;
-          s1 += v;
-          s2 += v * v;
         } else if constexpr (EK == E_SCALE_RC) {
           if (rok && cok) p.C[(long)row * p.ldc + col] = v * p.row_scale[row] * cs;
         } else if constexpr (EK == E_ROWDOT) {
           acc[i][j][e] = cok ? relu(fmaf(v, es, et)) * ew : 0.f;
         }
       }
+    }
     }
     if (want_stats) {
       s1 += __shfl_xor(s1, 32);

@@ -10,6 +10,7 @@
 #include "gemm_engine.hpp"
 #include "gemm_bf16x3.hpp"
 #include "gemm_dma.hpp"
+#include "gemm_conv_dma.hpp"
 #include "train_kernels.hpp"
 
 using namespace pn;
@@ -353,6 +354,12 @@ extern "C" int pn_set_f32_dma(int on) {
   return 0;
 }
 
+// smallest M for which an NT GEMM takes the 256-tile LDS-DMA kernel (PN_DMA_MIN_ROWS; A/B switch for measurements)
+static int g_dma_min_rows = [] {
+  const char* e = getenv("PN_DMA_MIN_ROWS");
+  return e ? atoi(e) : 16384;
+}();
+
 template <int AK, int EK, bool DROP = false>
 static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
   auto kern = gemm_nt_dma_kernel<AK, EK, DROP>;
@@ -378,6 +385,42 @@ static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
   {
     ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), GEMM_DMA_LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return finish_col_stats(p, tm, st);
+}
+
+// Encoder convolution as an all-LDS-DMA implicit GEMM (gemm_conv_dma.hpp): p.A / p.lda describe the staged activation H,
+// p.W / p.ldw the re-laid weights, p.Kseg = Kpad (a multiple of 32).  One column tile per XCD block: the 32 row tiles an
+// XCD runs at a time stream the same weight panel (7.6 MB for 192 x 9 x 1100) through its L2 in step.
+static int launch_conv_dma(const GemmParams& p, int Lp, int ktrue, hipStream_t st) {
+  constexpr int WN = 3;
+  auto kern = gemm_conv_dma_kernel<WN>;
+  constexpr int LDS = conv_dma_lds_bytes<WN>();
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  if (p.Kseg % 32 != 0) return fail("conv_dma: K segment %d not a multiple of 32", p.Kseg);
+  const long tm = (p.M + 255) / 256, tn = (p.Nstore + 64 * WN - 1) / (64 * WN);
+  ConvDmaParams cp;
+  cp.g = p;
+  cp.Lp = Lp;
+  cp.g.xcd_bc = (PN_XCD && tm >= 64) ? 1 : 0;
+  cp.g.xcd_br = cp.g.xcd_bc ? 32 : 0;
+  long grid = tm * tn;
+  if (cp.g.xcd_bc) {
+    const long nblk_ = ((tm + 31) / 32) * tn;
+    grid = ((nblk_ + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("conv_dma: grid too large");
+  {
+    ProfScope ps(A_CONV * 10 + E_CONV, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)ktrue, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, st, cp);
   }
   HIP_OK(hipGetLastError());
   return finish_col_stats(p, tm, st);
@@ -415,7 +458,8 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
     }
   }
   if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
-    if (PN_BIG && use_f32_dma() && (variant == 0 || EK == E_ROWDOT) && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 &&
+    // (row MLPs over the label table, M = N_L = 32102, take it too: 126 x 12 tiles = 5.9 rounds of 256 workgroups)
+    if (PN_BIG && use_f32_dma() && (variant == 0 || EK == E_ROWDOT) && p.M >= g_dma_min_rows && p.nseg == 1 && p.Kseg % 32 == 0 &&
         p.N % 256 == 0 && p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0)
       return launch_gemm_dma<AK, EK>(p, st);
   }
@@ -637,7 +681,13 @@ struct EncWs {
   float *x0, *xa, *xb, *z, *s1, *t1, *s2, *t2;
   double *sum_x, *sq_x, *sum_z, *sq_z;
   ColScr cs;  // per-tile partials of the train-mode BatchNorm statistics
+  float *H, *Wr;  // LDS-DMA convolution path (gemm_conv_dma.hpp): staged activation with guard rows, re-laid weights
 };
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// the all-DMA convolution kernel serves the wide layers of a big enough batch (conv1 with its 20 input channels and
+// toy models keep the register-staged engine)
+static bool conv_dma_shape(int ld_in, int ld_out, long P) { return PN_BIG && ld_in >= 256 && ld_out >= 512 && P >= 4096; }
 
 static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
   const long P = (long)B * L;
@@ -656,6 +706,16 @@ static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
   w.sum_z = bp.take<double>(2 * (size_t)ldb);
   w.sq_z = w.sum_z ? w.sum_z + ldb : nullptr;
   colscr_carve(bp, P, ldc, w.cs);
+  w.H = w.Wr = nullptr;
+  if (conv_dma_shape(ldb, ldc, P) || conv_dma_shape(ldc, ldb, P)) {
+    long dil = 1;
+    for (int i = 1; i < e->nblocks; ++i) dil *= e->dil_base;
+    const long G = (long)(e->ksize / 2) * dil;  // widest guard band
+    const size_t ha = (size_t)(G + (long)B * (L + G)) * round_up(ldc, 32), hb = (size_t)P * round_up(ldb, 32);
+    const size_t wa = (size_t)round_up(e->Cb, 192) * e->ksize * round_up(ldc, 32), wb = (size_t)round_up(e->C, 192) * round_up(ldb, 32);
+    w.H = bp.take<float>(ha > hb ? ha : hb);
+    w.Wr = bp.take<float>(wa > wb ? wa : wb);
+  }
   return bp.ok;
 }
 
@@ -723,6 +783,19 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     p.col_sum = csum; p.col_sumsq = csq;
     if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
     const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
+    if (g_math_mode == 0 && use_f32_dma() && s != nullptr && w.H != nullptr && conv_dma_shape(ld_in, ld_out, P)) {
+      // f32 default: stage relu(bn(in)) once (masked, K padded to 32, guard rows between sequences), re-lay the weights,
+      // then the all-LDS-DMA kernel - bit-identical to the register-staged tap gather below
+      const int Kpad = round_up(ld_in, 32), G = (ntap / 2) * dil, Lp = L + G, Cpad = round_up(Cout, 192);
+      hipLaunchKernelGGL(k_conv_relay_weight, dim3(nblk((long)Cpad * ntap * Kpad, 256)), dim3(256), 0, st, wpk, Cout, ntap,
+                         ld_in, w.Wr, Cpad, Kpad);
+      hipLaunchKernelGGL(k_conv_stage_act, dim3(nblk(((long)G + (long)B * Lp) * (Kpad / 4), 256)), dim3(256), 0, st, in,
+                         (long)ld_in, s, t, (const int*)lens32, w.H, Kpad, B, L, Lp, G, ld_in);
+      HIP_OK(hipGetLastError());
+      p.A = w.H + (long)G * Kpad; p.lda = Kpad; p.a_scale = nullptr; p.a_shift = nullptr;
+      p.W = w.Wr; p.ldw = (long)ntap * Kpad; p.Kseg = Kpad;
+      return launch_conv_dma(p, Lp, ld_in, st);
+    }
     return launch_gemm<A_CONV, E_CONV>(p, big ? 3 : pick_variant(ld_out), st);
   };
 
@@ -963,6 +1036,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
     const int nj = (NL - j0 < chunk) ? NL - j0 : chunk;
     const long rows = (long)nj * B;
     const float* in = nullptr;
+    bool in_act = false;  // `in` holds post-activation values (its producer applied BN + ReLU)
     int zsel = 0;
     if (prod) {
       // concatenation_prod: z1 = A1[i] + B1[j] + (P_e[i] (.) L_e[j]) W1c^T  (not separable: one more pair GEMM)
@@ -982,22 +1056,32 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
       GemmParams p = gp_zero();
       p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
       p.W = hd->w[li]; p.ldw = h; p.wsplit = w.wsplit;
+      // Eval mode knows every BatchNorm fold up front, so a stored layer's BN + ReLU is applied by its PRODUCER (E_STORE
+      // with e_scale / e_shift): the consumer then reads a plain operand, which the 256-tile kernels stage by LDS-DMA
+      // (an all-DMA slab loop instead of a register-staged, generated A operand).  Same fmaf + max on the same values
+      // as the operand-side fold: bit-identical logits.
+      const bool in_is_act = in_act;
       if (from_pairs) {
         p.A = w.A1; p.lda = h; p.A2 = w.B1 + (long)j0 * h; p.lda2 = h; p.pairB = B;
       } else {
-        p.A = in; p.lda = h; p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
+        p.A = in; p.lda = h;
+        if (!in_is_act) { p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1]; }
       }
       if (last) {
         p.e_scale = w.s[li]; p.e_shift = w.t[li]; p.e_w = hd->w_out; p.rowdot_out = w.partials;
         if (from_pairs) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_ROWDOT>(p, 0, st)));
+        else if (in_is_act) PN_OK((launch_gemm<A_PLAIN, E_ROWDOT>(p, 0, st)));
         else PN_OK((launch_gemm<A_AFFINE_RELU, E_ROWDOT>(p, 0, st)));
       } else {
         float* out = w.z[zsel];
         zsel ^= 1;
         p.C = out; p.ldc = h;
+        p.e_scale = w.s[li]; p.e_shift = w.t[li];  // store relu(bn(z_li)) instead of z_li
         if (from_pairs) PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+        else if (in_is_act) PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
         else PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
         in = out;
+        in_act = true;
       }
     }
     hipLaunchKernelGGL(k_rowdot_reduce, dim3(nblk(rows, 256)), dim3(256), 0, st, w.partials, w.nparts, rows,
@@ -2120,8 +2204,13 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
   } else {
     // the stored input of the last layer: ping-pong position after (li - 1) [+1 for prod] stores
     const int nstores = (li - 1) + (prod ? 1 : 0);
-    p.A = w.z[(nstores - 1) & 1]; p.lda = h; p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
-    PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+    p.A = w.z[(nstores - 1) & 1]; p.lda = h;
+    if (prod && li == 1) {  // z1 of concatenation_prod is stored raw (E_PAIRADD)
+      p.a_scale = w.s[li - 1]; p.a_shift = w.t[li - 1];
+      PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+    } else {  // pn_pairhead_fwd_eval stored relu(bn(z_{li-1})) (producer-side activation)
+      PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
+    }
   }
   hipLaunchKernelGGL(k_affine_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)zlast, (long)h,
                      hidden_pairs, (long)h, R, h, (const float*)w.s[li], (const float*)w.t[li]);

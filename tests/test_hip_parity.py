@@ -494,3 +494,44 @@ def test_pairhead_eval_lds_dma_grid_vs_oracle():
         out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
     err = (out.cpu() - ref).abs().max().item()
     assert ref.abs().max().item() > 0.5 and err < 5e-4, err
+
+
+@pytest.mark.parametrize("train_bn", [False, True])
+@pytest.mark.parametrize("B,Lmax,lens", [(10, 450, [450, 1, 333, 450, 77, 449, 40, 5, 256, 129]),
+                                          (3, 2048, [2048, 1500, 129])])
+def test_encoder_conv_dma_bit_identical(B, Lmax, lens, train_bn):
+    """The all-LDS-DMA convolution kernel (gemm_conv_dma.hpp: activation staged with guard rows, re-laid weights,
+    256x192 tiles) against the register-staged tap-gather engine: same products in the same order, padding adds exact
+    zeros -> embeddings (and, in train mode, the BatchNorm running statistics) must agree BIT FOR BIT; and against the
+    oracle.  Lengths include 1, < 4 * dilation and the full pad length; L = 2048 is the zero-shot bucket."""
+    from protnote_amd import _lib as L
+
+    cfg = dict(num_labels=11, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+               num_resnet_blocks=5, bottleneck_factor=0.5)
+    gen = torch.Generator().manual_seed(5)
+    sd = random_encoder_sd(cfg, gen)
+    ids = torch.randint(0, 20, (B, Lmax), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    x[0, :, lens[0]:] = 7.0  # garbage in the padding must not leak
+    lens_t = torch.tensor(lens)
+
+    def run(dma):
+        L.check(L.lib().pn_set_f32_dma(dma))
+        enc = make_encoder({k: v.clone() for k, v in sd.items()}, "", cfg, DEV)
+        enc.train(train_bn)
+        for p in enc.parameters():
+            p.requires_grad = False
+        emb = enc.get_embeddings(x.to(DEV), lens_t.to(DEV))
+        torch.cuda.synchronize()
+        return emb, {k: v.clone() for k, v in enc.state_dict().items()}
+
+    try:
+        (got, sd_got), (old, sd_old) = run(1), run(0)
+    finally:
+        L.lib().pn_set_f32_dma(1)
+    assert torch.equal(got, old)
+    for k in sd_old:
+        assert torch.equal(sd_got[k], sd_old[k]), k
+    if not train_bn:
+        ref = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, x, lens_t)
+        assert (got.cpu() - ref).abs().max().item() < 2e-4
