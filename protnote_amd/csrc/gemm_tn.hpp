@@ -49,6 +49,7 @@ struct TnParams {
   // ---- output ----
   float* Cpart;  // [nsplit][M][ldc]
   long ldc;
+  int task_ns;   // > 0: 1-D grid of 32-workgroup region tasks over a 12 x 12 tile grid with task_ns row splits (see kernel)
 };
 
 // one LDS-DMA wave-instruction (global_load_lds_dwordx4): lane l copies 16 bytes from its own global address to
@@ -91,7 +92,35 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
   int tile_m, tile_n;
-  if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
+  int split = blockIdx.y;
+  if (p.task_ns > 0) {
+    // Region tasks (12 x 12 tiles = the 3072 x 3072 weight gradients).  Workgroup id -> XCD is id % 8 and an XCD has 32
+    // CUs, one 256x256 workgroup each: ids {256 g + 8 i + x, i < 32} are the 32 workgroups XCD x runs TOGETHER in round
+    // g, and they finish together (same work), so round g+1's 32 start together too.  Each such task is one region of
+    // ONE row split whose operand panels the 32 workgroups stream in step through that XCD's 4 MB L2:
+    //   kind 0/1/3: 4 x 8 tiles (4 dz panels + 8 activation panels), kind 2: 8 x 4, and the 4 x 4 corner of two splits
+    //   share a task.  Per split 4 * 12 + 8 = 56 panel reads for 144 tiles (2.3x the 24 of a perfect cache) - and
+    // the sharing no longer depends on which workgroups happen to be co-resident (with one 6 x 3 region per XCD and
+    // split, 18 + 14 workgroups of two splits shared an XCD and drifted apart: fetch 0.7 or 1.6 TB per launch).
+    const int lid = blockIdx.x, xcd = lid & 7, slot = (lid & 255) >> 3;
+    const int T = (lid >> 8) * 8 + xcd, nfull = p.task_ns * 4;
+    if (T < nfull) {
+      split = T >> 2;
+      const int kind = T & 3;
+      if (kind == 2) {
+        tile_m = slot >> 2;
+        tile_n = 8 + (slot & 3);
+      } else {
+        tile_m = (kind == 0 ? 0 : (kind == 1 ? 4 : 8)) + (slot >> 3);
+        tile_n = slot & 7;
+      }
+    } else {
+      split = 2 * (T - nfull) + (slot >> 4);
+      if (split >= p.task_ns) return;
+      tile_m = 8 + ((slot & 15) >> 2);
+      tile_n = 8 + (slot & 3);
+    }
+  } else if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
     // XCD-aware order: workgroup x of a split runs on XCD x % 8; give each XCD one (ntm/2) x (ntn/4) region of
     // the tile grid so it streams 1/2 of dz and 1/4 of the activations through its L2 instead of all of dz
     // and 1/8 of the activations (24x24 tiles: 18 instead of 27 distinct operand tiles per slab and XCD).
@@ -104,7 +133,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     tile_m = blockIdx.x / ntn;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const long r_begin = (long)split * p.rows_per_split;
   long r_end = r_begin + p.rows_per_split;
   if (r_end > p.R) r_end = p.R;

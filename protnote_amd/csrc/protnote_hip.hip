@@ -1221,9 +1221,17 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
     ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
   }
   const unsigned tiles = (unsigned)(((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE));
+  dim3 grid(tiles, (unsigned)ns);
+  static const int task_map = [] { const char* e = getenv("PN_TN_TASKS"); return e ? atoi(e) : 1; }();
+  p.task_ns = 0;
+  if (BIG && task_map && p.M == 3072 && p.N == 3072 && ns >= 2) {  // 12 x 12 tiles: 32-workgroup region tasks (kernel)
+    p.task_ns = ns;
+    const int ntask = ns * 4 + (ns + 1) / 2;
+    grid = dim3((unsigned)((ntask + 7) / 8 * 256), 1);
+  }
   {
     ProfScope ps(100 + TA * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
-    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(BIG ? 512 : 256), LDS, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(BIG ? 512 : 256), LDS, st, p);
   }
   HIP_OK(hipGetLastError());
   if (ns > 1) {
