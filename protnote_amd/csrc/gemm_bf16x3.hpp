@@ -477,7 +477,10 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
 
   const int ntn = p.N / BN, ntm = p.M / BM;
   int tile_m, tile_n;
-  if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {
+  int split = blockIdx.y;
+  if (p.task_ns > 0) {  // 32-workgroup region tasks, see tn_task_coords (gemm_tn.hpp)
+    if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
+  } else if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {
     // the B operand comes from two small tables: only dz streams, so give each XCD as few dz column panels as
     // possible (4 x 2 regions: 3 of the 12 panels instead of 6)
     const int rm = ntm / 4, rn = ntn / 2;
@@ -494,7 +497,6 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
     tile_m = blockIdx.x / ntn;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const long r_begin = (long)split * p.rows_per_split;
   long r_end = r_begin + p.rows_per_split;
   if (r_end > p.R) r_end = p.R;

@@ -63,6 +63,38 @@ __device__ __forceinline__ void tn_glds16(const float* gsrc, unsigned lds_base_u
       : "memory");
 }
 
+// Region tasks (12 x 12 tiles = the 3072 x 3072 weight gradients; 1-D grid).  Workgroup id -> XCD is id % 8 and an XCD
+// has 32 CUs, one 256x256 workgroup each: ids {256 g + 8 i + x, i < 32} are the 32 workgroups XCD x runs TOGETHER in
+// round g, and they finish together (same work), so round g+1's 32 start together too.  Each such task is one region of
+// ONE row split whose operand panels the 32 workgroups stream in step through that XCD's 4 MB L2:
+//   kind 0/1/3: 4 x 8 tiles (4 dz panels + 8 activation panels), kind 2: 8 x 4, and the 4 x 4 corners of two splits
+//   share a task.  Per split 4 * 12 + 8 = 56 panel reads for 144 tiles (2.3x the 24 of a perfect cache) - and the
+// sharing no longer depends on which workgroups happen to be co-resident (with one 6 x 3 region per XCD and split,
+// 18 + 14 workgroups of two splits shared an XCD and drifted apart: fetch 0.7 or 1.6 TB per launch, measured
+// 0.73 -> 0.49 TB and L2 hit rate 0.70 -> 0.80, profiles/r02_tn_region_tasks_ab.json).  false = padding workgroup.
+__device__ __forceinline__ bool tn_task_coords(int task_ns, int& tile_m, int& tile_n, int& split) {
+  const int lid = blockIdx.x, xcd = lid & 7, slot = (lid & 255) >> 3;
+  const int T = (lid >> 8) * 8 + xcd, nfull = task_ns * 4;
+  if (T < nfull) {
+    split = T >> 2;
+    const int kind = T & 3;
+    if (kind == 2) {
+      tile_m = slot >> 2;
+      tile_n = 8 + (slot & 3);
+    } else {
+      tile_m = (kind == 0 ? 0 : (kind == 1 ? 4 : 8)) + (slot >> 3);
+      tile_n = slot & 7;
+    }
+    return true;
+  }
+  split = 2 * (T - nfull) + (slot >> 4);
+  if (split >= task_ns) return false;
+  tile_m = 8 + ((slot & 15) >> 2);
+  tile_n = 8 + (slot & 3);
+  return true;
+}
+inline unsigned tn_task_grid(int ns) { return (unsigned)((ns * 4 + (ns + 1) / 2 + 7) / 8 * 256); }
+
 // BIG = false: 128x128 output tile, 4 waves (2x2, each 64x64), 2 workgroups/CU.
 // BIG = true : 256x256 output tile, 8 waves (4x2, each 64x128), 1 workgroup/CU - half the operand traffic per flop.
 // ADMA (BIG, TA_PLAIN, every split a whole number of slabs): the plain A operand (the materialised dz) goes global ->
@@ -94,32 +126,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
   int tile_m, tile_n;
   int split = blockIdx.y;
   if (p.task_ns > 0) {
-    // Region tasks (12 x 12 tiles = the 3072 x 3072 weight gradients).  Workgroup id -> XCD is id % 8 and an XCD has 32
-    // CUs, one 256x256 workgroup each: ids {256 g + 8 i + x, i < 32} are the 32 workgroups XCD x runs TOGETHER in round
-    // g, and they finish together (same work), so round g+1's 32 start together too.  Each such task is one region of
-    // ONE row split whose operand panels the 32 workgroups stream in step through that XCD's 4 MB L2:
-    //   kind 0/1/3: 4 x 8 tiles (4 dz panels + 8 activation panels), kind 2: 8 x 4, and the 4 x 4 corner of two splits
-    //   share a task.  Per split 4 * 12 + 8 = 56 panel reads for 144 tiles (2.3x the 24 of a perfect cache) - and
-    // the sharing no longer depends on which workgroups happen to be co-resident (with one 6 x 3 region per XCD and
-    // split, 18 + 14 workgroups of two splits shared an XCD and drifted apart: fetch 0.7 or 1.6 TB per launch).
-    const int lid = blockIdx.x, xcd = lid & 7, slot = (lid & 255) >> 3;
-    const int T = (lid >> 8) * 8 + xcd, nfull = p.task_ns * 4;
-    if (T < nfull) {
-      split = T >> 2;
-      const int kind = T & 3;
-      if (kind == 2) {
-        tile_m = slot >> 2;
-        tile_n = 8 + (slot & 3);
-      } else {
-        tile_m = (kind == 0 ? 0 : (kind == 1 ? 4 : 8)) + (slot >> 3);
-        tile_n = slot & 7;
-      }
-    } else {
-      split = 2 * (T - nfull) + (slot >> 4);
-      if (split >= p.task_ns) return;
-      tile_m = 8 + ((slot & 15) >> 2);
-      tile_n = 8 + (slot & 3);
-    }
+    if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
   } else if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
     // XCD-aware order: workgroup x of a split runs on XCD x % 8; give each XCD one (ntm/2) x (ntn/4) region of
     // the tile grid so it streams 1/2 of dz and 1/4 of the activations through its L2 instead of all of dz

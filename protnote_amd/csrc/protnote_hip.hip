@@ -1195,6 +1195,12 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile,
   return (int)ns;
 }
 
+// PN_TN_TASKS=0 restores the per-split XCD regions (A/B measurements: tools/pmc_tn_tasks.sh)
+static bool tn_task_map() {
+  static const int on = [] { const char* e = getenv("PN_TN_TASKS"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
 template <int TA, int TB, bool BIG, bool ADMA = false, bool DROP = false>
 static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   auto kern = gemm_tn_kernel<TA, TB, BIG, ADMA, DROP>;
@@ -1222,12 +1228,10 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
   }
   const unsigned tiles = (unsigned)(((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE));
   dim3 grid(tiles, (unsigned)ns);
-  static const int task_map = [] { const char* e = getenv("PN_TN_TASKS"); return e ? atoi(e) : 1; }();
   p.task_ns = 0;
-  if (BIG && task_map && p.M == 3072 && p.N == 3072 && ns >= 2) {  // 12 x 12 tiles: 32-workgroup region tasks (kernel)
+  if (BIG && tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {  // 12 x 12 tiles: 32-workgroup region tasks
     p.task_ns = ns;
-    const int ntask = ns * 4 + (ns + 1) / 2;
-    grid = dim3((unsigned)((ntask + 7) / 8 * 256), 1);
+    grid = dim3(tn_task_grid(ns), 1);
   }
   {
     ProfScope ps(100 + TA * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
@@ -1267,9 +1271,15 @@ static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_
     ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
   }
   const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
+  dim3 grid(tiles, (unsigned)ns);
+  p.task_ns = 0;
+  if (tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {
+    p.task_ns = ns;
+    grid = dim3(tn_task_grid(ns), 1);
+  }
   {
     ProfScope ps(1100 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
-    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)ns), dim3(512), LDS, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, st, p);
   }
   HIP_OK(hipGetLastError());
   if (ns > 1) {
