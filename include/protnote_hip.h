@@ -286,6 +286,16 @@ size_t pn_ap_ws_bytes(int N_L, long long n, long long cap, int micro);
 int pn_ap_compute(const uint32_t* keys, const uint8_t* hits, int N_L, long long n, long long cap, double* ap,
                   long long* npos, double* micro_ap, long long* micro_npos, void* ws, size_t ws_bytes, void* stream);
 
+/* Multi-GPU micro AP without gathering the evaluation set on every GPU (the reference's sync_and_compute ships every
+ * rank's scores to every rank, ProtNoteTrainer.py:655-657): after a sample-sort exchange this GPU holds ALL pairs of the
+ * evaluation whose key falls into one key range; tp_before / k_before = positives / pairs held by the higher-ranked
+ * ranges.  partial [1] f64 = sum over this range's tie groups of (TP_g - TP_{g-1}) * TP_g / k_g with the global TP_g, k_g
+ * (not normalised), npos [1] i64 = positives of the range; micro AP = sum(partial) / sum(npos) over the GPUs.
+ * keys / hits [m] are not modified. */
+size_t pn_ap_partial_ws_bytes(long long m);
+int pn_ap_partial(const uint32_t* keys, const uint8_t* hits, long long m, long long tp_before, long long k_before,
+                  double* partial, long long* npos, void* ws, size_t ws_bytes, void* stream);
+
 /* Binned AUPRC.  Streaming state: pos_hist / all_hist [(N_L+1)][T+1] u64 (zero-initialised by the caller; row N_L
  * = all labels pooled, written by pn_binned_auprc when with_micro), bin(p) = #{k : p >= thresholds[k]},
  * thresholds [T] ascending f32 on the device (T <= 120).

@@ -140,6 +140,9 @@ _SIGS = {
     "pn_ap_ws_bytes": (C.c_size_t, [C.c_int, C.c_longlong, C.c_longlong, C.c_int]),
     "pn_ap_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_ap_partial_ws_bytes": (C.c_size_t, [C.c_longlong]),
+    "pn_ap_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_binned_hist_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pn_binned_auprc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

@@ -107,6 +107,8 @@ struct ApSeg {
   long long n;       // elements per segment
   long long chunk;   // elements per chunk (multiple of AP_TILE)
   int nchunks;
+  long long tp0, k0;  // rank offsets of a key-range shard of a larger ranking (pn_ap_partial): positives / elements
+                      // that rank before this segment's first element; 0 for a whole ranking
 };
 
 __device__ __forceinline__ long long block_sum(long long v, long long* sh) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(AP_T) void k_ap_apply(ApSeg sg, const long long* __
       const long long i = b + e;
       tp += hh[e];
       if (i < hi && (i == sg.n - 1 || kk[e] != kk[e + 1])) {
-        if (tp > prev) acc += (double)(tp - prev) * (double)tp / (double)(i + 1);
+        if (tp > prev) acc += (double)(tp - prev) * (double)(tp + sg.tp0) / (double)(i + 1 + sg.k0);
         prev = tp;
       }
     }
@@ -267,12 +269,13 @@ __global__ __launch_bounds__(AP_T) void k_ap_apply(ApSeg sg, const long long* __
 }
 
 __global__ void k_ap_final(int nseg, int nchunks, const double* __restrict__ c_part, const long long* __restrict__ npos,
-                           double* __restrict__ ap) {
+                           double* __restrict__ ap, int raw) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= nseg) return;
   double t = 0;
   for (int c = 0; c < nchunks; ++c) t += c_part[(long long)seg * nchunks + c];
-  ap[seg] = npos[seg] > 0 ? t / (double)npos[seg] : __longlong_as_double(0x7ff8000000000000LL);
+  if (raw) ap[seg] = t;  // un-normalised partial of a sharded ranking
+  else ap[seg] = npos[seg] > 0 ? t / (double)npos[seg] : __longlong_as_double(0x7ff8000000000000LL);
 }
 
 struct SegOff {  // offset of segment j: begin = j*stride, end = j*stride + n
@@ -311,8 +314,8 @@ char* carve(char* p, ApScratch& s, long long nseg, int nchunks) {
 }
 
 int ap_of_sorted(const uint32_t* keys, const uint8_t* hits, long long nseg, long long n, long long stride, char* scratch,
-                 double* ap, long long* npos_out, hipStream_t st) {
-  ApSeg sg{keys, hits, stride, n, chunk_for(n), 0};
+                 double* ap, long long* npos_out, hipStream_t st, long long tp0 = 0, long long k0 = 0, int raw = 0) {
+  ApSeg sg{keys, hits, stride, n, chunk_for(n), 0, tp0, k0};
   sg.nchunks = (int)((n + sg.chunk - 1) / sg.chunk);
   ApScratch s;
   carve(scratch, s, nseg, sg.nchunks);
@@ -334,7 +337,7 @@ int ap_of_sorted(const uint32_t* keys, const uint8_t* hits, long long nseg, long
     const long long o = s0 * sg.nchunks;
     hipLaunchKernelGGL(k_ap_apply, dim3(sg.nchunks, ns), dim3(AP_T), 0, st, g, s.c_tp_before + o, s.c_prev_end + o, s.c_part + o);
   }
-  hipLaunchKernelGGL(k_ap_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, (int)nseg, sg.nchunks, s.c_part, s.npos, ap);
+  hipLaunchKernelGGL(k_ap_final, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, (int)nseg, sg.nchunks, s.c_part, s.npos, ap, raw);
   if (npos_out) HIP_OK(hipMemcpyAsync(npos_out, s.npos, (size_t)nseg * 8, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipGetLastError());
   return 0;
@@ -450,6 +453,44 @@ extern "C" int pn_ap_compute(const uint32_t* keys, const uint8_t* hits, int N_L,
     if (ap_of_sorted(sk, shh, 1, (long long)total, 0, base + p.scratch, micro_ap, micro_npos, st)) return 1;
   }
   return 0;
+}
+
+// Sharded ranking (multi-GPU micro AP): this rank holds ALL pairs of the whole evaluation whose key lies in one key
+// range (a sample-sort bucket); tp_before / k_before = positives / pairs of the higher-ranked buckets.  Writes the
+// un-normalised partial sum over this bucket's tie groups of (TP_g - TP_{g-1}) * TP_g / k_g with the GLOBAL TP_g and
+// k_g, and the bucket's positives; micro AP = (sum of partials over ranks) / (sum of positives).
+extern "C" size_t pn_ap_partial_ws_bytes(long long m) {
+  if (m <= 0) return 256;
+  size_t t_flat = 0;
+  if (rocprim::radix_sort_pairs_desc(nullptr, t_flat, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint8_t*)nullptr,
+                                     (uint8_t*)nullptr, (size_t)m, 0, 32, (hipStream_t)0) != hipSuccess)
+    return 0;
+  const long long ch = chunk_for(m);
+  return al256((size_t)m * 4) + al256((size_t)m) + al256(t_flat ? t_flat : 1) + scratch_bytes(1, (int)((m + ch - 1) / ch)) + 512;
+}
+
+extern "C" int pn_ap_partial(const uint32_t* keys, const uint8_t* hits, long long m, long long tp_before, long long k_before,
+                             double* partial, long long* npos, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (m < 0 || tp_before < 0 || k_before < 0) return fail_msg("pn_ap_partial: negative size / offset");
+  if (m == 0) {
+    HIP_OK(hipMemsetAsync(partial, 0, sizeof(double), st));
+    HIP_OK(hipMemsetAsync(npos, 0, sizeof(long long), st));
+    return 0;
+  }
+  const size_t need = pn_ap_partial_ws_bytes(m);
+  if (need == 0) return fail_msg("rocprim radix sort: temp-storage query failed");
+  if (ws_bytes < need) return fail_msg("pn_ap_partial: workspace %zu < %zu bytes", ws_bytes, need);
+  char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  uint32_t* sk = (uint32_t*)base;
+  uint8_t* shh = (uint8_t*)(base + al256((size_t)m * 4));
+  size_t t_flat = 0;
+  rocprim::radix_sort_pairs_desc(nullptr, t_flat, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint8_t*)nullptr,
+                                 (uint8_t*)nullptr, (size_t)m, 0, 32, (hipStream_t)0);
+  char* tmp = base + al256((size_t)m * 4) + al256((size_t)m);
+  size_t tb = t_flat;
+  HIP_OK(rocprim::radix_sort_pairs_desc(tmp, tb, keys, sk, hits, shh, (size_t)m, 0, 32, st));
+  return ap_of_sorted(sk, shh, 1, m, 0, tmp + al256(t_flat ? t_flat : 1), partial, npos, st, tp_before, k_before, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -77,32 +77,116 @@ class DeviceAveragePrecision:
                                            _lib.stream_ptr()))
         self.n += B
 
-    def _gathered(self):
-        """Scores of all ranks side by side along the protein axis (every rank computes the same metric)."""
+    # ------------------------------------------------------------------------------------------------------------
+    # multi-GPU: the evaluation set is sharded by proteins (each rank scored its own sequences against all labels).
+    # Nothing is gathered onto every GPU.  Per-label AP: labels are dealt to the ranks in contiguous blocks and ONE
+    # all-to-all moves each label's columns to its owner (5 B per pair of the whole set, 1/W of it per GPU).  Micro AP:
+    # a sample sort - the global histogram of the keys' upper 16 bits (one 512 KB all-reduce) cuts the key space into W
+    # ranges of about equal population, a second all-to-all sends every pair to the owner of its range, each owner ranks
+    # its range (pn_ap_partial, given the positives / pairs of the higher ranges) and one all-reduce adds the partials.
+    # Equal keys share a range, so tie groups never straddle GPUs: the result is the single-GPU arithmetic.
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _exchange(chunks):
+        """Variable-size all-to-all of 1-D tensors: chunks[v] goes to rank v; returns what every rank sent here."""
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return self.keys, self.hits, self.n, self.capacity
-        W = dist.get_world_size()
-        ns = [torch.zeros(1, dtype=torch.int64, device=self.keys.device) for _ in range(W)]
-        dist.all_gather(ns, torch.tensor([self.n], dtype=torch.int64, device=self.keys.device))
+        W, rank, dev = dist.get_world_size(), dist.get_rank(), chunks[0].device
+        cnt = torch.tensor([c.numel() for c in chunks], dtype=torch.int64, device=dev)
+        allc = [torch.empty_like(cnt) for _ in range(W)]
+        dist.all_gather(allc, cnt)
+        recv = [int(allc[v][rank]) for v in range(W)]
+        sent = [int(c.numel()) for c in chunks]
+        inp = torch.cat(chunks)
+        out = torch.empty(sum(recv), dtype=inp.dtype, device=dev)
+        if dist.get_backend() == "nccl":  # RCCL over xGMI
+            dist.all_to_all_single(out, inp, recv, sent)
+        else:  # gloo (single-GPU dry runs and the CPU-transport tests): staged through the host
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), recv, sent)
+            out.copy_(o)
+        return list(out.split(recv))
+
+    def _compute_sharded(self, micro: bool) -> dict:
+        import torch.distributed as dist
+
+        L, W, rank, dev = _lib.lib(), dist.get_world_size(), dist.get_rank(), self.keys.device
+        nt = torch.tensor([self.n], dtype=torch.int64, device=dev)
+        ns = [torch.empty_like(nt) for _ in range(W)]
+        dist.all_gather(ns, nt)
         ns = [int(v) for v in ns]
-        nmax = max(ns)
-        if nmax == 0:
-            return self.keys, self.hits, 0, self.capacity
-        k_loc = torch.zeros(self.num_labels, nmax, dtype=torch.int32, device=self.keys.device)
-        h_loc = torch.zeros(self.num_labels, nmax, dtype=torch.uint8, device=self.keys.device)
-        k_loc[:, :self.n], h_loc[:, :self.n] = self.keys[:, :self.n], self.hits[:, :self.n]
-        k_all = [torch.empty_like(k_loc) for _ in range(W)]
-        h_all = [torch.empty_like(h_loc) for _ in range(W)]
-        dist.all_gather(k_all, k_loc)
-        dist.all_gather(h_all, h_loc)
-        keys = torch.cat([k[:, :m] for k, m in zip(k_all, ns)], dim=1).contiguous()
-        hits = torch.cat([h[:, :m] for h, m in zip(h_all, ns)], dim=1).contiguous()
-        return keys, hits, sum(ns), sum(ns)
+        n_tot = sum(ns)
+        if n_tot == 0:
+            raise RuntimeError("DeviceAveragePrecision.compute() before any update()")
+        NL = self.num_labels
+        k_loc, h_loc = self.keys[:, :self.n], self.hits[:, :self.n]
+        # ---- per-label AP: rank v ranks labels [bounds[v], bounds[v+1]) over the proteins of ALL ranks
+        bounds = [(NL * v) // W for v in range(W + 1)]
+        rk = self._exchange([k_loc[bounds[v]:bounds[v + 1]].reshape(-1) for v in range(W)])
+        rh = self._exchange([h_loc[bounds[v]:bounds[v + 1]].reshape(-1) for v in range(W)])
+        mine = bounds[rank + 1] - bounds[rank]
+        lmax = max(bounds[v + 1] - bounds[v] for v in range(W))
+        ap_me = torch.full((lmax,), float("nan"), dtype=torch.float64, device=dev)
+        np_me = torch.zeros(lmax, dtype=torch.int64, device=dev)
+        if mine > 0:
+            keys = torch.cat([t.view(mine, ns[u]) for u, t in enumerate(rk)], dim=1).contiguous()
+            hits = torch.cat([t.view(mine, ns[u]) for u, t in enumerate(rh)], dim=1).contiguous()
+            nbytes = L.pn_ap_ws_bytes(mine, n_tot, n_tot, 0)
+            if nbytes == 0:
+                _lib.check(1)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.pn_ap_compute(_lib.ptr(keys), _lib.ptr(hits), mine, n_tot, n_tot, _lib.ptr(ap_me), _lib.ptr(np_me),
+                                       None, None, _lib.ptr(ws), nbytes, _lib.stream_ptr()))
+            del ws, keys, hits
+        del rk, rh
+        ap_all = [torch.empty_like(ap_me) for _ in range(W)]
+        np_all = [torch.empty_like(np_me) for _ in range(W)]
+        dist.all_gather(ap_all, ap_me)
+        dist.all_gather(np_all, np_me)
+        ap = torch.cat([a[:bounds[v + 1] - bounds[v]] for v, a in enumerate(ap_all)])
+        npos = torch.cat([a[:bounds[v + 1] - bounds[v]] for v, a in enumerate(np_all)])
+        out = {"ap_per_label": ap, "positives_per_label": npos, "map_macro": _macro(ap, self.empty_label_ap)}
+        if not micro:
+            return out
+        # ---- micro AP: sample sort by the upper 16 key bits (u32 keys live in int32 storage)
+        kf, hf = k_loc.reshape(-1), h_loc.reshape(-1)
+        hi16 = (kf.long() & 0xFFFFFFFF) >> 16
+        hist = torch.bincount(hi16, minlength=65536)
+        dist.all_reduce(hist)
+        top = hist.flip(0)  # descending key order: range 0 holds the best-ranked pairs
+        before = torch.cumsum(top, 0) - top
+        lut = torch.clamp((before * W) // torch.clamp(top.sum(), min=1), max=W - 1).flip(0)
+        dest = lut[hi16]
+        del hi16
+        sel = [dest == v for v in range(W)]
+        mk = torch.cat(self._exchange([kf[m] for m in sel]))
+        mh = torch.cat(self._exchange([hf[m] for m in sel]))
+        del sel, dest
+        tot = torch.stack([mh.sum(dtype=torch.int64), torch.tensor(mk.numel(), dtype=torch.int64, device=dev)])
+        tots = [torch.empty_like(tot) for _ in range(W)]
+        dist.all_gather(tots, tot)
+        tp_before = sum(int(t[0]) for t in tots[:rank])
+        k_before = sum(int(t[1]) for t in tots[:rank])
+        part = torch.zeros(1, dtype=torch.float64, device=dev)
+        pnp = torch.zeros(1, dtype=torch.int64, device=dev)
+        m = int(mk.numel())
+        nbytes = L.pn_ap_partial_ws_bytes(m)
+        if nbytes == 0:
+            _lib.check(1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.pn_ap_partial(_lib.ptr(mk) if m else None, _lib.ptr(mh) if m else None, m, tp_before, k_before,
+                                   _lib.ptr(part), _lib.ptr(pnp), _lib.ptr(ws), nbytes, _lib.stream_ptr()))
+        both = torch.stack([part[0], pnp[0].double()])
+        dist.all_reduce(both)
+        out["map_micro"] = float(both[0] / both[1]) if float(both[1]) > 0 else float("nan")
+        return out
 
     def compute(self, micro: bool = True) -> dict:
-        keys, hits, n, cap = self._gathered()
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return self._compute_sharded(micro)
+        keys, hits, n, cap = self.keys, self.hits, self.n, self.capacity
         if n == 0:
             raise RuntimeError("DeviceAveragePrecision.compute() before any update()")
         L = _lib.lib()

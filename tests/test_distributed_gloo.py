@@ -124,3 +124,42 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from protnote_amd.utils import distributed as D
+    from protnote_amd.utils.evaluation import DeviceAveragePrecision
+
+    D.init_from_env(backend="gloo")
+    # rank r sends r + v + 1 elements to rank v (value = 100 * sender + 10 * receiver + position), one chunk may be empty
+    chunks = [torch.arange(rank + v + 1, dtype=torch.int32) + 100 * rank + 10 * v for v in range(world)]
+    if rank == 1:
+        chunks[0] = chunks[0][:0]
+    got = DeviceAveragePrecision._exchange(chunks)
+    import pickle
+
+    q.put(pickle.dumps((rank, [g.clone() for g in got])))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_variable_exchange():
+    """The all-to-all of the rank-sharded exact AP (label blocks to their owner, key ranges to theirs): uneven and empty
+    chunks arrive at the right rank in sender order."""
+    import pickle
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((pickle.loads(q.get(timeout=120)) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res[0][1], res[1][1]
+    assert r0[0].tolist() == [0] and r0[1].tolist() == []                      # from rank 0: 1 element; from rank 1: empty
+    assert r1[0].tolist() == [10, 11] and r1[1].tolist() == [110, 111, 112]    # from rank 0: 2; from rank 1: 3

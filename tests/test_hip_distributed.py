@@ -1,6 +1,7 @@
 """Two ranks on ONE MI355X (PN_SHARE_GPU=1, gloo moving the device tensors): the data-parallel code paths with real
 HIP buffers - flat-gradient all-reduce inside train_step, BN-buffer broadcast, and the cross-rank evaluation metrics
-(exact AP gathers the score columns of all ranks, binned AUPRC all-reduces its histograms).  On the 8-GPU node the same
+(exact AP: label-sharded all-to-all for the per-label ranking + a sample sort for the micro ranking, nothing gathered
+on every rank; binned AUPRC all-reduces its histograms).  On the 8-GPU node the same
 code runs over RCCL."""
 import os
 import socket
@@ -24,10 +25,14 @@ def _free_port():
 
 def _data():
     g = torch.Generator().manual_seed(3)
-    n, nl = 600, 37
+    n, nl = 601, 37  # odd: the two ranks hold shards of different size
     logits = torch.randn(n, nl, generator=g) * 2
     y = (torch.rand(n, nl, generator=g) < 0.1) | ((logits > 2) & (torch.rand(n, nl, generator=g) < 0.5))
-    return torch.sigmoid(logits).float(), y
+    p = torch.sigmoid(logits).float()
+    p[:, :10] = torch.round(p[:, :10] * 20) / 20  # heavy ties: tie groups span both ranks' shards
+    p[:, 10] = 0.25                               # one label all tied
+    y[:, 5] = False                               # one label without positives (AP = NaN, macro counts it as 0)
+    return p, y
 
 
 def _worker(rank, world, port, q, backend="gloo"):
@@ -117,7 +122,7 @@ def _run_two_ranks(backend):
     for _, mi, ma, apl, bmi, bma, _w, _gn in res:  # every rank reports the metric of the WHOLE evaluation set
         np.testing.assert_allclose(mi, micro, rtol=1e-12)
         np.testing.assert_allclose(ma, MO.macro_mean(per), rtol=1e-12)
-        np.testing.assert_allclose(apl, per, rtol=1e-12)
+        np.testing.assert_allclose(apl, per, rtol=1e-12)  # NaN (label 5) in the same place
         np.testing.assert_allclose(bmi, bmicro, rtol=1e-12)
         np.testing.assert_allclose(bma, bmacro, rtol=1e-12)
     # averaged gradients + identical start => identical parameters on both ranks after the step

@@ -169,3 +169,39 @@ def test_exact_ap_full_label_set_known_answer():
     micro = float(np.sum(pos_at_rank * tp / (ranks * NL)) / tp[-1])
     np.testing.assert_allclose(out["map_micro"], micro, rtol=1e-12)
     np.testing.assert_array_equal(out["positives_per_label"].cpu().numpy()[keep], (n // m.numpy())[keep])
+
+
+@pytest.mark.parametrize("n,nl,cuts,kw", [(5000, 7, 3, dict(ties=True)), (40000, 5, 8, {}), (300, 3, 8, dict(saturate=True))])
+def test_ap_partial_key_ranges_sum_to_the_whole_ranking(n, nl, cuts, kw):
+    """pn_ap_partial (the per-GPU piece of the multi-GPU micro AP): cut the key space into `cuts` ranges (equal keys
+    share a range, some ranges may be empty), rank every range on its own with the positives / pairs of the higher
+    ranges as offsets - the partial sums add up to the AP of the whole ranking (oracle, 1e-12)."""
+    from protnote_amd import _lib as L
+    from protnote_amd.utils.evaluation import DeviceAveragePrecision
+
+    p, y = _case(n, nl, seed=n + cuts, **kw)
+    acc = DeviceAveragePrecision(nl, n, DEV)
+    acc.update(p.to(DEV), y.to(DEV))
+    keys, hits = acc.keys[:, :n].reshape(-1), acc.hits[:, :n].reshape(-1)
+    k64 = keys.long() & 0xFFFFFFFF
+    edges = torch.quantile(k64.double().cpu(), torch.linspace(0, 1, cuts + 1, dtype=torch.float64)[1:-1]).long().to(DEV)
+    dest = (cuts - 1) - torch.bucketize(k64, edges, right=True)  # range 0 = highest keys
+    total, npos_total, tp_before, k_before = 0.0, 0, 0, 0
+    for v in range(cuts):
+        sel = dest == v
+        mk, mh = keys[sel].contiguous(), hits[sel].contiguous()
+        m = int(mk.numel())
+        part = torch.zeros(1, dtype=torch.float64, device=DEV)
+        npos = torch.zeros(1, dtype=torch.int64, device=DEV)
+        nbytes = L.lib().pn_ap_partial_ws_bytes(m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        L.check(L.lib().pn_ap_partial(L.ptr(mk) if m else None, L.ptr(mh) if m else None, m, tp_before, k_before,
+                                      L.ptr(part), L.ptr(npos), L.ptr(ws), nbytes, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert int(npos) == int(mh.sum())
+        total += float(part)
+        npos_total += int(npos)
+        tp_before += int(npos)
+        k_before += m
+    micro = MO.average_precision_fast(p.numpy().ravel(), y.numpy().ravel())
+    np.testing.assert_allclose(total / npos_total, micro, rtol=1e-12)
