@@ -312,6 +312,16 @@ int pn_binned_auprc(unsigned long long* pos_hist, unsigned long long* all_hist, 
  * matrix pipe with f32 accumulation - ~1e-5 relative error per product instead of 6e-8, several times faster.
  * The encoder, the row MLPs (W_p, W_l) and all reductions stay f32 in either mode. */
 int pn_set_math_mode(int mode);
+
+/* SYNC_BN: True (reference bin/main.py:449-450, nn.SyncBatchNorm.convert_sync_batchnorm): train-mode BatchNorm of the
+ * encoder, the projection heads and the pair head takes its statistics over the batches of ALL ranks, in the forward
+ * (sum, sum of squares) and in the backward (sum du, sum du*xhat; dgamma / dbeta stay rank-local, as in torch's
+ * SyncBatchNorm).  The library calls hook(n, user) whenever the first n doubles of `stage` (device memory) must be
+ * summed over the ranks, in place and ordered on the stream the library was called on; it returns 0 on success.
+ * `world` = number of ranks; every rank must run the same batch shape.  hook == NULL switches back to per-rank
+ * statistics (the default, SYNC_BN: False). */
+typedef int (*pn_sync_hook)(long n_doubles, void* user);
+int pn_set_sync_bn(pn_sync_hook hook, void* user, double* stage, long stage_doubles, int world);
 int pn_get_math_mode(void);
 
 /* Operand staging of the f32 pair-grid GEMMs: 1 (default; env PN_F32_DMA) = LDS-DMA (global_load_lds, gemm_dma.hpp),

@@ -227,6 +227,47 @@ extern "C" int pn_dropout_mask(unsigned seed, int stream, float p, long rows, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// SYNC_BN (reference bin/main.py:449-450, nn.SyncBatchNorm.convert_sync_batchnorm): train-mode BatchNorm statistics over
+// the batches of ALL ranks.  The statistics of a layer are reduced inside one C call, between the GEMM that accumulates
+// them and the fold that consumes them, so the cross-rank sum is a callback: the host registers `hook(n, user)`, which
+// must sum the first n doubles of the staging buffer over the ranks in place, ordered on the launch stream
+// (protnote_amd.utils.distributed.enable_sync_batchnorm: torch.distributed.all_reduce = RCCL).  Forward: per-column
+// [sum, sum of squares] travel and the count is multiplied by the world size (every rank runs the same batch shape, as
+// the reference's DistributedSampler guarantees).  Backward: [sum du, sum du*xhat] travel for the dz generator's p / q
+// vectors, while dgamma / dbeta stay the LOCAL sums (the gradient all-reduce averages them like every other
+// gradient) - torch's SyncBatchNorm backward.
+// ------------------------------------------------------------------------------------------------
+typedef int (*pn_sync_hook_t)(long n_doubles, void* user);
+static pn_sync_hook_t g_sync_hook = nullptr;
+static void* g_sync_user = nullptr;
+static double* g_sync_stage = nullptr;
+static long g_sync_cap = 0;
+static int g_sync_world = 1;
+
+extern "C" int pn_set_sync_bn(pn_sync_hook_t hook, void* user, double* stage, long stage_doubles, int world) {
+  if (hook == nullptr) {
+    g_sync_hook = nullptr; g_sync_user = nullptr; g_sync_stage = nullptr; g_sync_cap = 0; g_sync_world = 1;
+    return 0;
+  }
+  if (stage == nullptr || stage_doubles < 4096 || world < 1) return fail("pn_set_sync_bn: need a staging buffer of >= 4096 doubles and world >= 1");
+  g_sync_hook = hook; g_sync_user = user; g_sync_stage = stage; g_sync_cap = stage_doubles; g_sync_world = world;
+  return 0;
+}
+static bool sync_bn_on() { return g_sync_hook != nullptr && g_sync_world > 1; }
+// a[0..n) and b[0..n) (device, f64) become their sums over the ranks
+static int sync_sum2(double* a, double* b, long n, hipStream_t st) {
+  if (!sync_bn_on()) return 0;
+  if (2 * n > g_sync_cap) return fail("sync_bn: %ld statistics exceed the staging buffer (%ld doubles)", 2 * n, g_sync_cap);
+  HIP_OK(hipMemcpyAsync(g_sync_stage, a, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(g_sync_stage + n, b, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (g_sync_hook(2 * n, g_sync_user) != 0) return fail("sync_bn: the all-reduce callback failed");
+  HIP_OK(hipMemcpyAsync(a, g_sync_stage, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(b, g_sync_stage + n, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+static double sync_count(double local) { return sync_bn_on() ? local * (double)g_sync_world : local; }
+
+// ------------------------------------------------------------------------------------------------
 // GEMM launch
 // ------------------------------------------------------------------------------------------------
 template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool DROP = false>
@@ -575,6 +616,16 @@ __global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq
   t[c] = sh;
 }
 
+// fold of a train-mode BatchNorm from this rank's column sums; with SYNC_BN the sums of all ranks (see pn_set_sync_bn)
+static int fold_train(hipStream_t st, pn_bn bn, const double* sum, const double* sumsq, double count, float eps,
+                      float momentum, int C, int ld, float* s, float* t, float* mean_out, float* invstd_out) {
+  PN_OK(sync_sum2(const_cast<double*>(sum), const_cast<double*>(sumsq), C, st));
+  hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ld, 256)), dim3(256), 0, st, bn, sum, sumsq, sync_count(count), eps,
+                     momentum, C, ld, s, t, mean_out, invstd_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // masked mean over positions (protein_encoders.py:114-117); x is channels-last and already zero at pads
 __global__ void k_pool(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ emb, int L,
                        int C, int ldx, int ld_emb) {
@@ -816,9 +867,9 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     if (sv) xn = sv->X[i + 1];
     // bn_activation_1 folded into conv_a's operand load
     if (training) {
-      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const double*)w.sum_x,
+      PN_OK(fold_train(st, bk.bn1, (const double*)w.sum_x,
                          (const double*)w.sq_x, (double)P, bn_eps, bn_mom, e->C, ldc, s1, t1,
-                         sv ? sv->m1[i] : (float*)nullptr, sv ? sv->i1[i] : (float*)nullptr);
+                         sv ? sv->m1[i] : (float*)nullptr, sv ? sv->i1[i] : (float*)nullptr));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldc, 256)), dim3(256), 0, st, bk.bn1, (const float*)nullptr,
                          bn_eps, e->C, ldc, s1, t1);
@@ -826,9 +877,9 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     PN_OK(conv(x, ldc, bk.conv_a_w, bk.conv_a_b, e->Cb, ldb, z, e->ksize, dil, s1, t1, nullptr,
                training ? w.sum_z : nullptr, training ? w.sq_z : nullptr));
     if (training) {
-      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const double*)w.sum_z,
+      PN_OK(fold_train(st, bk.bn2, (const double*)w.sum_z,
                          (const double*)w.sq_z, (double)P, bn_eps, bn_mom, e->Cb, ldb, s2, t2,
-                         sv ? sv->m2[i] : (float*)nullptr, sv ? sv->i2[i] : (float*)nullptr);
+                         sv ? sv->m2[i] : (float*)nullptr, sv ? sv->i2[i] : (float*)nullptr));
     } else {
       hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldb, 256)), dim3(256), 0, st, bk.bn2, (const float*)nullptr,
                          bn_eps, e->Cb, ldb, s2, t2);
@@ -1328,6 +1379,25 @@ static TnParams tn_zero() {
 
 static const size_t TN_PART_FLOATS_MAX = (size_t)16 * 3072 * 3072;
 
+// BatchNorm-backward vectors of the dz generator from this rank's S1 = sum du, S2 = sum du * xhat.  With SYNC_BN the
+// first launch takes dgamma / dbeta (and dw_out) from the LOCAL sums, then S1 / S2 are summed over the ranks and a second
+// launch overwrites cs / p / q with the global ones (count * world rows).
+static int bwd_finalize(hipStream_t st, const double* S1, const double* S2, const double* dwacc, double count, int C,
+                        const float* gamma, const float* s, const float* mean, const float* invstd, const float* w,
+                        float* cs, float* pv, float* qv, float* dgamma, float* dbeta, float* dw_out) {
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, dwacc, count, C, gamma, s, mean,
+                     invstd, w, cs, pv, qv, dgamma, dbeta, dw_out);
+  HIP_OK(hipGetLastError());
+  if (sync_bn_on() && gamma != nullptr) {
+    PN_OK(sync_sum2(const_cast<double*>(S1), const_cast<double*>(S2), C, st));
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, (const double*)nullptr,
+                       sync_count(count), C, gamma, s, mean, invstd, w, cs, pv, qv, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // row MLP (W_p / W_l), train forward + backward
 // ------------------------------------------------------------------------------------------------
@@ -1442,9 +1512,9 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
       PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, pick_variant(N), st)));
     }
     if (!last) {
-      hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(N, 256)), dim3(256), 0, st, m->bn[l], (const double*)w.S1,
+      PN_OK(fold_train(st, m->bn[l], (const double*)w.S1,
                          (const double*)w.S2, (double)rows, m->bn_eps, m->bn_momentum, N, N, sv.s[l], sv.t[l],
-                         sv.mean[l], sv.invstd[l]);
+                         sv.mean[l], sv.invstd[l]));
       HIP_OK(hipGetLastError());
       if (drop) {  // H_l = relu(bn(Y_l)) * mask / (1 - p), the next layer's plain operand
         PN_OK(launch_dropout<1>(sv.Y[l], N, sv.H[l], N, rows, N, sv.s[l], sv.t[l],
@@ -1501,10 +1571,10 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
       hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(N, 1024), nblk(rows, MLP_STATS_ROWS)), dim3(256), 0, st, sp);
       PN_OK(reduce_parts<double>(w.statscr.part, nblk(rows, MLP_STATS_ROWS), 2 * N, N, w.S1, w.S2, nullptr,
                                  w.statscr.red, st));
-      hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(N, 256)), dim3(256), 0, st, (const double*)w.S1,
+      PN_OK(bwd_finalize(st, (const double*)w.S1,
                          (const double*)w.S2, (const double*)nullptr, (double)rows, N, m->bn[l].weight,
                          (const float*)sv.s[l], (const float*)sv.mean[l], (const float*)sv.invstd[l],
-                         (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[l], gr->dbeta[l], (float*)nullptr);
+                         (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[l], gr->dbeta[l], (float*)nullptr));
       HIP_OK(hipGetLastError());
     }
     // dW_l[N][K] = dY_l^T X_l
@@ -1696,7 +1766,16 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
   }
   if (!prod) {
     if (hd->bn[0].weight == nullptr) fold_nobn(0);
-    else
+    else if (sync_bn_on()) {
+      // SYNC_BN: this rank's grid sums (sum = NL sumA + B sumB, sumsq = NL sqA + 2 sumA sumB + B sqB), added over the
+      // ranks, folded like any other BatchNorm over world * B * NL rows (the ranks' tables differ, so the global grid
+      // is not a product grid and the var_i(A) + var_j(Bm) shortcut does not apply)
+      hipLaunchKernelGGL(k_pair_grid_sums, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.sumA,
+                         (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL, h, w.S1,
+                         w.S2);
+      PN_OK(fold_train(st, hd->bn[0], (const double*)w.S1, (const double*)w.S2, (double)B * (double)NL, hd->bn_eps,
+                       hd->bn_momentum, h, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]));
+    } else
     hipLaunchKernelGGL(k_bn_fold_pair, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.sumA,
                        (const double*)w.sqA, (double)B, (const double*)w.sumB, (const double*)w.sqB, (double)NL,
                        hd->bn_eps, hd->bn_momentum, h, sv.s[0], sv.t[0], sv.mean[0], sv.invstd[0]);
@@ -1718,9 +1797,9 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
     if (hd->bn[0].weight == nullptr) fold_nobn(0);
     else
-    hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[0], (const double*)w.S1,
+    PN_OK(fold_train(st, hd->bn[0], (const double*)w.S1,
                        (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[0], sv.t[0],
-                       sv.mean[0], sv.invstd[0]);
+                       sv.mean[0], sv.invstd[0]));
     HIP_OK(hipGetLastError());
   }
 
@@ -1743,9 +1822,9 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     }
     if (hd->bn[l].weight == nullptr) fold_nobn(l);
     else
-    hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(h, 256)), dim3(256), 0, st, hd->bn[l], (const double*)w.S1,
+    PN_OK(fold_train(st, hd->bn[l], (const double*)w.S1,
                        (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[l], sv.t[l],
-                       sv.mean[l], sv.invstd[l]);
+                       sv.mean[l], sv.invstd[l]));
     HIP_OK(hipGetLastError());
   }
   hipLaunchKernelGGL(k_rowdot_rows, dim3(nblk(R, 4)), dim3(256), 0, st,
@@ -1798,11 +1877,11 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), sg, dim3(256), 0, st, sp);
       PN_OK(reduce_parts<double>(w.statscr.part, sg.y, 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
     }
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
+    PN_OK(bwd_finalize(st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)(top ? w.dwacc : nullptr), (double)R, h,
                        hd->bn[l].weight, (const float*)sv.s[l], (const float*)sv.mean[l],
                        (const float*)sv.invstd[l], top ? hd->w_out : (const float*)nullptr, w.cs, w.p, w.q,
-                       gr->dgamma[l], gr->dbeta[l], top ? gr->dw_out : (float*)nullptr);
+                       gr->dgamma[l], gr->dbeta[l], top ? gr->dw_out : (float*)nullptr));
     HIP_OK(hipGetLastError());
 
     // dz_l materialised once, in place: over z_l itself for the top layer (its upstream gradient is the rank-1
@@ -1879,7 +1958,16 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     hipLaunchKernelGGL(k_pair_bn0_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.statscr.red, nchunk,
                        (const float*)sv.A1, (long)h, (const float*)w.dA1, (long)h, B, NL, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], w.cs, w.p, w.q,
-                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2);
+                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2, sync_bn_on() ? g_sync_stage + g_sync_cap / 2 : (double*)nullptr);
+    if (sync_bn_on() && hd->bn[0].weight != nullptr) {  // global S1 / S2 -> cs, p, q (dgamma / dbeta stay local)
+      double* s12 = g_sync_stage + g_sync_cap / 2;
+      PN_OK(sync_sum2(s12, s12 + h, h, st));
+      hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)s12, (const double*)(s12 + h),
+                         (const double*)nullptr, sync_count((double)B * (double)NL), h, hd->bn[0].weight,
+                         (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], (const float*)nullptr,
+                         w.cs, w.p, w.q, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+      HIP_OK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_pair_apply, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.dB1, (long)h,
                        (const float*)sv.B1, (long)h, (long)NL, h, (const float*)w.cs, (const float*)w.p,
                        (const float*)w.q, (const double*)w.S1, (double)B);
@@ -1898,10 +1986,10 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     sp.part = w.statscr.part;
     hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
     PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.S1,
+    PN_OK(bwd_finalize(st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
-                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr);
+                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr));
     DzParams dp;
     memset(&dp, 0, sizeof(dp));
     dp.R = R; dp.C = h; dp.rows_per_block = 512;
@@ -2468,9 +2556,9 @@ extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* de
     hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(ld, 1024), nblk(P, ENC_STATS_ROWS)), dim3(256), 0, st, sp);
     PN_OK(reduce_parts<double>(w.statscr.part, nblk(P, ENC_STATS_ROWS), 2 * ld, ld, w.S1, w.S2, nullptr, w.statscr.red,
                                st));
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(cols, 256)), dim3(256), 0, st, (const double*)w.S1,
+    PN_OK(bwd_finalize(st, (const double*)w.S1,
                        (const double*)w.S2, (const double*)nullptr, (double)P, cols, bn.weight, s, mean, invstd,
-                       (const float*)nullptr, w.cs, w.p, w.q, dgamma, dbeta, (float*)nullptr);
+                       (const float*)nullptr, w.cs, w.p, w.q, dgamma, dbeta, (float*)nullptr));
     DzParams dp;
     memset(&dp, 0, sizeof(dp));
     dp.R = P; dp.C = ld; dp.rows_per_block = 512;

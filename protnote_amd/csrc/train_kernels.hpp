@@ -355,6 +355,15 @@ __global__ void k_bn_fold_pair(pn_bn bn, const double* sumA, const double* sqA, 
   bn.running_var[c] = (1.f - momentum) * bn.running_var[c] + momentum * (float)unb;
 }
 
+// SYNC_BN: column sum / sum of squares of z1[i,j] = A[i] + Bm[j] over THIS rank's nA x nB grid, from the table sums
+__global__ void k_pair_grid_sums(const double* sumA, const double* sqA, double nA, const double* sumB, const double* sqB,
+                                 double nB, int C, double* sum, double* sumsq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  sum[c] = nB * sumA[c] + nA * sumB[c];
+  sumsq[c] = nB * sqA[c] + 2.0 * sumA[c] * sumB[c] + nA * sqB[c];
+}
+
 // ------------------------------------------------------------------------------------------------
 // layer-1 reductions over the pair grid (z1 = A[i] + Bm[j] regenerated from the two small tables):
 //   MODE 0: one label per workgroup row   grid (C/1024, NL)   rows of one label are contiguous
@@ -442,7 +451,7 @@ __global__ void k_pair_bn0_finalize(const double* __restrict__ chunks, int nchun
                                     const float* __restrict__ M1, long ldm1, int B, int NL, int C,
                                     const float* gamma, const float* s, const float* mean, const float* invstd,
                                     float* cs, float* pv, float* qv, float* dgamma, float* dbeta, double* sumA,
-                                    double* sumB) {
+                                    double* sumB, double* s12_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double S1 = 0, T = 0, sb = 0;
@@ -462,6 +471,10 @@ __global__ void k_pair_bn0_finalize(const double* __restrict__ chunks, int nchun
   const double count = (double)B * (double)NL;
   if (gamma != nullptr) {
     const double S2 = (double)invstd[c] * (T - (double)mean[c] * S1);
+    if (s12_out) {  // SYNC_BN: this rank's S1 / S2, to be summed over the ranks
+      s12_out[c] = S1;
+      s12_out[C + c] = S2;
+    }
     const float sc = s[c];
     const float q = (float)(-(double)sc * (double)invstd[c] * (S2 / count));
     cs[c] = sc;

@@ -95,9 +95,12 @@ def build_training(config: dict, model, world_size: int = 1):
 
     p = config["params"]
     if p.get("SYNC_BN", False) and world_size > 1:
-        # bin/main.py:449-450 converts to SyncBatchNorm; here the statistics of a GEMM are reduced inside one C call,
-        # per rank (the reference default) - say so instead of silently training something else
-        raise NotImplementedError("SYNC_BN: True is not implemented (BatchNorm statistics are per rank)")
+        # bin/main.py:449-450 converts to SyncBatchNorm; here the statistics of a layer are reduced inside one C call,
+        # so the switch is library-wide: the per-rank column sums are all-reduced through a callback
+        from .distributed import enable_sync_batchnorm
+
+        if not enable_sync_batchnorm():
+            raise RuntimeError("SYNC_BN: True with world_size > 1 needs an initialised torch.distributed process group")
     loss_fn = get_loss(config, bce_pos_weight=torch.tensor(float(p.get("BCE_POS_WEIGHT", 1))))
     name = p.get("OPTIMIZER", "Adam")
     if name not in ("Adam", "AdamW"):

@@ -176,3 +176,46 @@ def allreduce_mean_loss(loss_sum: float, n_batches: int, device):
     t = torch.tensor([loss_sum, float(n_batches)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0] / t[1].clamp(min=1.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SYNC_BN: True (reference bin/main.py:449-450)
+# ---------------------------------------------------------------------------------------------------------------
+_sync_bn = {}  # keeps the staging tensor and the ctypes callback alive while the library holds their addresses
+
+
+def enable_sync_batchnorm(device=None):
+    """The reference converts every BatchNorm to SyncBatchNorm when SYNC_BN is set (bin/main.py:449-450).  Here the
+    BatchNorm statistics are reduced inside the HIP library's calls, so the switch is library-wide: the library hands
+    its per-rank column sums to this callback, which all-reduces them over the process group (RCCL), in the forward
+    and in the backward of every train-mode BatchNorm (encoder, W_p, W_l, output MLP).  No-op on one rank."""
+    import ctypes as C
+
+    from .. import _lib as L
+
+    if not active():
+        return False
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    stage = torch.zeros(16384, dtype=torch.float64, device=dev)
+    err = []
+
+    def hook(n, _user):
+        try:
+            with _Timed("sync_bn_allreduce", stage[:n]):
+                dist.all_reduce(stage[:n], op=dist.ReduceOp.SUM)
+            return 0
+        except Exception as e:  # surfaces as a library error ("the all-reduce callback failed") on this rank
+            err.append(e)
+            return 1
+
+    cb = C.CFUNCTYPE(C.c_int, C.c_long, C.c_void_p)(hook)
+    L.check(L.lib().pn_set_sync_bn(C.cast(cb, C.c_void_p), None, L.ptr(stage), stage.numel(), dist.get_world_size()))
+    _sync_bn.update(stage=stage, cb=cb, err=err)
+    return True
+
+
+def disable_sync_batchnorm():
+    from .. import _lib as L
+
+    L.check(L.lib().pn_set_sync_bn(None, None, None, 0, 1))
+    _sync_bn.clear()

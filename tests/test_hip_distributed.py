@@ -172,3 +172,108 @@ def test_bench_self_launches_its_ranks():
     assert c["grad_allreduce"]["calls_per_step"] == 1 and c["bn_buffer_broadcast"]["calls_per_step"] == 1
     assert j["value"] > 0 and j["forward_only"]["f32"]["value"] > 0
     assert all(v["value"] > 0 for v in j["zero_shot"]["f32"].values())
+
+
+def _sync_bn_worker(rank, world, port, q, train_encoder):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PN_SHARE_GPU="1")
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils import distributed as D
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+    from tests.helpers import make_protnote
+
+    r, _, w = D.init_from_env()
+    dev = f"cuda:{torch.cuda.current_device()}"
+    g = np.load(os.path.join(GOLDEN, "protnote_small_concatenation.npz"))
+    x, lens, yy = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"]), torch.from_numpy(g["multihots"]).float()
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+
+    def run(rows, sync, reduce=False):
+        model, _ = make_protnote(g, dev, label_embedding_noising_alpha=0.0, train_sequence_encoder=train_encoder)
+        params = list(head_parameters(model))
+        if train_encoder:
+            params += list(model.sequence_encoder.trunk_parameters())
+        else:
+            for n_, q_ in model.named_parameters():
+                if n_.startswith("sequence_encoder"):
+                    q_.requires_grad = False
+        model.train()
+        opt = FusedClipAdam(params, lr=3e-4, max_norm=1.0)
+        if sync:
+            assert D.enable_sync_batchnorm(dev)
+        try:
+            logits, _ = model(sequence_onehots=x[rows].to(dev), sequence_lengths=lens[rows].to(dev),
+                              label_embeddings=lab.to(dev))
+            loss = loss_fn(logits, yy[rows].to(dev))
+            loss.backward()
+            if sync or reduce:
+                D.allreduce_gradients(opt)
+        finally:
+            if sync:
+                D.disable_sync_batchnorm()
+        torch.cuda.synchronize()
+        bufs = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
+        return float(loss), opt.flat_g.detach().cpu().clone(), bufs
+
+    l_sync, g_sync, b_sync = run(D.shard_batch(x.shape[0], r, w), True)
+    torch.distributed.barrier()
+    _, g_per_rank, _ = run(D.shard_batch(x.shape[0], r, w), False, reduce=True)  # control: per-rank statistics
+    torch.distributed.barrier()
+    out = (r, l_sync, g_sync.numpy(), {k: v.numpy() for k, v in b_sync.items()}, None, g_per_rank.numpy())
+    if r == 0:  # the same step on ONE rank over the whole batch, per-rank statistics (= statistics of the whole batch)
+        l_full, g_full, b_full = run(list(range(x.shape[0])), False)
+        out = out[:4] + ((l_full, g_full.numpy(), {k: v.numpy() for k, v in b_full.items()}), out[5])
+    import pickle
+
+    q.put(pickle.dumps(out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("train_encoder", [False, True])
+def test_sync_bn_two_ranks_equal_one_rank_on_the_whole_batch(train_encoder):
+    """SYNC_BN: True (bin/main.py:449-450).  Two ranks, three proteins each, statistics synchronised in the forward and
+    the backward of every BatchNorm (encoder, W_p, W_l, output MLP incl. the closed-form first pair layer) must reproduce
+    ONE rank running the six proteins: the mean of the two losses is the whole-batch loss, the AVERAGED gradients equal the
+    whole-batch gradients, and the BatchNorm running statistics agree - except W_l's running variances, whose label
+    rows are replicated on every rank: SyncBatchNorm counts them world times, which only changes the unbiased-variance
+    factor from N/(N-1) to 2N/(2N-1)."""
+    import pickle
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, q, train_encoder)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((pickle.loads(q.get(timeout=300)) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, g0, b0, full, g_ctl), (_, l1, g1, b1, _, _) = res
+    l_full, g_full, b_full = full
+    np.testing.assert_allclose(0.5 * (l0 + l1), l_full, rtol=2e-6)
+    np.testing.assert_array_equal(g0, g1)                       # one all-reduce -> the same averaged gradient everywhere
+    assert np.linalg.norm(g0) > 0
+    rel = np.linalg.norm(g0 - g_full) / np.linalg.norm(g_full)
+    assert rel < 2e-5, rel
+    # control: with per-rank statistics (SYNC_BN: False) the same two ranks do NOT reproduce the whole-batch gradient
+    assert np.linalg.norm(g_ctl - g_full) / np.linalg.norm(g_full) > 1e-2
+    n_lab, mom = 10, 0.1
+    g = np.load(os.path.join(GOLDEN, "protnote_small_concatenation.npz"))
+    for k, v in b_full.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.startswith("W_l.") and k.endswith("running_var"):
+            before = g["sd/" + k]
+            ratio = (b0[k] - (1 - mom) * before) / (v - (1 - mom) * before)
+            np.testing.assert_allclose(ratio, (2 * n_lab / (2 * n_lab - 1)) / (n_lab / (n_lab - 1)), rtol=1e-3, err_msg=k)
+        else:
+            np.testing.assert_allclose(b0[k], v, rtol=2e-5, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(b1[k], v, rtol=2e-5, atol=1e-6, err_msg=k)
