@@ -61,7 +61,21 @@ def main(out_dir, tag):
             u["valu"] += c.get("SQ_INSTS_VALU", 0.0)
             u["mfma"] += c.get("SQ_INSTS_MFMA", 0.0)
             u["sec"] += dur[key]
-    total_bytes = total_launch = 0
+    # full pair-grid launches, classified PER DISPATCH (the passes replay the same launch sequence, so Dispatch_Id pairs the
+    # FETCH_SIZE pass with the WRITE_SIZE pass): a kernel name also covers the small row-MLP launches and the 1/32-grid
+    # chunks of the top layer's dh GEMM, which must not dilute the per-launch figure
+    wr = {key: c.get("WRITE_SIZE", 0.0) for key, c in write.items()}
+    full = defaultdict(list)
+    for key, c in fetch.items():
+        k = key[0]
+        if big(k) and "bf16x3" not in k:
+            b = (2 * c.get("FETCH_SIZE", 0.0) + wr.get(key, 0.0)) * 1024.0
+            if b >= 100e9:
+                full[short(k)].append(b)
+    total_bytes = sum(sum(v) for v in full.values())
+    total_launch = sum(len(v) for v in full.values())
+    res["full_grid_launches"] = {k: {"launches": len(v), "hbm_side_GB_per_launch": sum(v) / len(v) / 1e9}
+                                 for k, v in sorted(full.items())}
     for k, a in sorted(agg.items()):
         n = max(a["launches"], 1)
         per = (2 * a["fetch_kb"] / n + a["write_kb"] / max(wl[k], 1)) * 1024.0
@@ -74,11 +88,8 @@ def main(out_dir, tag):
             e["valu_insts_per_mfma"] = u["valu"] / u["mfma"] if u["mfma"] > 0 else None
             e["avg_ms"] = u["sec"] / u["n"] * 1e3
         res["per_kernel"][k] = e
-        if per > 50e9 and "bf16x3" not in k:   # the full pair-grid f32 launches (top-layer dh chunks are smaller)
-            total_bytes += per * a["launches"]
-            total_launch += a["launches"]
     res["bytes_per_launch"] = total_bytes / total_launch if total_launch else None
-    res["bytes_per_launch_definition"] = ("mean over the full-pair-grid f32 GEMM launches (> 50 GB each) of "
+    res["bytes_per_launch_definition"] = ("mean over the full-pair-grid f32 GEMM launches (dispatches moving >= 100 GB) of "
                                           "2 * FETCH_SIZE + WRITE_SIZE; algorithmic bytes of such a launch: 202 GB")
     path = os.path.join(out_dir, f"{tag}_hbm_traffic.json")
     json.dump(res, open(path, "w"), indent=1)
