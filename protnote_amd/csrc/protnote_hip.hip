@@ -11,6 +11,7 @@
 #include "gemm_bf16x3.hpp"
 #include "gemm_dma.hpp"
 #include "gemm_conv_dma.hpp"
+#include "gemm_tn_fast.hpp"
 #include "train_kernels.hpp"
 
 using namespace pn;
@@ -1246,6 +1247,11 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile,
   return (int)ns;
 }
 
+// PN_TN_FAST=0 keeps the generic big TN kernel (A/B measurements)
+static bool tn_fast_on() {
+  static const int on = [] { const char* e = getenv("PN_TN_FAST"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
 // PN_TN_TASKS=0 restores the per-split XCD regions (A/B measurements: tools/pmc_tn_tasks.sh)
 static bool tn_task_map() {
   static const int on = [] { const char* e = getenv("PN_TN_TASKS"); return e ? atoi(e) : 1; }();
@@ -1287,6 +1293,50 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
   {
     ProfScope ps(100 + TA * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
     hipLaunchKernelGGL(kern, grid, dim3(BIG ? 512 : 256), LDS, st, p);
+  }
+  HIP_OK(hipGetLastError());
+  if (ns > 1) {
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nblk((long)p.M * p.N, 256)), dim3(256), 0, st, (const float*)part, ns,
+                       p.M, p.N, (long)p.N, dst, ldd);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+// the specialised f32 kernel of the big weight gradients (gemm_tn_fast.hpp); preconditions checked by launch_tn
+template <int TB>
+static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
+  auto kern = gemm_tn_fast_kernel<TB>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TN_FAST_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats, 256, 1);
+  if (ns == 1) {
+    p.Cpart = dst;
+    p.ldc = ldd;
+    p.rows_per_split = (p.R + 31) / 32 * 32;
+  } else {
+    if (part == nullptr) return fail("gemm_tn: no partial buffer");
+    p.Cpart = part;
+    p.ldc = p.N;
+    long rps = (p.R + ns - 1) / ns;
+    p.rows_per_split = (rps + 31) / 32 * 32;
+    ns = (int)((p.R + p.rows_per_split - 1) / p.rows_per_split);
+  }
+  const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
+  dim3 grid(tiles, (unsigned)ns);
+  p.task_ns = 0;
+  if (tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {
+    p.task_ns = ns;
+    grid = dim3(tn_task_grid(ns), 1);
+  }
+  {
+    ProfScope ps(100 + TA_PLAIN * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
+    hipLaunchKernelGGL(kern, grid, dim3(512), TN_FAST_LDS_BYTES, st, p);
   }
   HIP_OK(hipGetLastError());
   if (ns > 1) {
@@ -1362,8 +1412,15 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
   // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction); a plain A operand (the
   // materialised dz) is staged by LDS-DMA when every split is a whole number of 32-row slabs
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
-    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 && p.R % 32 == 0 && p.lda % 4 == 0)
+    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 && p.R % 32 == 0 && p.lda % 4 == 0) {
+      if constexpr (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU) {
+        // the low-VALU kernel: 32-bit per-lane offsets, and for the pair sum a slab inside one label
+        const bool fits = (long)8 * p.ldb * 4 < (1L << 31) && p.ldb % 4 == 0 && (TB != TB_AFFINE_RELU || p.b_s != nullptr);
+        const bool pair_ok = TB != TB_PAIRSUM_RELU || (p.pairB % 32 == 0 && p.ldb2 % 4 == 0);
+        if (tn_fast_on() && fits && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
+      }
       return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
+    }
   }
   if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536)
     return launch_tn_cfg<TA, TB, true>(p, dst, ldd, part, part_cap_floats, st);
