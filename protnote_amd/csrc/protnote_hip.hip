@@ -12,6 +12,7 @@
 #include "gemm_dma.hpp"
 #include "gemm_conv_dma.hpp"
 #include "gemm_tn_fast.hpp"
+#include "gemm_b3_fast.hpp"
 #include "train_kernels.hpp"
 
 using namespace pn;
@@ -341,14 +342,23 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
     if (p.wsplit != nullptr && use_b3_dma() && p.Nstore == p.N)
       return launch_gemm_bf16x3<AK, EK, WAVES_N, WN, GEN, true>(p, st);
   }
-  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
+  // PN_B3_FAST=1: BDMA pair-grid launches take the experimental low-VALU kernel (gemm_b3_fast.hpp).  Bit-identical, 1.3-1.8
+  // instead of 3.5 VALU per MFMA - but measured SLOWER so far (matrix pipe 0.50 busy at 2.0-2.1 GHz against 0.62-0.70 at
+  // 1.85 GHz: every k-step's 12 fragment reads are waited for in full before its first MFMA), so it is off by default
+  static const bool b3_fast = [] { const char* e = getenv("PN_B3_FAST"); return e != nullptr && atoi(e) != 0; }();
+  const bool fast = BDMA && b3_fast && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0 &&
+                    (AK != A_PAIRSUM_RELU || ((long)(p.M / p.pairB + 1) * p.lda2 * 4 < (1L << 32) && p.lda2 % 4 == 0));
+  void (*kern)(const GemmParams) = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
+  if constexpr (BDMA) {
+    if (fast) kern = gemm_nt_b3_fast_kernel<AK, EK>;
+  }
   constexpr int LDS_BYTES = BDMA ? 2 * (256 * 36 + 2 * 256 * 16) * (int)sizeof(float) : Cfg::LDS_BYTES;
-  static bool attr_done[64] = {false};
+  static bool attr_done[2][64] = {{false}};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-  if (dev < 64 && !attr_done[dev]) {
+  if (dev < 64 && !attr_done[fast ? 1 : 0][dev]) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_done[dev] = true;
+    attr_done[fast ? 1 : 0][dev] = true;
   }
   if (p.M <= 0 || p.Nstore <= 0) return 0;
   if (p.Kseg % 4 != 0) return fail("gemm: K segment %d not a multiple of 4", p.Kseg);
