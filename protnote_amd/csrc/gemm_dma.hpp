@@ -20,6 +20,10 @@
 #pragma once
 #include "gemm_engine.hpp"
 
+#ifndef PN_DMA_SPLIT
+#define PN_DMA_SPLIT 1  // 0: all DMA / loads of the next slab at the slab top; 1: the weight tile after the first k-step
+#endif
+
 namespace pn {
 
 // one LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS[lds_base + 16 l]
@@ -59,6 +63,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // nothing can consume them earlier - before the first use.
 __device__ __forceinline__ void gload4_s(f32x4& dst, const float* sbase_uniform, unsigned voff_bytes) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase_uniform) : "memory");
+}
+// s_waitcnt vmcnt(VM) with the awaited registers as operands: no consumer can be scheduled above it
+template <int VM>
+__device__ __forceinline__ void wait_vm6(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void wait_vm8(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f, f32x4& g, f32x4& h) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
+               : "n"(VM)
+               : "memory");
 }
 __device__ __forceinline__ float relu_raw(float x) {  // v_max_f32 without the canonicalising self-max the compiler
   float r;                                            // puts in front of fmaxf on values it did not compute itself
@@ -196,18 +212,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   };
   // wait for the register operand (and, vmcnt being in order, the DMA issued before it): the destination registers are
   // operands of the wait, so no consumer can be scheduled above it
-  auto pin_a = [&]() {
+  auto pin_a = [&](auto vm_c) {
+    constexpr int PIN_VMCNT = decltype(vm_c)::value;
     static_assert(NQA == 4, "operand list below");
-    if constexpr (AK == A_PAIRSUM_RELU)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra2[0]), "+v"(ra2[1]), "+v"(ra2[2]), "+v"(ra2[3])
-                   :
-                   : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rsc), "+v"(rsh)
-                   :
-                   : "memory");
+    // (PN_DMA_SPLIT == 1: the four W-tile DMAs issued after the first k-step are YOUNGER than the register loads - the
+    //  counter is in order, "at most 4 outstanding" is the register operand complete with the DMA still in flight)
+    if constexpr (AK == A_PAIRSUM_RELU) wait_vm8<PIN_VMCNT>(ra[0], ra[1], ra[2], ra[3], ra2[0], ra2[1], ra2[2], ra2[3]);
+    else wait_vm6<PIN_VMCNT>(ra[0], ra[1], ra[2], ra[3], rsc, rsh);
   };
   auto commit_a = [&](auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     issue_a(0, I0{});
   } else {
     fetch_a(0);
-    pin_a();
+    pin_a(I0{});
     commit_a(I0{});
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -300,16 +311,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     using C = integral_constant<int, CUR>;
     using N = integral_constant<int, CUR ^ 1>;
     const int nxt = s + 1 < nslab ? s + 1 : s;
-    issue_b(nxt, N{});  // the other buffer was last read in slab s-1, which ended with a barrier
-    if constexpr (A_DMA) issue_a(nxt, N{});
+    // The DMA / load issue of slab s+1 is spread over the slab instead of bursting at its top (where both waves of a SIMD
+    // would sit in ~100 scalar + VMEM instructions with the matrix pipe idle): the operand that streams from HBM goes
+    // first, the L2-resident weight tile after the first k-step.  (Before the address work this spreading cost 4 %: the
+    // per-instruction 64-bit vector adds landed between the MFMAs.)
+    if constexpr (A_DMA) issue_a(nxt, N{});  // the other buffer was last read in slab s-1, which ended with a barrier
     else fetch_a(nxt);
+    if (PN_DMA_SPLIT == 0) issue_b(nxt, N{});
     __builtin_amdgcn_sched_barrier(0);
     read_frag(C{}, I1{}, ga, gb);
     mma(fa, fb);
+    if (PN_DMA_SPLIT == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_b(nxt, N{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_frag(C{}, I2{}, fa, fb);
     mma(ga, gb);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!A_DMA) pin_a();
+    if (PN_DMA_SPLIT == 2) {
+      issue_b(nxt, N{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!A_DMA) pin_a(integral_constant<int, (PN_DMA_SPLIT == 1 ? 4 : 0)>{});
     read_frag(C{}, I3{}, ga, gb);
     mma(fa, fb);
     if constexpr (!A_DMA) commit_a(N{});
