@@ -37,6 +37,8 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   const f32x2 x = {x0, x1};
   const bf16x2 h = __builtin_convertvector(x, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
   hi = __builtin_bit_cast(uint32_t, h);
+  // (a packed subtract - v_pk_add_f32 with neg modifiers from inline asm - was measured here and is SLOWER, -6 % on every
+  //  bf16x3 kernel: the sched_group_barrier weave cannot classify inline asm, and the pair constraint costs register moves)
   const float r0 = x0 - __uint_as_float(hi << 16);          // exact in f32
   const float r1 = x1 - __uint_as_float(hi & 0xffff0000u);
   const f32x2 r = {r0, r1};
