@@ -262,7 +262,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b3_fast_kernel(const GemmParam
     __builtin_amdgcn_sched_barrier(0);
     mma();
     commit_a(N{}, N{});
+#ifdef PN_B3_WEAVE
     weave(integral_constant<int, (AK == A_PLAIN ? 2 : 3)>{});
+#endif
     __builtin_amdgcn_sched_barrier(0);
     fetch_st(s + 2 < lasts ? s + 2 : lasts);  // (before A(s+3): vmcnt is in order, the next slab must be able to wait
     fetch_a(s + 3 < lasts ? s + 3 : lasts, N{});  //  for these quads without waiting for the younger A(s+3))
