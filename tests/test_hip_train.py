@@ -929,8 +929,10 @@ def test_attention_pooling_golden(golden_dir, monkeypatch):
     assert abs(got["raw_attn_scorer.bias"] - g["sd/raw_attn_scorer.bias"]).max() <= 3e-4 * 1.01
 
 
-def test_lds_dma_engine_bit_identical_train_step():
-    """Full-width head on a 64 x 1040 pair grid (66 560 rows: the smallest grid the LDS-DMA kernels take) - logits and
+@pytest.mark.parametrize("B,NL", [(64, 1040), (96, 694)])  # 66 560 rows: even slab count per split; 66 624: odd + ragged last split
+def test_lds_dma_engine_bit_identical_train_step(B, NL):
+    """Full-width head on a 64 x 1040 pair grid (66 560 rows: the smallest grid the LDS-DMA kernels take; B % 32 == 0 but
+    not 256, so a 256-row tile spans several labels and the specialised TN kernel's scalar pair decode wraps) - logits and
     every gradient of a train step with the LDS-DMA GEMMs equal, bit for bit, those of the register-staged engine that
     the small-grid oracle tests pin (same products, same accumulation order; only the operand staging differs)."""
     from protnote_amd import _lib as L
@@ -939,7 +941,6 @@ def test_lds_dma_engine_bit_identical_train_step():
 
     gen = torch.Generator().manual_seed(77)
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
-    B, NL = 64, 1040
     P_f = torch.randn(B, 1100, generator=gen).to(DEV)
     lab = torch.randn(NL, 1024, generator=gen).to(DEV)
     y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
@@ -1086,7 +1087,6 @@ def test_mlp_dropout_big_kernels_match_small_tiles():
 
     gen = torch.Generator().manual_seed(79)
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
-    B, NL = 64, 1040
     P_f = torch.randn(B, 1100, generator=gen).to(DEV)
     lab = torch.randn(NL, 1024, generator=gen).to(DEV)
     y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
