@@ -12,6 +12,10 @@
 #include "gemm_dma.hpp"
 #include "gemm_tn.hpp"
 
+#ifndef PN_TN_WAIT_KK
+#define PN_TN_WAIT_KK 14
+#endif
+
 namespace pn {
 
 __device__ __forceinline__ float2 lds_read2(unsigned addr) {
@@ -31,6 +35,14 @@ __device__ __forceinline__ f32x4 bload4(const float* sbase_uniform, unsigned vof
 }
 __device__ __forceinline__ void lds_write2(unsigned addr, float2 v) {
   *reinterpret_cast<PN_LDS f32x2*>(addr) = f32x2{v.x, v.y};
+}
+
+template <int I0_, int I1_, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0_ < I1_) {
+    f(std::integral_constant<int, I0_>{});
+    static_for<I0_ + 1, I1_>(f);
+  }
 }
 
 template <int TB>
@@ -160,39 +172,48 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
   unsigned fb_addr = lds0 + 2u * TILEB + (unsigned)fk * ROWB + (unsigned)(wn * 128 + 4 * fcol) * 4u;
   asm volatile("" : "+v"(fa_addr), "+v"(fb_addr));
 
-  // k-pairs [KK0, KK1) of the slab in buffer BUF; the fragments of k-pair kk+1 are read before the MFMAs of k-pair kk
+  // Fragment pipeline: (fa, fb) always hold the fragments of the NEXT k-pair to execute; the fragments of k-pair kk+1 are
+  // read before the MFMAs of k-pair kk, so the LDS latency sits under the matrix pipe.  The loop is rotated across the
+  // barrier like gemm_nt_dma_kernel's: the last k-pair's 8 MFMAs of a slab are issued AFTER the barrier, behind the first
+  // fragment reads of the next slab.
+  float2 fa;
+  float4 fb;  // (group 0: x, y; group 1: z, w)
+  auto read_pair = [&](auto buf_c, auto kk_c, float2& a, float4& b) {
+    constexpr int BUF = decltype(buf_c)::value, KK = decltype(kk_c)::value;
+    a = lds_read2(fa_addr + (BUF * TILEB + 2 * KK * ROWB));
+    b = lds_read4(fb_addr + (BUF * TILEB + 2 * KK * ROWB));
+  };
+  auto mma8 = [&](float2 a, float4 b) {  // (same order of MFMAs per k-pair as gemm_tn_kernel: group 0's four tiles, then group 1's)
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.z, acc[0][2], 0, 0, 0);
+    acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.w, acc[0][3], 0, 0, 0);
+    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.z, acc[1][2], 0, 0, 0);
+    acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.w, acc[1][3], 0, 0, 0);
+  };
+  // k-pairs [KK0, KK1) of the slab in buffer BUF: entered with (fa, fb) = fragments of KK0, left with those of KK1
+  // (KK1 < 16; the caller reads k-pair 0 of the next slab itself, after the barrier)
   auto compute = [&](auto buf_c, auto kk0_c, auto kk1_c) {
     constexpr int BUF = decltype(buf_c)::value, KK0 = decltype(kk0_c)::value, KK1 = decltype(kk1_c)::value;
-    float2 a = lds_read2(fa_addr + (BUF * TILEB + 2 * KK0 * ROWB));
-    float4 b = lds_read4(fb_addr + (BUF * TILEB + 2 * KK0 * ROWB));  // (group 0: x, y; group 1: z, w)
-#pragma unroll
-    for (int kk = KK0; kk < KK1; ++kk) {
-      float2 na = a;
-      float4 nb = b;
-      if (kk + 1 < KK1) {
-        na = lds_read2(fa_addr + (BUF * TILEB + (2 * kk + 2) * ROWB));
-        nb = lds_read4(fb_addr + (BUF * TILEB + (2 * kk + 2) * ROWB));
-      }
-      // (same order of MFMAs per k-pair as gemm_tn_kernel: group 0's four tiles, then group 1's)
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
-      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.z, acc[0][2], 0, 0, 0);
-      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.w, acc[0][3], 0, 0, 0);
-      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.z, acc[1][2], 0, 0, 0);
-      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.w, acc[1][3], 0, 0, 0);
-      a = na;
-      b = nb;
-    }
+    static_for<KK0, KK1>([&](auto kk_c) {
+      constexpr int KK = decltype(kk_c)::value;
+      float2 na;
+      float4 nb;
+      read_pair(std::integral_constant<int, BUF>{}, std::integral_constant<int, KK + 1>{}, na, nb);
+      mma8(fa, fb);
+      fa = na;
+      fb = nb;
+    });
   };
 
   using std::integral_constant;
   using I0 = integral_constant<int, 0>;
   using I1 = integral_constant<int, 1>;
   using K0 = integral_constant<int, 0>;
-  using K8 = integral_constant<int, 8>;
-  using K16 = integral_constant<int, 16>;
+  using K8 = integral_constant<int, PN_TN_WAIT_KK>;  // k-pair in front of which the loads of slab t+1 are waited for
+  using K15 = integral_constant<int, 15>;
   if (nsl > 0) {
     const int last = nsl - 1;
     issue_a(0, I0{});
@@ -202,8 +223,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
     fetch_b(last < 1 ? last : 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    read_pair(I0{}, K0{}, fa, fb);
     // slab t < last out of buffer CUR: A(t+1) by DMA at the top (the idle buffer was last read in the previous slab,
-    // barrier passed); in the middle everything in flight is at least half a slab (~8k cycles) old - this wave's share of
+    // barrier passed); late in the slab (before k-pair 14 of 16: measured best of 8 / 12 / 14 / 15) everything in flight is at least ~14k cycles old - this wave's share of
     // the A(t+1) DMA (invisible to hipcc: explicit wait) and the B(t+1) registers, fetched a whole slab ago; B(t+1) is
     // transformed and written under the second half of the MFMAs, B(t+2) goes out behind it and stays in flight across
     // the barrier.  Past the end the last slab is fetched again (branch-free; nobody reads it).
@@ -217,12 +239,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       pin_b();
-      compute(C{}, K8{}, K16{});
+      compute(C{}, K8{}, K15{});
       commit_b(N{});
       __builtin_amdgcn_sched_barrier(0);
       fetch_b(t + 2 < last ? t + 2 : last);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (k-pair 15's fragments are in registers: buffer CUR is free)
       __builtin_amdgcn_s_barrier();
+      float2 na;
+      float4 nb;
+      read_pair(N{}, K0{}, na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma8(fa, fb);  // k-pair 15 of slab t, behind the first reads of slab t+1
+      fa = na;
+      fb = nb;
+    };
+    auto last_slab = [&](auto cur_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      compute(integral_constant<int, CUR>{}, K0{}, K15{});
+      mma8(fa, fb);
     };
     int t = 0;
     for (; t + 2 <= last; t += 2) {
@@ -231,9 +265,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
     }
     if (t < last) {  // one more full slab, then the last one sits in buffer 1
       slab(t, I0{});
-      compute(I1{}, K0{}, K16{});
+      last_slab(I1{});
     } else {
-      compute(I0{}, K0{}, K16{});
+      last_slab(I0{});
     }
   }
 
