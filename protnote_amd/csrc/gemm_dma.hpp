@@ -280,6 +280,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
       }
   };
 
+  auto mma_rows = [&](const float4 (&a)[WM], const float4 (&b)[WN], auto i_c) {  // one 32-row strip of the wave tile
+    constexpr int i = decltype(i_c)::value;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    }
+  };
+
   using std::integral_constant;
   using I0 = integral_constant<int, 0>;
   using I1 = integral_constant<int, 1>;
@@ -333,10 +344,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
       issue_b(nxt, N{});
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!A_DMA) pin_a(integral_constant<int, (PN_DMA_SPLIT == 1 ? 4 : 0)>{});
     read_frag(C{}, I3{}, ga, gb);
-    mma(fa, fb);
-    if constexpr (!A_DMA) commit_a(N{});
+    if constexpr (A_DMA) {
+      mma(fa, fb);
+    } else {  // the register operand is waited for as late as its transform + LDS write still fit under MFMAs: after the
+              // first 16 of k-step 2's 32 MFMAs (three quarters of a slab to land)
+      mma_rows(fa, fb, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      pin_a(integral_constant<int, (PN_DMA_SPLIT == 1 ? 4 : 0)>{});
+      mma_rows(fa, fb, I1{});
+      commit_a(N{});
+    }
     __builtin_amdgcn_sched_barrier(0);
     // DMA of slab s+1 complete for this wave, its LDS writes and this wave's fragment reads drained; then the barrier
     // makes every wave's share visible (and frees buffer CUR for the DMA of slab s+2)
