@@ -1087,6 +1087,7 @@ def test_mlp_dropout_big_kernels_match_small_tiles():
 
     gen = torch.Generator().manual_seed(79)
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1040
     P_f = torch.randn(B, 1100, generator=gen).to(DEV)
     lab = torch.randn(NL, 1024, generator=gen).to(DEV)
     y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
