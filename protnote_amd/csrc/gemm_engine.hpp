@@ -93,6 +93,7 @@ struct GemmParams {
   uint16_t* wsplit;      // optional scratch, 2 * N * Kseg bf16: bf16x3 mode pre-splits W into hi / lo planes there and
   const uint16_t* w_hi;  // stages them by LDS-DMA (set by the launcher from wsplit)
   const uint16_t* w_lo;
+  int nvb;             // persistent kernels: number of virtual blocks (the grid a one-tile-per-workgroup launch would have)
   int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
 };
 
@@ -137,23 +138,24 @@ __device__ __forceinline__ void pin4(float4& v) {
 // on its 32 CUs) at a time: inside a block each A row-panel is shared by bc and each W column-panel by br
 // workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
 template <int BM, int BN>
-__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n) {
+__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n, int bid = -1) {
+  if (bid < 0) bid = blockIdx.x;  // (persistent kernels pass the virtual block id of the tile they are about to compute)
   const int ntn = (p.Nstore + BN - 1) / BN;
   if (PN_XCD && p.xcd_bc > 0) {
     const int ntm = (p.M + BM - 1) / BM;
     const int br = p.xcd_br, bc = p.xcd_bc, bsz = br * bc;
     const int nbn = ntn / bc;
     const int nbm = (ntm + br - 1) / br;
-    const int xw = blockIdx.x >> 3;
-    const int gb = (xw / bsz) * 8 + (blockIdx.x & 7);
+    const int xw = bid >> 3;
+    const int gb = (xw / bsz) * 8 + (bid & 7);
     if (gb >= nbm * nbn) return false;
     const int r = xw % bsz;
     tile_m = (gb / nbn) * br + r / bc;
     tile_n = (gb % nbn) * bc + r % bc;
     return tile_m < ntm && tile_n < ntn;
   }
-  tile_n = blockIdx.x % ntn;
-  tile_m = blockIdx.x / ntn;
+  tile_n = bid % ntn;
+  tile_m = bid / ntn;
   return true;
 }
 

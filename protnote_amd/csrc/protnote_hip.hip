@@ -412,9 +412,33 @@ static int g_dma_min_rows = [] {
   return e ? atoi(e) : 16384;
 }();
 
-template <int AK, int EK, bool DROP = false>
+// PN_PERSIST=1: persistent workgroups for the plain-operand NT launches (gemm_nt_dma_kernel<.., PERSIST>).  Measured SLOWER
+// (nt:plain 149.8 -> 147.3 TFLOP/s) and therefore off: stores and loads share vmcnt on this chip and the counter is in
+// order, so the wait that publishes the next tile's second slab also waits for the 256 KB of epilogue stores every CU has
+// just issued at the same moment (a 64 MB burst, ~10 us to drain) - a fresh workgroup starts with fresh counters and
+// overlaps that drain with its first slabs, which is worth more than the 7.9 us of launch + first-slab latency it costs.
+static bool persist_on() {
+  static const int on = [] { const char* e = getenv("PN_PERSIST"); return e ? atoi(e) : 0; }();
+  return on != 0;
+}
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+  }();
+  return n;
+}
+
+template <int AK, int EK, bool DROP = false, bool PERSIST = false>
 static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_nt_dma_kernel<AK, EK, DROP>;
+  if constexpr (!PERSIST && !DROP && AK == A_PLAIN && (EK == E_STORE || EK == E_ROWDOT)) {
+    // persistent variant: the epilogue must not use the LDS (no column statistics), whole row tiles, even slab count
+    if (persist_on() && p.col_part == nullptr && p.col_sum == nullptr && p.M % 256 == 0 && (p.Kseg / 32) % 2 == 0 &&
+        cu_count() > 0 && cu_count() % 8 == 0 && (long)(p.M / 256) * (p.N / 256) >= 4L * cu_count())
+      return launch_gemm_dma<AK, EK, DROP, true>(p, st);
+  }
+  auto kern = gemm_nt_dma_kernel<AK, EK, DROP, PERSIST>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -434,6 +458,8 @@ static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
     grid = ((nblk_ + 7) / 8) * 8 * 32;
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  pp.nvb = (int)grid;
+  if (PERSIST) grid = cu_count();  // one workgroup per CU (128 KiB of LDS each), ids keep their XCD: 256 % 8 == 0
   {
     ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), GEMM_DMA_LDS_BYTES, st, pp);
