@@ -49,6 +49,7 @@ struct TnParams {
   // ---- output ----
   float* Cpart;  // [nsplit][M][ldc]
   long ldc;
+  int* task_sync;  // optional [tasks][4] arrival counters (zeroed by the launcher): keeps a task's workgroups in step
   int task_ns;   // > 0: 1-D grid of 32-workgroup region tasks over a 12 x 12 tile grid with task_ns row splits (see kernel)
 };
 

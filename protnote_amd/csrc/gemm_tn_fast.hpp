@@ -45,7 +45,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int TB>
+// SYNC: the region task's workgroups pace each other (checkpoint below); compiled in only where it is used - the code in the
+// slab loop costs 1-3 % even when it does nothing.
+template <int TB, bool SYNC = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) {
   static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the fast TN kernel");
   constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
@@ -62,8 +64,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
   const int ntn = p.N / BN, ntm = p.M / BM;
   int tile_m, tile_n;
   int split = blockIdx.y;
+  int* sync_ctr = nullptr;  // this task's four arrival counters (whole-split tasks only: equal work for all 32 workgroups)
   if (p.task_ns > 0) {
     if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
+    const int T = ((int)blockIdx.x >> 8) * 8 + ((int)blockIdx.x & 7);
+    if (SYNC && p.task_sync != nullptr && T < p.task_ns * 4) sync_ctr = p.task_sync + 4 * T;
   } else if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
     const int rm = ntm / 2, rn = ntn / 4;
     const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
@@ -229,6 +234,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
     // the A(t+1) DMA (invisible to hipcc: explicit wait) and the B(t+1) registers, fetched a whole slab ago; B(t+1) is
     // transformed and written under the second half of the MFMAs, B(t+2) goes out behind it and stays in flight across
     // the barrier.  Past the end the last slab is fetched again (branch-free; nobody reads it).
+    // Keeping a task's 32 workgroups in step.  They share operand panels through the XCD's 4 MB L2, which holds ~10 slabs of
+    // the task's stream; nothing couples them once every load is hidden (the better the prefetch, the freer they drift -
+    // measured: fetch 0.49 TB per launch when they happen to stay together, 1.5-1.9 TB when not, same speed).  Every 4
+    // slabs workgroup thread 0 reports its arrival and waits until ALL 32 have reached the previous checkpoint, so nobody
+    // is more than 8 slabs ahead.  The wait gives up after ~0.3 ms (it is an optimisation, never a dependency: if the 32
+    // were not co-resident it must not hang), the other waves simply meet thread 0 at the slab's barrier.
+    auto checkpoint = [&](int t) {
+      // (scalar conditions first: the other seven waves skip this with one scalar branch; called where no load is in
+      //  flight - right after the mid-slab wait - because hipcc answers a control-flow merge with conservative waits)
+      if (sync_ctr != nullptr && (t & 3) == 0 && wave == 0 && lane == 0) {  // epoch e = t / 4 reports into slot e % 4
+        const int e = t >> 2;
+        __hip_atomic_fetch_add(sync_ctr + (e & 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e > 1) {
+          const int* c = sync_ctr + ((e - 1) & 3);
+          const int want = 32 * (((e - 1) >> 2) + 1);
+          for (int spin = 0; spin < 1024 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+            __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    };
     auto slab = [&](int t, auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
       using C = integral_constant<int, CUR>;
@@ -239,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       pin_b();
+      if constexpr (SYNC && CUR == 0) checkpoint(t);
       compute(C{}, K8{}, K15{});
       commit_b(N{});
       __builtin_amdgcn_sched_barrier(0);

@@ -1342,7 +1342,9 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
 // the specialised f32 kernel of the big weight gradients (gemm_tn_fast.hpp); preconditions checked by launch_tn
 template <int TB>
 static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_fast_kernel<TB>;
+  // pacing only for the kind whose second operand streams from HBM too (the pair-sum kind's tables are L2-resident: 0.22 TB)
+  constexpr bool SYNC = TB == TB_AFFINE_RELU;
+  auto kern = gemm_tn_fast_kernel<TB, SYNC>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -1366,9 +1368,21 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
+  p.task_sync = nullptr;
   if (tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
+    // arrival counters of the region tasks (gemm_tn_fast.hpp): 16 KB per device, allocated once by the library itself -
+    // the one buffer that is not part of a caller-provided workspace (it carries no result, only pacing)
+    static int* ctr[64] = {nullptr};
+    static const bool sync_on = [] { const char* e = getenv("PN_TN_SYNC"); return e == nullptr || atoi(e) != 0; }();
+    if (SYNC && sync_on && dev < 64) {
+      if (ctr[dev] == nullptr && hipMalloc((void**)&ctr[dev], 4096 * sizeof(int)) != hipSuccess) ctr[dev] = nullptr;
+      if (ctr[dev] != nullptr && ns * 4 * 4 <= 4096) {
+        HIP_OK(hipMemsetAsync(ctr[dev], 0, (size_t)ns * 4 * 4 * sizeof(int), st));
+        p.task_sync = ctr[dev];
+      }
+    }
   }
   {
     ProfScope ps(100 + TA_PLAIN * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
