@@ -22,12 +22,13 @@ struct ConvDmaParams {
   int Lp;           // row pitch of one sequence in H (L + G)
 };
 
+// (slab loop in the style of gemm_nt_dma_kernel: SGPR-base DMA, loop unrolled over the two LDS buffers so that every ds
+//  offset is an immediate, the weight tile's DMA after the first k-step - no vector instruction but MFMAs in the loop)
 template <int WN>
 __global__ __launch_bounds__(512, 2) void gemm_conv_dma_kernel(const ConvDmaParams cp) {
   constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, BK = 32;
   constexpr int BM = 256, BN = WAVES_N * WN * 32;
-  constexpr int TILE_A = BM * BK, TILE_B = BN * BK;  // floats per operand stage
-  constexpr int STAGE = TILE_A + TILE_B;
+  constexpr unsigned TILEA = BM * BK * 4u, TILEB = BN * BK * 4u;  // bytes per operand buffer; LDS: A0 | A1 | B0 | B1
   constexpr int QB = BN / 64;  // DMA instructions per wave for the B tile (8 rows each)
   const GemmParams& p = cp.g;
 
@@ -45,11 +46,15 @@ __global__ __launch_bounds__(512, 2) void gemm_conv_dma_kernel(const ConvDmaPara
   const int col0 = tile_n * BN;
   const int spt = p.Kseg / BK;  // slabs per tap
   const int nslab = p.nseg * spt;
+  const unsigned lds0 = lds_addr(smem);
 
-  // ---- DMA source addresses (gemm_dma.hpp): instruction q of wave w covers 8 tile rows; lane l: row + l / 8, LDS
-  //      granule l % 8 holds source granule (l % 8) ^ ((row >> 1) & 7)
-  const float* asrc[4];
-  const float* bsrc[QB];
+  // ---- DMA sources (gemm_dma.hpp): instruction q of wave w covers 8 tile rows; lane l: row + l / 8, LDS granule l % 8
+  //      holds source granule (l % 8) ^ ((row >> 1) & 7).  Per-lane byte offsets from the tile's first activation row.
+  const int b0 = row0 / p.L;
+  const long hrow0 = (long)b0 * cp.Lp + (row0 - b0 * p.L);  // H row of the tile's first output row
+  const float* a_tile = p.A + hrow0 * p.lda;
+  const float* w_tile = p.W + (long)col0 * p.ldw;
+  unsigned aoff[4], boff[QB];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = 8 * (4 * wave + q) + (lane >> 3);
@@ -58,22 +63,27 @@ __global__ __launch_bounds__(512, 2) void gemm_conv_dma_kernel(const ConvDmaPara
     if (pr > p.M - 1) pr = p.M - 1;  // clamp: duplicate rows are discarded by the epilogue
     const int b = pr / p.L;
     const int t = pr - b * p.L;
-    asrc[q] = p.A + ((long)b * cp.Lp + t) * p.lda + 4 * g;
+    aoff[q] = (unsigned)((((long)b * cp.Lp + t) - hrow0) * p.lda + 4 * g) * 4u;
   }
 #pragma unroll
   for (int q = 0; q < QB; ++q) {
     const int r = 8 * (QB * wave + q) + (lane >> 3);
     const int g = (lane & 7) ^ ((r >> 1) & 7);
-    bsrc[q] = p.W + (long)(col0 + r) * p.ldw + 4 * g;  // rows up to round192(Cout) exist (zero padded)
+    boff[q] = (unsigned)((long)r * p.ldw + 4 * g) * 4u;  // rows up to round192(Cout) exist (zero padded)
   }
-  const unsigned lds0 = lds_addr(smem);
-  auto issue = [&](long aoff, int boff, int buf) {
-    const unsigned abase = lds0 + (unsigned)(buf * STAGE) * 4u + (unsigned)wave * 4096u;
-    const unsigned bbase = lds0 + (unsigned)(buf * STAGE + TILE_A) * 4u + (unsigned)wave * (QB * 1024u);
+  auto issue_a = [&](long aoff_s, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const float* src = a_tile + aoff_s;  // (a negative tap offset reaches into the guard rows in front: allocated, zero)
+    const unsigned base = lds0 + BUF * TILEA + (unsigned)wave * 4096u;
 #pragma unroll
-    for (int q = 0; q < QB; ++q) glds16(bsrc[q] + boff, __builtin_amdgcn_readfirstlane(bbase + q * 1024u));
+    for (int q = 0; q < 4; ++q) glds16s(src, aoff[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
+  };
+  auto issue_b = [&](int boff_s, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const float* src = w_tile + boff_s;
+    const unsigned base = lds0 + 2u * TILEA + BUF * TILEB + (unsigned)wave * (QB * 1024u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(asrc[q] + aoff, __builtin_amdgcn_readfirstlane(abase + q * 1024u));
+    for (int q = 0; q < QB; ++q) glds16s(src, boff[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
   };
 
   f32x16 acc[WM][WN];
@@ -87,19 +97,20 @@ __global__ __launch_bounds__(512, 2) void gemm_conv_dma_kernel(const ConvDmaPara
   const int frow = lane & 31;
   const int fh = lane >> 5;
   const int sw = (lane >> 1) & 7;
-  int fo[4];
+  unsigned fa_addr[4], fb_addr[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) fo[kk] = 4 * ((2 * kk + fh) ^ sw);
-  const int a_base = (wm * WM * 32 + frow) * BK;
-  const int b_base = TILE_A + (wn * WN * 32 + frow) * BK;
-
-  auto read_frag = [&](int buf, int kk, float4 (&a)[WM], float4 (&b)[WN]) {
-    const float* As = smem + buf * STAGE + a_base + fo[kk];
-    const float* Bs = smem + buf * STAGE + b_base + fo[kk];
+  for (int kk = 0; kk < 4; ++kk) {
+    const int fo = 4 * ((2 * kk + fh) ^ sw);
+    fa_addr[kk] = lds0 + (unsigned)((wm * WM * 32 + frow) * BK + fo) * 4u;
+    fb_addr[kk] = lds0 + 2u * TILEA + (unsigned)((wn * WN * 32 + frow) * BK + fo) * 4u;
+    asm volatile("" : "+v"(fa_addr[kk]), "+v"(fb_addr[kk]));
+  }
+  auto read_frag = [&](auto buf_c, auto kk_c, float4 (&a)[WM], float4 (&b)[WN]) {
+    constexpr int BUF = decltype(buf_c)::value, KK = decltype(kk_c)::value;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4*>(As + i * 32 * BK);
+    for (int i = 0; i < WM; ++i) a[i] = lds_read4(fa_addr[KK] + (BUF * TILEA + i * 32 * BK * 4));
 #pragma unroll
-    for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * BK);
+    for (int j = 0; j < WN; ++j) b[j] = lds_read4(fb_addr[KK] + (BUF * TILEB + j * 32 * BK * 4));
   };
   auto mma = [&](const float4 (&a)[WM], const float4 (&b)[WN]) {
 #pragma unroll
@@ -129,30 +140,47 @@ __global__ __launch_bounds__(512, 2) void gemm_conv_dma_kernel(const ConvDmaPara
     s_b = more ? s_b + BK : s_b;
   };
 
-  issue(a_tap + c, s_b, 0);
+  using std::integral_constant;
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
+  using I2 = integral_constant<int, 2>;
+  using I3 = integral_constant<int, 3>;
+  issue_a(a_tap + c, I0{});
+  issue_b(s_b, I0{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   float4 fa[WM], fb[WN], ga[WM], gb[WN];
-  read_frag(0, 0, fa, fb);
-  for (int s = 0; s < nslab; ++s) {
-    const int cur = s & 1;
+  auto slab = [&](int s, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    using C = integral_constant<int, CUR>;
+    using N = integral_constant<int, CUR ^ 1>;
     advance(s);
-    issue(a_tap + c, s_b, cur ^ 1);
+    issue_a(a_tap + c, N{});
     __builtin_amdgcn_sched_barrier(0);
-    read_frag(cur, 1, ga, gb);
+    read_frag(C{}, I1{}, ga, gb);
     mma(fa, fb);
-    read_frag(cur, 2, fa, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(s_b, N{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(C{}, I2{}, fa, fb);
     mma(ga, gb);
-    read_frag(cur, 3, ga, gb);
+    read_frag(C{}, I3{}, ga, gb);
     mma(fa, fb);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_frag(cur ^ 1, 0, fa, fb);
+    read_frag(N{}, I0{}, fa, fb);
     __builtin_amdgcn_sched_barrier(0);
     mma(ga, gb);
+  };
+  read_frag(I0{}, I0{}, fa, fb);
+  int s = 0;
+  for (; s + 1 < nslab; s += 2) {
+    slab(s, I0{});
+    slab(s + 1, I1{});
   }
+  if (s < nslab) slab(s, I0{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
