@@ -510,12 +510,23 @@ static int rowdot_nparts(int n);
 #ifndef PN_BIG
 #define PN_BIG 1
 #endif
+// the LDS-DMA kernels address their operands as SGPR base + 32-bit per-lane byte offset: a 256-row tile of either
+// operand (and, for the pair sum, each of the two tables from its origin) must span less than 4 GB
+template <int AK>
+static bool dma_offsets_fit(const GemmParams& p) {
+  const long lim = 1L << 32;
+  if ((long)256 * p.lda * 4 >= lim || (long)256 * p.ldw * 4 >= lim) return false;
+  if (AK == A_PAIRSUM_RELU)
+    return p.pairB > 0 && p.lda2 % 4 == 0 && (long)p.pairB * p.lda * 4 < lim && ((long)p.M / p.pairB + 1) * p.lda2 * 4 < lim;
+  return true;
+}
+
 template <int AK, int EK>
 static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
   if (p.drop_thresh != 0) {  // dropped hidden activations (training): f32 engines with the mask in the A loader
     if constexpr ((AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && EK == E_STORE) {
       if (PN_BIG && use_f32_dma() && variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 &&
-          p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0)
+          p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0 && dma_offsets_fit<AK>(p))
         return launch_gemm_dma<AK, EK, true>(p, st);
       return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK, true>(p, st);
     } else {
@@ -538,7 +549,7 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
   if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
     // (row MLPs over the label table, M = N_L = 32102, take it too: 126 x 12 tiles = 5.9 rounds of 256 workgroups)
     if (PN_BIG && use_f32_dma() && (variant == 0 || EK == E_ROWDOT) && p.M >= g_dma_min_rows && p.nseg == 1 && p.Kseg % 32 == 0 &&
-        p.N % 256 == 0 && p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0)
+        p.N % 256 == 0 && p.Nstore == p.N && p.lda % 4 == 0 && p.ldw % 4 == 0 && dma_offsets_fit<AK>(p))
       return launch_gemm_dma<AK, EK>(p, st);
   }
   if constexpr ((EK == E_STORE && (AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU)) ||
