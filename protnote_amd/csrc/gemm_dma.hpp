@@ -21,7 +21,8 @@
 #include "gemm_engine.hpp"
 
 #ifndef PN_DMA_SPLIT
-#define PN_DMA_SPLIT 1  // 0: all DMA / loads of the next slab at the slab top; 1: the weight tile after the first k-step
+#define PN_DMA_SPLIT 3  // 0: all DMA / loads of the next slab at the slab top; 1: the weight tile after the first k-step;
+                        // 3 (all-DMA kernels; others take 1): half of it after the first, half after the second k-step
 #endif
 
 namespace pn {
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, WN = 4, BK = 32;
   constexpr int BM = 256, BN = 256;
   constexpr bool A_DMA = (AK == A_PLAIN);
+  constexpr int SPLIT = A_DMA ? PN_DMA_SPLIT : (PN_DMA_SPLIT >= 3 ? 1 : PN_DMA_SPLIT);
   static_assert(AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "operand kind not built for the DMA kernel");
   constexpr int TILE = BM * BK;             // floats per operand buffer (32 KiB)
   constexpr unsigned TILEB = TILE * 4u;     // LDS bytes: A buffer c at c * TILEB, B buffer c at (2 + c) * TILEB
@@ -159,19 +161,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     if (ra_ > p.M - 1) ra_ = p.M - 1;  // clamp: duplicate rows are discarded by the epilogue
     aoff_dma[q] = (unsigned)((long)(ra_ - row0) * p.lda + 4 * g) * 4u;
   }
-  auto issue_b = [&](int s, auto buf_c, const float* over = nullptr) {
+  auto issue_b = [&](int s, auto buf_c, const float* over = nullptr, int q0 = 0, int q1 = 4) {
     constexpr int BUF = decltype(buf_c)::value;
     const float* src = over ? over : w_tile + s * BK;
     const unsigned base = lds0 + (2 + BUF) * TILEB + (unsigned)wave * 4096u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16s(src, boff[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
+    for (int q = 0; q < 4; ++q)
+      if (q >= q0 && q < q1) glds16s(src, boff[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
   };
-  auto issue_a = [&](int s, auto buf_c, const float* over = nullptr) {
+  auto issue_a = [&](int s, auto buf_c, const float* over = nullptr, int q0 = 0, int q1 = 4) {
     constexpr int BUF = decltype(buf_c)::value;
     const float* src = over ? over : a_tile + s * BK;
     const unsigned base = lds0 + BUF * TILEB + (unsigned)wave * 4096u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16s(src, aoff_dma[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
+    for (int q = 0; q < 4; ++q)
+      if (q >= q0 && q < q1) glds16s(src, aoff_dma[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
   };
 
   // ---- register path of a generated A operand: thread = (row r_in + 64 q, granule kv), 4 rows per thread
@@ -333,28 +337,43 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     const int nxt = s + 1 < nslab ? s + 1 : s;
     // The DMA / load issue of slab s+1 is spread over the slab instead of bursting at its top (where both waves of a SIMD
     // would sit in ~100 scalar + VMEM instructions with the matrix pipe idle): the operand that streams from HBM goes
-    // first, the L2-resident weight tile after the first k-step.  (Before the address work this spreading cost 4 %: the
+    // first, the L2-resident weight tile after the first k-step - in the all-DMA kernels in two halves, after the first and
+    // the second (148.5 -> 150.0 -> 150.5 TFLOP/s on the probe GEMM).  (Before the address work this spreading cost 4 %: the
     // per-instruction 64-bit vector adds landed between the MFMAs.)
     // (PERSIST: the slab after a tile's last one is slab 0 of the workgroup's next tile)
     const bool roll = PERSIST && has_next && s + 1 >= nslab;
     const float* a_over = roll ? a_next : nullptr;
     const float* w_over = roll ? w_next : nullptr;
-    if constexpr (A_DMA) issue_a(nxt, N{}, a_over);  // the other buffer was last read in slab s-1, which ended with a barrier
+    if constexpr (A_DMA) issue_a(nxt, N{}, a_over, 0, SPLIT == 4 ? 2 : 4);  // the other buffer was last read in slab s-1
     else fetch_a(nxt);
-    if (PN_DMA_SPLIT == 0) issue_b(nxt, N{}, w_over);
+    if (SPLIT == 0) issue_b(nxt, N{}, w_over);
     __builtin_amdgcn_sched_barrier(0);
     read_frag(C{}, I1{}, ga, gb);
     mma(fa, fb);
-    if (PN_DMA_SPLIT == 1) {
+    if (SPLIT == 1) {
       __builtin_amdgcn_sched_barrier(0);
       issue_b(nxt, N{}, w_over);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPLIT == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_b(nxt, N{}, w_over, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPLIT == 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(nxt, N{}, a_over, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
     }
     read_frag(C{}, I2{}, fa, fb);
     mma(ga, gb);
     __builtin_amdgcn_sched_barrier(0);
-    if (PN_DMA_SPLIT == 2) {
+    if (SPLIT == 2 || SPLIT == 4) {
       issue_b(nxt, N{}, w_over);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPLIT == 3) {
+      issue_b(nxt, N{}, w_over, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
     }
     read_frag(C{}, I3{}, ga, gb);
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
               // first 16 of k-step 2's 32 MFMAs (three quarters of a slab to land)
       mma_rows(fa, fb, I0{});
       __builtin_amdgcn_sched_barrier(0);
-      pin_a(integral_constant<int, (PN_DMA_SPLIT == 1 ? 4 : 0)>{});
+      pin_a(integral_constant<int, (SPLIT == 1 ? 4 : 0)>{});
       mma_rows(fa, fb, I1{});
       commit_a(N{});
     }
