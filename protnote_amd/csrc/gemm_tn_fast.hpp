@@ -12,6 +12,9 @@
 #include "gemm_dma.hpp"
 #include "gemm_tn.hpp"
 
+#ifndef PN_TN_SYNC_SLABS
+#define PN_TN_SYNC_SLABS 8  // slabs per pacing checkpoint (power of two); measured 4 / 8 / 16: 0.54 / 0.62 / 0.76 TB per launch at 143.8 / 145.6 / 146.0 TFLOP/s
+#endif
 #ifndef PN_TN_WAIT_KK
 #define PN_TN_WAIT_KK 14
 #endif
@@ -236,15 +239,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
     // the barrier.  Past the end the last slab is fetched again (branch-free; nobody reads it).
     // Keeping a task's 32 workgroups in step.  They share operand panels through the XCD's 4 MB L2, which holds ~10 slabs of
     // the task's stream; nothing couples them once every load is hidden (the better the prefetch, the freer they drift -
-    // measured: fetch 0.49 TB per launch when they happen to stay together, 1.5-1.9 TB when not, same speed).  Every 4
-    // slabs workgroup thread 0 reports its arrival and waits until ALL 32 have reached the previous checkpoint, so nobody
-    // is more than 8 slabs ahead.  The wait gives up after ~0.3 ms (it is an optimisation, never a dependency: if the 32
+    // measured: fetch 0.49 TB per launch when they happen to stay together, 1.5-1.9 TB when not, same speed).  Every
+    // PN_TN_SYNC_SLABS slabs workgroup thread 0 reports its arrival and waits until ALL 32 have reached the previous
+    // checkpoint, so nobody is more than two checkpoints ahead.  The wait gives up after ~0.3 ms (it is an optimisation, never a dependency: if the 32
     // were not co-resident it must not hang), the other waves simply meet thread 0 at the slab's barrier.
     auto checkpoint = [&](int t) {
       // (scalar conditions first: the other seven waves skip this with one scalar branch; called where no load is in
       //  flight - right after the mid-slab wait - because hipcc answers a control-flow merge with conservative waits)
-      if (sync_ctr != nullptr && (t & 3) == 0 && wave == 0 && lane == 0) {  // epoch e = t / 4 reports into slot e % 4
-        const int e = t >> 2;
+      if (sync_ctr != nullptr && (t & (PN_TN_SYNC_SLABS - 1)) == 0 && wave == 0 && lane == 0) {  // epoch e reports into slot e % 4
+        const int e = t / PN_TN_SYNC_SLABS;
         __hip_atomic_fetch_add(sync_ctr + (e & 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e > 1) {
           const int* c = sync_ctr + ((e - 1) & 3);
