@@ -320,6 +320,10 @@ int pn_set_math_mode(int mode);
  * summed over the ranks, in place and ordered on the stream the library was called on; it returns 0 on success.
  * `world` = number of ranks; every rank must run the same batch shape.  hook == NULL switches back to per-rank
  * statistics (the default, SYNC_BN: False). */
+/* Row-MLP backward over >= 16384 rows (W_l over the label table): 1 (default) materialises dY once and runs the 256-tile
+ * kernels, 0 regenerates it in the operand loaders of the 128-tile engine (A/B switch; no reference counterpart). */
+int pn_set_mlp_materialize(int on);
+
 typedef int (*pn_sync_hook)(long n_doubles, void* user);
 int pn_set_sync_bn(pn_sync_hook hook, void* user, double* stage, long stage_doubles, int world);
 int pn_get_math_mode(void);

@@ -149,6 +149,7 @@ _SIGS = {
                                   C.c_void_p]),
     "pn_dropout_mask": (C.c_int, [C.c_uint, C.c_int, C.c_float, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_set_math_mode": (C.c_int, [C.c_int]),
+    "pn_set_mlp_materialize": (C.c_int, [C.c_int]),
     "pn_set_sync_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),

@@ -1473,7 +1473,7 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
   // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction); a plain A operand (the
   // materialised dz) is staged by LDS-DMA when every split is a whole number of 32-row slabs
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
-    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 && p.R % 32 == 0 && p.lda % 4 == 0) {
+    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 16384 && p.R % 32 == 0 && p.lda % 4 == 0) {
       if constexpr (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU) {
         // the low-VALU kernel: 32-bit per-lane offsets, and for the pair sum a slab inside one label
         const bool fits = (long)8 * p.ldb * 4 < (1L << 31) && p.ldb % 4 == 0 && (TB != TB_AFFINE_RELU || p.b_s != nullptr);
@@ -1483,7 +1483,7 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
       return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
     }
   }
-  if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536)
+  if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 16384)
     return launch_tn_cfg<TA, TB, true>(p, dst, ldd, part, part_cap_floats, st);
   return launch_tn_cfg<TA, TB, false>(p, dst, ldd, part, part_cap_floats, st);
 }
@@ -1651,6 +1651,14 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
   return 0;
 }
 
+// PN_MLP_MAT=0 / pn_set_mlp_materialize(0): the row-MLP backward regenerates dY in the operand loaders for every row count
+// (the path the small-size oracle tests pin) - an A/B switch for tests and measurements
+static int g_mlp_mat = [] { const char* e = getenv("PN_MLP_MAT"); return e ? atoi(e) : 1; }();
+extern "C" int pn_set_mlp_materialize(int on) {
+  g_mlp_mat = on ? 1 : 0;
+  return 0;
+}
+
 extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int rows, const float* dy,
                                const pn_mlp_grads* gr, float* dx, void* save, size_t save_bytes, void* ws,
                                size_t ws_bytes, void* stream) {
@@ -1695,10 +1703,23 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
                          (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[l], gr->dbeta[l], (float*)nullptr));
       HIP_OK(hipGetLastError());
     }
+    // Big row counts (W_l over the label table): dY_l is materialised once, in place over the incoming gradient (our
+    // scratch), and both GEMMs take it as a plain operand - the 256-tile LDS-DMA NT kernel and the big TN tiles - instead of
+    // regenerating it in the operand loaders of the 128-tile engine (0.70 of peak).  Same dz arithmetic (k_dz_apply).
+    const bool mat = !last && g_mlp_mat && rows >= g_dma_min_rows && g_math_mode == 0 && use_f32_dma();
+    if (mat) {
+      DzParams dp;
+      memset(&dp, 0, sizeof(dp));
+      dp.R = rows; dp.C = N; dp.rows_per_block = 512;
+      dp.Z = sv.Y[l]; dp.ldz = N; dp.G = G; dp.ldg = ldg; dp.s = sv.s[l]; dp.t = sv.t[l]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q;
+      dp.out = const_cast<float*>(G); dp.ldo = ldg;
+      hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(N, 1024), nblk(rows, 512)), dim3(256), 0, st, dp);
+      HIP_OK(hipGetLastError());
+    }
     // dW_l[N][K] = dY_l^T X_l
     TnParams tp = tn_zero();
     tp.R = rows; tp.M = N; tp.N = K;
-    if (last) {
+    if (last || mat) {
       tp.A = G; tp.lda = ldg;
     } else {
       tp.A = sv.Y[l]; tp.lda = N; tp.G = G; tp.ldg = ldg;
@@ -1706,11 +1727,11 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
     }
     if (l == 0 || drop) {  // plain B operand: the input rows, or the materialised dropped activation H_{l-1}
       tp.B = l == 0 ? x : sv.H[l - 1]; tp.ldb = l == 0 ? ldx : K;
-      if (last) PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+      if (last || mat) PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
       else PN_OK((launch_tn<TA_DZ_ELEM, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
     } else {
       tp.B = sv.Y[l - 1]; tp.ldb = K; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
-      if (last) PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
+      if (last || mat) PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
       else PN_OK((launch_tn<TA_DZ_ELEM, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
     }
     // dX_l[rows][K] = dY_l W_l   (NT engine against W_l^T)
@@ -1721,7 +1742,7 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
       p.W = w.WT; p.ldw = N;
       float* out = (l == 0) ? dx : w.G[gsel];
       p.C = out; p.ldc = K;
-      if (last) {
+      if (last || mat) {
         p.A = G; p.lda = ldg;
         PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, pick_variant(K), st)));
       } else {

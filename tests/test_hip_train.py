@@ -1115,3 +1115,48 @@ def test_mlp_dropout_big_kernels_match_small_tiles():
     for i, (x, z) in enumerate(zip(a, b)):  # different tilings / split-K groupings: f32 reassociation noise only
         rel = (x - z).norm().item() / max(z.norm().item(), 1e-30)
         assert rel < 2e-4, (i, rel)
+
+
+@pytest.mark.parametrize("NL", [20000, 20006])  # whole 32-row slabs (LDS-DMA / specialised TN kernels) and a ragged row count
+def test_row_mlp_backward_big_kernels_match_small_tiles(NL):
+    """W_l over a label table of >= 16384 rows: the backward materialises dY once and runs the 256-tile LDS-DMA NT kernel and
+    the big TN tiles instead of regenerating dY in the operand loaders of the 128-tile engine.  With pn_set_mlp_materialize(0) the
+    old backward runs (the one the small-size oracle tests pin) behind the same forward: the materialised dY equals the
+    regenerated one and the NT products keep their order, so only the weight gradients' row splits differ -
+    accumulation-order noise."""
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(83)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B = 4
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, label_embedding_noising_alpha=0.0)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+
+    def run(mat):
+        L.check(L.lib().pn_set_mlp_materialize(mat))
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        (la, ga), (lb, gb) = run(1), run(0)
+    finally:
+        L.lib().pn_set_mlp_materialize(1)
+    assert torch.equal(la, lb)  # same forward
+    checked = 0
+    for n in ga:
+        if n.startswith("W_l."):
+            rel = ((ga[n] - gb[n]).double().norm() / gb[n].double().norm().clamp_min(1e-30)).item()
+            assert rel < 2e-5, (n, rel)
+            checked += 1
+    assert checked >= 7
