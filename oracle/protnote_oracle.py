@@ -197,6 +197,64 @@ def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], 
     return torch.special.logit(p, eps=1e-7)
 
 
+def train_forward_chunked(sd: SD, P_f: Tensor, L_f: Tensor, *, fusion: str = "concatenation", label_chunk: int = 512,
+                          momentum: float = 0.1, eps: float = 1e-5) -> Tensor:
+    """ProtNote.forward in TRAINING mode (ProtNote.py:270-309: W_p, W_l, _get_joint_embeddings :112-152, output_layer
+    = get_mlp :337-378 with train-mode BatchNorm1d) for pair grids too large to materialise: the same naive
+    formulation - joint rows, Linear, BatchNorm over ALL B*N_L rows, ReLU - evaluated in label chunks.  A layer's
+    batch statistics need every row before any row can be normalised, so hidden layer n costs one pass that recomputes
+    layers < n from the joint rows; one more pass produces the logits.  Column sums are accumulated in float64;
+    running_mean / running_var / num_batches_tracked in `sd` advance exactly like torch's BatchNorm1d (unbiased
+    variance into running_var).  Device-agnostic plain torch: tests run it on CPU against protnote_forward (small
+    grids) and on the GPU at BASELINE configs[2] size, where it is the independent check of the HIP train forward.
+    Returns logits [B, N_L]."""
+    P_e = mlp_rows(sd, "W_p.", P_f, True)
+    L_e = mlp_rows(sd, "W_l.", L_f, True)
+    b, n = P_e.shape[0], L_e.shape[0]
+    rows = b * n
+    lin = _linear_indices(sd, "output_layer.")
+    hidden, out_i = lin[:-1], lin[-1]
+    stats = []  # per normalised hidden layer: (mean f32, scale f32, shift f32) or None without BatchNorm
+
+    def chain(j0: int, j1: int, upto: int) -> Tensor:
+        """pre-activation of hidden layer `upto` (or the logits for upto == len(hidden)) for labels [j0, j1)."""
+        x = joint_embeddings(P_e, L_e[j0:j1], fusion)
+        for m, i in enumerate(hidden[:upto]):
+            x = F.linear(x, sd[f"output_layer.{i}.weight"], sd.get(f"output_layer.{i}.bias"))
+            if stats[m] is not None:
+                mean, scale, shift = stats[m]
+                x = x.sub_(mean).mul_(scale).add_(shift)
+            x = F.relu_(x)
+        i = hidden[upto] if upto < len(hidden) else out_i
+        return F.linear(x, sd[f"output_layer.{i}.weight"], sd.get(f"output_layer.{i}.bias"))
+
+    for m, i in enumerate(hidden):
+        pre = f"output_layer.{i + 1}."
+        if pre + "running_mean" not in sd:
+            stats.append(None)
+            continue
+        s1 = torch.zeros(sd[pre + "weight"].shape[0], dtype=torch.float64, device=P_e.device)
+        s2 = torch.zeros_like(s1)
+        for j0 in range(0, n, label_chunk):
+            z = chain(j0, min(n, j0 + label_chunk), m).double()
+            s1 += z.sum(0)
+            s2 += (z * z).sum(0)
+        mean = s1 / rows
+        var = (s2 / rows - mean * mean).clamp_min(0.0)  # biased, as used for normalisation
+        dt = sd[pre + "weight"].dtype
+        scale = (sd[pre + "weight"].double() / torch.sqrt(var + eps)).to(dt)
+        stats.append((mean.to(dt), scale, sd[pre + "bias"]))
+        sd[pre + "running_mean"].mul_(1 - momentum).add_(mean.to(dt), alpha=momentum)
+        sd[pre + "running_var"].mul_(1 - momentum).add_((var * (rows / max(rows - 1, 1))).to(dt), alpha=momentum)
+        if pre + "num_batches_tracked" in sd:
+            sd[pre + "num_batches_tracked"] += 1
+    logits = torch.empty(b, n, dtype=P_e.dtype, device=P_e.device)
+    for j0 in range(0, n, label_chunk):
+        j1 = min(n, j0 + label_chunk)
+        logits[:, j0:j1] = chain(j0, j1, len(hidden)).reshape(b, j1 - j0)
+    return logits
+
+
 # ------------------------------------------------------------------------------------------------
 # losses / metrics / optimiser step
 # ------------------------------------------------------------------------------------------------

@@ -50,6 +50,20 @@ def stale() -> bool:
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in deps)
 
 
+def csrc_hash() -> str:
+    """sha256 over the device sources (csrc/*.hip, csrc/*.hpp, the C-ABI header), file names included: profiles that
+    describe kernel behaviour (profiles/*_hbm_traffic.json) are stamped with it so bench.py can tell when they no longer
+    belong to the kernels it is running (.git does not travel to the GPU box)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    for f in [os.path.join(CSRC, f) for f in files] + [API]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale() and not _extra():
         return LIB

@@ -234,8 +234,7 @@ extern "C" int pn_dropout_mask(unsigned seed, int stream, float p, long rows, in
 // them and the fold that consumes them, so the cross-rank sum is a callback: the host registers `hook(n, user)`, which
 // must sum the first n doubles of the staging buffer over the ranks in place, ordered on the launch stream
 // (protnote_amd.utils.distributed.enable_sync_batchnorm: torch.distributed.all_reduce = RCCL).  Forward: per-column
-// [sum, sum of squares] travel and the count is multiplied by the world size (every rank runs the same batch shape, as
-// the reference's DistributedSampler guarantees).  Backward: [sum du, sum du*xhat] travel for the dz generator's p / q
+// [sum, sum of squares, row count] travel (the ranks' batch shapes may differ: see sync_sum2).  Backward: [sum du, sum du*xhat] travel for the dz generator's p / q
 // vectors, while dgamma / dbeta stay the LOCAL sums (the gradient all-reduce averages them like every other
 // gradient) - torch's SyncBatchNorm backward.
 // ------------------------------------------------------------------------------------------------
@@ -256,18 +255,27 @@ extern "C" int pn_set_sync_bn(pn_sync_hook_t hook, void* user, double* stage, lo
   return 0;
 }
 static bool sync_bn_on() { return g_sync_hook != nullptr && g_sync_world > 1; }
-// a[0..n) and b[0..n) (device, f64) become their sums over the ranks
-static int sync_sum2(double* a, double* b, long n, hipStream_t st) {
+__global__ void k_set_double(double* p, double v) { *p = v; }
+// a[0..n) and b[0..n) (device, f64) become their sums over the ranks, and so does this rank's row count: the ranks'
+// batches differ in shape (each collator pads to its own batch maximum, collators.py:40, and the last batch of an epoch
+// is ragged), so the global count is the SUM of the local ones (torch.nn.SyncBatchNorm all-gathers the counts), not
+// local * world.  Returns (through count_dev) the device address of the global count, valid until the next call; the
+// kernels that consume the statistics read it from there.  nullptr when SYNC_BN is off.
+static int sync_sum2(double* a, double* b, long n, double local_count, const double** count_dev, hipStream_t st) {
+  *count_dev = nullptr;
   if (!sync_bn_on()) return 0;
-  if (2 * n > g_sync_cap) return fail("sync_bn: %ld statistics exceed the staging buffer (%ld doubles)", 2 * n, g_sync_cap);
+  if (2 * n + 2 > g_sync_cap) return fail("sync_bn: %ld statistics exceed the staging buffer (%ld doubles)", 2 * n + 2, g_sync_cap);
   HIP_OK(hipMemcpyAsync(g_sync_stage, a, n * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(g_sync_stage + n, b, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (g_sync_hook(2 * n, g_sync_user) != 0) return fail("sync_bn: the all-reduce callback failed");
+  hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, g_sync_stage + 2 * n, local_count);
+  if (g_sync_hook(2 * n + 1, g_sync_user) != 0) return fail("sync_bn: the all-reduce callback failed");
   HIP_OK(hipMemcpyAsync(a, g_sync_stage, n * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(b, g_sync_stage + n, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  double* keep = g_sync_stage + g_sync_cap - 1;  // outside every staged range: survives until the next call
+  HIP_OK(hipMemcpyAsync(keep, g_sync_stage + 2 * n, sizeof(double), hipMemcpyDeviceToDevice, st));
+  *count_dev = keep;
   return 0;
 }
-static double sync_count(double local) { return sync_bn_on() ? local * (double)g_sync_world : local; }
 
 // ------------------------------------------------------------------------------------------------
 // GEMM launch
@@ -638,11 +646,12 @@ __global__ void k_bn_fold_eval(pn_bn bn, const float* lin_bias, float eps, int C
 
 // train-mode BatchNorm from accumulated column sums: batch mean / biased variance for normalisation,
 // running stats updated with momentum and the unbiased variance (torch.nn.BatchNorm1d semantics).
-__global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq, double count, float eps,
-                                float momentum, int C, int ld, float* s, float* t, float* mean_out,
-                                float* invstd_out) {
+__global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq, double count,
+                                const double* count_dev, float eps, float momentum, int C, int ld, float* s, float* t,
+                                float* mean_out, float* invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ld) return;
+  if (count_dev != nullptr) count = *count_dev;  // SYNC_BN: the rows of all ranks
   float sc = 0.f, sh = 0.f;
   if (c < C) {
     const double mean = sum[c] / count;
@@ -667,8 +676,9 @@ __global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq
 // fold of a train-mode BatchNorm from this rank's column sums; with SYNC_BN the sums of all ranks (see pn_set_sync_bn)
 static int fold_train(hipStream_t st, pn_bn bn, const double* sum, const double* sumsq, double count, float eps,
                       float momentum, int C, int ld, float* s, float* t, float* mean_out, float* invstd_out) {
-  PN_OK(sync_sum2(const_cast<double*>(sum), const_cast<double*>(sumsq), C, st));
-  hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ld, 256)), dim3(256), 0, st, bn, sum, sumsq, sync_count(count), eps,
+  const double* gcount = nullptr;
+  PN_OK(sync_sum2(const_cast<double*>(sum), const_cast<double*>(sumsq), C, count, &gcount, st));
+  hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ld, 256)), dim3(256), 0, st, bn, sum, sumsq, count, gcount, eps,
                      momentum, C, ld, s, t, mean_out, invstd_out);
   HIP_OK(hipGetLastError());
   return 0;
@@ -1503,13 +1513,14 @@ static const size_t TN_PART_FLOATS_MAX = (size_t)16 * 3072 * 3072;
 static int bwd_finalize(hipStream_t st, const double* S1, const double* S2, const double* dwacc, double count, int C,
                         const float* gamma, const float* s, const float* mean, const float* invstd, const float* w,
                         float* cs, float* pv, float* qv, float* dgamma, float* dbeta, float* dw_out) {
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, dwacc, count, C, gamma, s, mean,
-                     invstd, w, cs, pv, qv, dgamma, dbeta, dw_out);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, dwacc, count,
+                     (const double*)nullptr, C, gamma, s, mean, invstd, w, cs, pv, qv, dgamma, dbeta, dw_out);
   HIP_OK(hipGetLastError());
   if (sync_bn_on() && gamma != nullptr) {
-    PN_OK(sync_sum2(const_cast<double*>(S1), const_cast<double*>(S2), C, st));
+    const double* gcount = nullptr;
+    PN_OK(sync_sum2(const_cast<double*>(S1), const_cast<double*>(S2), C, count, &gcount, st));
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, (const double*)nullptr,
-                       sync_count(count), C, gamma, s, mean, invstd, w, cs, pv, qv, (float*)nullptr, (float*)nullptr,
+                       count, gcount, C, gamma, s, mean, invstd, w, cs, pv, qv, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr);
     HIP_OK(hipGetLastError());
   }
@@ -1786,7 +1797,7 @@ static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& 
 }
 
 struct PairTrainWs {
-  double *sumA, *sqA, *sumB, *sqB, *S1, *S2, *dwacc, *scal;
+  double *sumA, *sqA, *sumB, *sqB, *S1, *S2, *dwacc, *scal, *s12;
   float *cs, *p, *q, *WT, *weff, *dweff, *part, *dA1, *dB1;
   size_t part_floats;
   ColScr colscr;
@@ -1806,6 +1817,7 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.S2 = bp.take<double>(h);
   w.dwacc = bp.take<double>(h);
   w.scal = bp.take<double>(4 + SUM_BLOCKS);  // [0] result, [4..) per-workgroup partials of k_sum
+  w.s12 = bp.take<double>(2 * (size_t)h);    // SYNC_BN: the separable first layer's S1 | S2 on their way to the all-reduce
   w.cs = bp.take<float>(h);
   w.p = bp.take<float>(h);
   w.q = bp.take<float>(h);
@@ -2097,12 +2109,13 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     hipLaunchKernelGGL(k_pair_bn0_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.statscr.red, nchunk,
                        (const float*)sv.A1, (long)h, (const float*)w.dA1, (long)h, B, NL, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], w.cs, w.p, w.q,
-                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2, sync_bn_on() ? g_sync_stage + g_sync_cap / 2 : (double*)nullptr);
+                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2, sync_bn_on() ? w.s12 : (double*)nullptr);
     if (sync_bn_on() && hd->bn[0].weight != nullptr) {  // global S1 / S2 -> cs, p, q (dgamma / dbeta stay local)
-      double* s12 = g_sync_stage + g_sync_cap / 2;
-      PN_OK(sync_sum2(s12, s12 + h, h, st));
+      double* s12 = w.s12;  // workspace, not the staging buffer: sync_sum2 stages through that itself
+      const double* gcount = nullptr;
+      PN_OK(sync_sum2(s12, s12 + h, h, (double)B * (double)NL, &gcount, st));
       hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)s12, (const double*)(s12 + h),
-                         (const double*)nullptr, sync_count((double)B * (double)NL), h, hd->bn[0].weight,
+                         (const double*)nullptr, (double)B * (double)NL, gcount, h, hd->bn[0].weight,
                          (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], (const float*)nullptr,
                          w.cs, w.p, w.q, (float*)nullptr, (float*)nullptr, (float*)nullptr);
       HIP_OK(hipGetLastError());

@@ -297,12 +297,13 @@ __global__ void k_unpack_conv_grad(const float* __restrict__ packed, int Cout, i
 // From S1,S2: dgamma = S2, dbeta = S1 and the per-column vectors of the dz generator
 //   dz = (mask ? g*cs : 0) + p + q*z,   cs = s*(w or 1),  q = -s*invstd*S2/R,  p = -s*S1/R - q*mean
 // (s = gamma*invstd).  Without BatchNorm (gamma == nullptr): cs = (w or 1), p = q = 0, dbias = S1.
-__global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const double* dwacc, double count, int C,
-                                  const float* gamma, const float* s, const float* mean, const float* invstd,
-                                  const float* w, float* cs, float* pv, float* qv, float* dgamma, float* dbeta,
-                                  float* dw_out) {
+__global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const double* dwacc, double count,
+                                  const double* count_dev, int C, const float* gamma, const float* s, const float* mean,
+                                  const float* invstd, const float* w, float* cs, float* pv, float* qv, float* dgamma,
+                                  float* dbeta, float* dw_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev != nullptr) count = *count_dev;  // SYNC_BN: the rows of all ranks (see sync_sum2)
   const float wc = w ? w[c] : 1.f;
   if (gamma != nullptr) {
     const float sc = s[c];

@@ -140,6 +140,10 @@ class ProtNote(nn.Module):
                 batch_norm=outout_mlp_add_batchnorm, dropout=dropout)
         # label-chunk size of the eval pair head (rows = chunk * B); None = auto (~512k pair rows)
         self.pair_label_chunk = None
+        # eval-mode cache of L_e = W_l(label table) (see _label_projection_eval) and named tables (set_label_table)
+        self.__dict__["_pn_le_cache"] = {}
+        self.__dict__["_pn_label_tables"] = {}
+        self.label_projection_cache_size = 4
 
     def _get_concatenated_features_dim(self):
         dim = {"concatenation_diff": self.latent_dim * 3, "concatenation_prod": self.latent_dim * 3,
@@ -205,6 +209,56 @@ class ProtNote(nn.Module):
                                          L.stream_ptr()))
         del keep
         return y
+
+    # ------------------------------------------------------------------ eval-mode label projection cache
+    def train(self, mode=True):
+        """A train-mode forward moves W_l's BatchNorm buffers and an optimiser step its weights through raw device
+        pointers (no tensor version changes), so every train()/eval() switch drops the cached label projections."""
+        self.__dict__.setdefault("_pn_le_cache", {}).clear()
+        return super().train(mode)
+
+    def _w_l_state_key(self):
+        from ..utils.optim import weights_generation
+
+        vs = tuple((t.data_ptr(), t._version) for t in list(self.W_l.parameters()) + list(self.W_l.buffers()))
+        return (weights_generation(), L.get_math_mode(), vs)
+
+    def _label_projection_eval(self, label_embeddings):
+        """L_e = W_l(L_f) in eval mode depends only on the label table and W_l (reference ProtNote.py:192-196,270-271
+        recomputes it on every call: 3.2 TFLOP for 64 204 description rows, i.e. 1/B of the head's work - 12 % at the
+        reference's per-GPU batch of 8).  Cached per table OBJECT: the entry holds a reference to the tensor it was
+        computed from (so its address cannot be recycled) and is valid while that tensor's version counter, W_l's
+        parameters / buffers (addresses + version counters), the fused optimiser's step generation and the math mode are
+        unchanged; train()/eval() switches clear it.  A fresh tensor per call simply recomputes, as the reference does."""
+        cache = self.__dict__.setdefault("_pn_le_cache", {})
+        t = label_embeddings
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+        state = (t._version, self._w_l_state_key())
+        hit = cache.get(key)
+        if hit is not None and hit[0] is t and hit[1] == state:
+            cache[key] = cache.pop(key)  # most recently used last
+            return hit[2]
+        L_e = self._project_eval(self.W_l, t.detach().float().contiguous())
+        cache.pop(key, None)
+        cache[key] = (t, state, L_e)
+        while len(cache) > max(int(self.label_projection_cache_size), 0):
+            cache.pop(next(iter(cache)))
+        return L_e
+
+    def set_label_table(self, name, label_embeddings):
+        """Register a label table (cached description embeddings [N_L * n_desc, d_l] on the device) under `name`;
+        forward(label_embeddings=name) then scores against it.  Swapping GO -> EC at run time (BASELINE configs[4],
+        reference bin/test_models.py:14-23 re-runs main.py per test set) is a dictionary lookup: the table stays in HBM
+        and its projection L_e is computed once per weight state, not once per batch."""
+        L.require_hip(label_embeddings)
+        self.__dict__.setdefault("_pn_label_tables", {})[str(name)] = label_embeddings
+        return label_embeddings
+
+    def label_table(self, name):
+        try:
+            return self.__dict__.get("_pn_label_tables", {})[str(name)]
+        except KeyError:
+            raise KeyError(f"no label table named {name!r}; call set_label_table first") from None
 
     def _train_chunk(self, B, NL):
         """Labels per chunk of the backward ring (rows = chunk * B); ~256k pair rows by default (each chunk is one
@@ -296,6 +350,8 @@ class ProtNote(nn.Module):
                 label_embeddings=None, label_token_counts=None, save_embeddings=False):
         """Reference ProtNote.forward (ProtNote.py:168-334).  Returns (logits [B, N_L], embeddings dict)."""
         # ---- label branch (:192-217): cached-embedding path only ----
+        if isinstance(label_embeddings, str):  # a table registered with set_label_table
+            label_embeddings = self.label_table(label_embeddings)
         if label_embeddings is not None and (self.label_encoder_num_trainable_layers == 0 or not self.training):
             L_f = label_embeddings
         elif tokenized_labels is not None and self.training:
@@ -327,6 +383,7 @@ class ProtNote(nn.Module):
                 return logits, {"output_layer_embeddings": [], "joint_embeddings": []}
 
             with torch.no_grad():
+                table = L_f if not (pool_all or self.training) else None  # the caller's table object: cacheable
                 L_f = L_f.detach().float().contiguous()
                 if self.training and label_token_counts is not None and self.label_embedding_noising_alpha > 0:
                     # reference :219-240
@@ -341,7 +398,7 @@ class ProtNote(nn.Module):
                 if self.training:
                     raise NotImplementedError("train-mode forward under no_grad is not implemented")
                 P_e = self._project_eval(self.W_p, P_f)
-                L_e = self._project_eval(self.W_l, L_f)
+                L_e = self._label_projection_eval(table) if table is not None else self._project_eval(self.W_l, L_f)
                 B, NL = P_e.shape[0], L_e.shape[0]
                 ndesc = 1 if self.training else int(self.inference_descriptions_per_label)
                 if self.feature_fusion == "similarity":

@@ -9,6 +9,20 @@ import torch
 from .. import _lib as L
 
 
+_weights_generation = 0
+
+
+def weights_generation() -> int:
+    """Bumped whenever a fused optimiser rewrites parameters through raw device pointers (step / repack /
+    load_state_dict): tensor version counters do not see those writes, caches of weight-derived tensors key on this."""
+    return _weights_generation
+
+
+def _bump_generation():
+    global _weights_generation
+    _weights_generation += 1
+
+
 class FusedClipAdam:
     def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0):
         self.params = [p for p in params if p.requires_grad]
@@ -55,6 +69,7 @@ class FusedClipAdam:
                                    "was moved / cast / re-assigned after the optimiser was built); rebuild the "
                                    "optimiser, or call repack()")
         self.step_count += 1
+        _bump_generation()
         ws = L.workspace(L.PN_ADAM_WS_BYTES, self.flat_w.device, "adam")
         max_norm = -1.0 if self.max_norm is None else float(self.max_norm)
         L.check(L.lib().pn_clip_adam_step(L.ptr(self.flat_w), L.ptr(self.flat_g), L.ptr(self.flat_m),
@@ -65,6 +80,7 @@ class FusedClipAdam:
 
     def repack(self):
         """Re-adopt the parameters' current values (after the model was moved / re-assigned) as views of flat_w."""
+        _bump_generation()
         with torch.no_grad():
             for p, off in self._offsets():
                 view = self.flat_w[off:off + p.numel()].view_as(p)

@@ -172,9 +172,20 @@ def test_bench_self_launches_its_ranks():
     assert c["grad_allreduce"]["calls_per_step"] == 1 and c["bn_buffer_broadcast"]["calls_per_step"] == 1
     assert j["value"] > 0 and j["forward_only"]["f32"]["value"] > 0
     assert all(v["value"] > 0 for v in j["zero_shot"]["f32"].values())
+    # after K all-reduced steps from deliberately different seeds the replicas hold bit-identical weights
+    assert j["comm"]["replicas_in_sync"] is True and len(j["comm"]["flat_w_checksum_per_rank"]) == 2
+    assert len(j["comm"]["own_seconds_before_barrier"]["per_rank"]) == 2
+    # configs[4]: sequences (not batches) are dealt to the ranks - nobody idles, the shares differ by at most one
+    # sequence per length bucket, and every rank reports its own seconds
+    zs = j["zero_shot"]
+    assert zs["sequences_per_rank"] == [8.0, 8.0] or (sum(zs["sequences_per_rank"]) == 16 and
+                                                      max(zs["sequences_per_rank"]) - min(zs["sequences_per_rank"]) <= 5)
+    assert min(zs["batches_per_rank"]) >= 1
+    for v in zs["f32"].values():
+        assert len(v["rank_seconds"]["per_rank"]) == 2 and v["rank_seconds"]["min"] > 0
 
 
-def _sync_bn_worker(rank, world, port, q, train_encoder):
+def _sync_bn_worker(rank, world, port, q, train_encoder, mode="even"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), PN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PN_SHARE_GPU="1")
     import sys
@@ -193,7 +204,14 @@ def _sync_bn_worker(rank, world, port, q, train_encoder):
     lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
 
-    def run(rows, sync, reduce=False):
+    def shard(rk):
+        if mode == "uneven_B":  # 4 + 2 proteins: the ranks' BatchNorm row counts differ (ragged last batch of an epoch)
+            return [0, 1, 2, 3] if rk == 0 else [4, 5]
+        if mode == "ragged_L":  # lens [50, 50, 44] | [3, 21, 17]: rank 1's collator pads to 21, not 50 (collators.py:40)
+            return [0, 3, 5] if rk == 0 else [1, 2, 4]
+        return D.shard_batch(x.shape[0], rk, w)
+
+    def run(rows, sync, reduce=False, lmax=None, weight=1.0):
         model, _ = make_protnote(g, dev, label_embedding_noising_alpha=0.0, train_sequence_encoder=train_encoder)
         params = list(head_parameters(model))
         if train_encoder:
@@ -207,10 +225,11 @@ def _sync_bn_worker(rank, world, port, q, train_encoder):
         if sync:
             assert D.enable_sync_batchnorm(dev)
         try:
-            logits, _ = model(sequence_onehots=x[rows].to(dev), sequence_lengths=lens[rows].to(dev),
+            xr = x[rows] if lmax is None else x[rows][:, :, :lmax].contiguous()
+            logits, _ = model(sequence_onehots=xr.to(dev), sequence_lengths=lens[rows].to(dev),
                               label_embeddings=lab.to(dev))
             loss = loss_fn(logits, yy[rows].to(dev))
-            loss.backward()
+            (loss * weight).backward()
             if sync or reduce:
                 D.allreduce_gradients(opt)
         finally:
@@ -220,13 +239,19 @@ def _sync_bn_worker(rank, world, port, q, train_encoder):
         bufs = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
         return float(loss), opt.flat_g.detach().cpu().clone(), bufs
 
-    l_sync, g_sync, b_sync = run(D.shard_batch(x.shape[0], r, w), True)
+    mine = shard(r)
+    # unequal shards: the mean of per-rank mean losses is not the whole-batch mean; weigh each rank's loss by its share so
+    # that the AVERAGED gradient is the whole-batch gradient (the statistics must then be the whole-batch ones as well)
+    wgt = len(mine) * w / x.shape[0]
+    lmax = int(lens[mine].max()) if mode == "ragged_L" else None
+    l_sync, g_sync, b_sync = run(mine, True, lmax=lmax, weight=wgt)
+    l_sync *= wgt
     torch.distributed.barrier()
-    _, g_per_rank, _ = run(D.shard_batch(x.shape[0], r, w), False, reduce=True)  # control: per-rank statistics
+    _, g_per_rank, _ = run(mine, False, reduce=True, lmax=lmax, weight=wgt)  # control: per-rank statistics
     torch.distributed.barrier()
     out = (r, l_sync, g_sync.numpy(), {k: v.numpy() for k, v in b_sync.items()}, None, g_per_rank.numpy())
     if r == 0:  # the same step on ONE rank over the whole batch, per-rank statistics (= statistics of the whole batch)
-        l_full, g_full, b_full = run(list(range(x.shape[0])), False)
+        l_full, g_full, b_full = run(shard(0) + shard(1), False)
         out = out[:4] + ((l_full, g_full.numpy(), {k: v.numpy() for k, v in b_full.items()}), out[5])
     import pickle
 
@@ -235,27 +260,68 @@ def _sync_bn_worker(rank, world, port, q, train_encoder):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("train_encoder", [False, True])
-def test_sync_bn_two_ranks_equal_one_rank_on_the_whole_batch(train_encoder):
-    """SYNC_BN: True (bin/main.py:449-450).  Two ranks, three proteins each, statistics synchronised in the forward and
-    the backward of every BatchNorm (encoder, W_p, W_l, output MLP incl. the closed-form first pair layer) must reproduce
-    ONE rank running the six proteins: the mean of the two losses is the whole-batch loss, the AVERAGED gradients equal the
-    whole-batch gradients, and the BatchNorm running statistics agree - except W_l's running variances, whose label
-    rows are replicated on every rank: SyncBatchNorm counts them world times, which only changes the unbiased-variance
-    factor from N/(N-1) to 2N/(2N-1)."""
+def _run_sync_bn(train_encoder, mode):
     import pickle
 
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, q, train_encoder)) for r in range(world)]
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, q, train_encoder, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((pickle.loads(q.get(timeout=300)) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+def test_sync_bn_ragged_padding_uses_the_summed_row_count():
+    """SYNC_BN with a different padded length on every rank (each collator pads to its own batch maximum,
+    collators.py:40): rank 0 holds lens [50, 50, 44] padded to 50, rank 1 lens [3, 21, 17] padded to 21.  The BatchNorm row
+    count of the encoder layers is then 150 on one rank and 63 on the other; the global statistics are the summed column
+    sums over the SUMMED count (torch.nn.SyncBatchNorm gathers the counts), not over local_count * world.  Checked: both
+    ranks end with bit-identical BatchNorm buffers, and the first encoder BatchNorm's running statistics equal the
+    oracle's convolution outputs of BOTH shards pooled over 213 rows."""
+    from oracle import protnote_oracle as O
+
+    (_, _, _, b0, _, _), (_, _, _, b1, _, _) = _run_sync_bn(False, "ragged_L")
+    for k in b0:
+        np.testing.assert_array_equal(b0[k], b1[k], err_msg=k)
+    g = np.load(os.path.join(GOLDEN, "protnote_small_concatenation.npz"))
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    s1 = s2 = 0.0
+    n = 0
+    for rows in ([0, 3, 5], [1, 2, 4]):
+        lmax = int(lens[rows].max())
+        f = O.masked_conv1d(x[rows][:, :, :lmax], lens[rows], sd["sequence_encoder.conv1.weight"],
+                            sd["sequence_encoder.conv1.bias"], 1).double()
+        s1 = s1 + f.sum(dim=(0, 2))
+        s2 = s2 + (f * f).sum(dim=(0, 2))
+        n += f.shape[0] * f.shape[2]
+    assert n == 3 * 50 + 3 * 21
+    mean = s1 / n
+    var_unb = (s2 / n - mean * mean) * n / (n - 1)
+    key, mom = "sequence_encoder.resnet_blocks.0.bn_activation_1.0.", 0.01
+    np.testing.assert_allclose(b0[key + "running_mean"], (1 - mom) * sd[key + "running_mean"].numpy() + mom * mean.numpy(),
+                               rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b0[key + "running_var"], (1 - mom) * sd[key + "running_var"].numpy() + mom * var_unb.numpy(),
+                               rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("train_encoder,mode", [(False, "even"), (True, "even"), (True, "uneven_B")])
+def test_sync_bn_two_ranks_equal_one_rank_on_the_whole_batch(train_encoder, mode):
+    """SYNC_BN: True (bin/main.py:449-450).  Two ranks, three proteins each, statistics synchronised in the forward and
+    the backward of every BatchNorm (encoder, W_p, W_l, output MLP incl. the closed-form first pair layer) must reproduce
+    ONE rank running the six proteins (mode "uneven_B": four proteins on one rank and two on the other, each rank's loss
+    weighted by its share - the BatchNorm row counts then differ per rank and must be summed, not multiplied by the world
+    size): the mean of the two (weighted) losses is the whole-batch loss, the AVERAGED gradients equal the
+    whole-batch gradients, and the BatchNorm running statistics agree - except W_l's running variances, whose label
+    rows are replicated on every rank: SyncBatchNorm counts them world times, which only changes the unbiased-variance
+    factor from N/(N-1) to 2N/(2N-1)."""
+    res = _run_sync_bn(train_encoder, mode)
     (_, l0, g0, b0, full, g_ctl), (_, l1, g1, b1, _, _) = res
     l_full, g_full, b_full = full
     np.testing.assert_allclose(0.5 * (l0 + l1), l_full, rtol=2e-6)

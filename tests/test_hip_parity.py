@@ -390,6 +390,14 @@ def test_full_size_eval_properties():
         sub, _ = model(sequence_onehots=x[rows].contiguous(), sequence_lengths=lens[rows],
                        label_embeddings=lab[cols].contiguous())
         assert (sub - full[rows][:, cols]).abs().max().item() < 2e-5
+        # ... and against the REFERENCE ALGORITHM: eval logits are pair-local (ProtNote.py:270-309), so the CPU oracle on
+        # these 8 proteins x 500 labels (naive joint tensor, explicit padding masks) pins the same entries of the
+        # full-size grid - the 256-protein batch, 63 label chunks and every tile position they sit in
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref = O.protnote_forward(sd, x[rows].cpu(), lens[rows].cpu(), lab[cols].cpu(), fusion="concatenation")
+        assert float(ref.std()) > 0.1
+        assert (full[rows][:, cols].cpu() - ref).abs().max().item() < 5e-4
+        assert (sub.cpu() - ref).abs().max().item() < 5e-4
         model.inference_descriptions_per_label = 2
         dup = lab[cols].repeat_interleave(2, dim=0).contiguous()
         ens, _ = model(sequence_onehots=x[rows].contiguous(), sequence_lengths=lens[rows], label_embeddings=dup)

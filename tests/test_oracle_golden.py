@@ -105,6 +105,35 @@ def _check_train(g, fusion, loss):
             np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
 
 
+@pytest.mark.parametrize("name,fusion", [("protnote_small_concatenation.npz", "concatenation"),
+                                         ("protnote_small_concatenation_diff.npz", "concatenation_diff"),
+                                         ("protnote_small_concatenation_prod.npz", "concatenation_prod"),
+                                         ("protnote_small_concatenation_nobn.npz", "concatenation")])
+def test_chunked_train_forward_matches_reference_golden(golden_dir, name, fusion):
+    """O.train_forward_chunked (the label-chunked, multi-pass form of the train-mode forward that the GPU suite uses
+    as the independent reference at BASELINE configs[2] size) reproduces the REFERENCE's own train-mode logits and
+    BatchNorm running statistics on the golden inputs - ragged chunks of 3 labels."""
+    g = _load(golden_dir, name)
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
+    u = torch.from_numpy(g["train/noise_u"])
+    L_f = O.noised_label_embeddings(lab, float(g["head_cfg_label_embedding_noising_alpha"]), u)
+    with torch.no_grad():
+        P_f = O.proteinfer_get_embeddings(sd, x, lens, True, 3, "sequence_encoder.")
+        logits = O.train_forward_chunked(sd, P_f, L_f, fusion=fusion, label_chunk=3)
+    np.testing.assert_allclose(logits.numpy(), g["train_BCE/logits"], atol=1e-4, rtol=1e-5)
+    l = O.bce_loss(logits, torch.from_numpy(g["multihots"]).float())
+    np.testing.assert_allclose(float(l), float(g["train_BCE/loss"]), rtol=1e-5)
+    n = 0
+    for k in g.files:
+        if k.startswith("train_BCE/sd_after/") and k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            key = k[len("train_BCE/sd_after/"):]
+            np.testing.assert_allclose(sd[key].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=key)
+            n += 1
+    assert n > 0
+
+
 def test_losses_and_metrics(golden_dir):
     g = _load(golden_dir, "losses_metrics.npz")
     logits = torch.from_numpy(g["logits"])

@@ -91,6 +91,10 @@ def main(out_dir, tag):
     res["bytes_per_launch"] = total_bytes / total_launch if total_launch else None
     res["bytes_per_launch_definition"] = ("mean over the full-pair-grid f32 GEMM launches (dispatches moving >= 100 GB) of "
                                           "2 * FETCH_SIZE + WRITE_SIZE; algorithmic bytes of such a launch: 202 GB")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from protnote_amd.build import csrc_hash
+
+    res["csrc_hash"] = csrc_hash()  # bench.py marks `traffic_stale` when the kernels have changed since
     path = os.path.join(out_dir, f"{tag}_hbm_traffic.json")
     json.dump(res, open(path, "w"), indent=1)
     print(path, res["bytes_per_launch"])
