@@ -20,11 +20,6 @@
 #pragma once
 #include "gemm_engine.hpp"
 
-#ifndef PN_DMA_SPLIT
-#define PN_DMA_SPLIT 3  // 0: all DMA / loads of the next slab at the slab top; 1: the weight tile after the first k-step;
-                        // 3 (all-DMA kernels; others take 1): half of it after the first, half after the second k-step
-#endif
-
 namespace pn {
 
 // one LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS[lds_base + 16 l]
@@ -112,18 +107,15 @@ __device__ __forceinline__ void lds_write4(unsigned addr, float4 v) {
 //     immediate offsets of precomputed per-lane byte addresses (LDS: A0 | A1 | B0 | B1, 32 KiB each);
 //   * the BatchNorm affine of the generated operand uses packed f32 FMAs (v_pk_fma_f32: two lanes' worth per issue).
 // all-DMA loop 18 -> 0, relu(s*z+t) loop 68 -> ~25, pair-sum loop 82 -> ~25 vector instructions per slab and wave.
-// PERSIST (A_PLAIN, an epilogue that does not use the LDS, M % 256 == 0, an even number of slabs): one workgroup per CU
-// walks the virtual block ids b, b + gridDim, b + 2 gridDim, ... (same XCD, same slot as the one-tile-per-workgroup launch)
-// and the last slab of a tile stages slab 0 of the NEXT tile instead of re-staging itself - the pipeline runs straight
-// through the tile boundary: no workgroup launch, no exposed first-slab latency between tiles (7.9 us per 660 us tile).
-template <int AK, int EK, bool DROP = false, bool PERSIST = false>
+// (Measured and dropped, DESIGN.md 4.0: persistent workgroups that pipeline through the tile boundary - 149.8 -> 147.3
+// TFLOP/s, loads and stores share the in-order vmcnt; issuing all of a slab's DMA at its top, or the weight tile after the
+// second k-step only.)
+template <int AK, int EK, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p) {
-  static_assert(!PERSIST || (AK == A_PLAIN && (EK == E_STORE || EK == E_ROWDOT) && !DROP), "persistent variant: plain operands");
   static_assert(!DROP || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "dropout applies to the hidden activations");
   constexpr int WAVES_M = 4, WAVES_N = 2, WM = 2, WN = 4, BK = 32;
   constexpr int BM = 256, BN = 256;
   constexpr bool A_DMA = (AK == A_PLAIN);
-  constexpr int SPLIT = A_DMA ? PN_DMA_SPLIT : (PN_DMA_SPLIT >= 3 ? 1 : PN_DMA_SPLIT);
   static_assert(AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU, "operand kind not built for the DMA kernel");
   constexpr int TILE = BM * BK;             // floats per operand buffer (32 KiB)
   constexpr unsigned TILEB = TILE * 4u;     // LDS bytes: A buffer c at c * TILEB, B buffer c at (2 + c) * TILEB
@@ -137,10 +129,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   const int wn = wave % WAVES_N;
 
   int tile_m, tile_n;
-  int vb = blockIdx.x;  // virtual block id of the current tile
-  if (!tile_coords<BM, BN>(p, tile_m, tile_n, vb)) return;  // (padding ids come last: nothing follows them)
-  int row0 = tile_m * BM;
-  int col0 = tile_n * BN;
+  if (!tile_coords<BM, BN>(p, tile_m, tile_n)) return;
+  const int row0 = tile_m * BM;
+  const int col0 = tile_n * BN;
   const int nslab = p.Kseg / BK;
 
   // ---- DMA sources: wave w, instruction q covers tile rows 8 (4 w + q) .. + 7; lane l: row + l / 8, LDS granule
@@ -148,10 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   const unsigned lds0 = lds_addr(smem);
   const float* w_tile = p.W + (long)col0 * p.ldw;
   const float* a_tile = p.A + (long)row0 * p.lda;
-  const float* w_next = w_tile;  // PERSIST: the tile after this one (slab 0 of it is staged by this tile's last slab)
-  const float* a_next = a_tile;
-  bool has_next = false;  // (A_PAIRSUM_RELU addresses its two tables from their origins)
-  unsigned boff[4], aoff_dma[4];
+  unsigned boff[4], aoff_dma[4];  // (A_PAIRSUM_RELU addresses its two tables from their origins)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = 8 * (4 * wave + q) + (lane >> 3);
@@ -161,21 +149,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     if (ra_ > p.M - 1) ra_ = p.M - 1;  // clamp: duplicate rows are discarded by the epilogue
     aoff_dma[q] = (unsigned)((long)(ra_ - row0) * p.lda + 4 * g) * 4u;
   }
-  auto issue_b = [&](int s, auto buf_c, const float* over = nullptr, int q0 = 0, int q1 = 4) {
+  auto issue_b = [&](int s, auto buf_c, int q0 = 0, int q1 = 4) {
     constexpr int BUF = decltype(buf_c)::value;
-    const float* src = over ? over : w_tile + s * BK;
+    const float* src = w_tile + s * BK;
     const unsigned base = lds0 + (2 + BUF) * TILEB + (unsigned)wave * 4096u;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (q >= q0 && q < q1) glds16s(src, boff[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
   };
-  auto issue_a = [&](int s, auto buf_c, const float* over = nullptr, int q0 = 0, int q1 = 4) {
+  auto issue_a = [&](int s, auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
-    const float* src = over ? over : a_tile + s * BK;
+    const float* src = a_tile + s * BK;
     const unsigned base = lds0 + BUF * TILEB + (unsigned)wave * 4096u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q >= q0 && q < q1) glds16s(src, aoff_dma[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
+    for (int q = 0; q < 4; ++q) glds16s(src, aoff_dma[q], __builtin_amdgcn_readfirstlane(base + q * 1024u));
   };
 
   // ---- register path of a generated A operand: thread = (row r_in + 64 q, granule kv), 4 rows per thread
@@ -228,8 +215,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
   auto pin_a = [&](auto vm_c) {
     constexpr int PIN_VMCNT = decltype(vm_c)::value;
     static_assert(NQA == 4, "operand list below");
-    // (PN_DMA_SPLIT == 1: the four W-tile DMAs issued after the first k-step are YOUNGER than the register loads - the
-    //  counter is in order, "at most 4 outstanding" is the register operand complete with the DMA still in flight)
+    // (the four W-tile DMAs issued after the first k-step are YOUNGER than the register loads - the counter is in order,
+    //  "at most 4 outstanding" is the register operand complete with the DMA still in flight)
     if constexpr (AK == A_PAIRSUM_RELU) wait_vm8<PIN_VMCNT>(ra[0], ra[1], ra[2], ra[3], ra2[0], ra2[1], ra2[2], ra2[3]);
     else wait_vm6<PIN_VMCNT>(ra[0], ra[1], ra[2], ra[3], rsc, rsh);
   };
@@ -340,40 +327,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     // first, the L2-resident weight tile after the first k-step - in the all-DMA kernels in two halves, after the first and
     // the second (148.5 -> 150.0 -> 150.5 TFLOP/s on the probe GEMM).  (Before the address work this spreading cost 4 %: the
     // per-instruction 64-bit vector adds landed between the MFMAs.)
-    // (PERSIST: the slab after a tile's last one is slab 0 of the workgroup's next tile)
-    const bool roll = PERSIST && has_next && s + 1 >= nslab;
-    const float* a_over = roll ? a_next : nullptr;
-    const float* w_over = roll ? w_next : nullptr;
-    if constexpr (A_DMA) issue_a(nxt, N{}, a_over, 0, SPLIT == 4 ? 2 : 4);  // the other buffer was last read in slab s-1
+    if constexpr (A_DMA) issue_a(nxt, N{});  // the other buffer was last read in slab s-1
     else fetch_a(nxt);
-    if (SPLIT == 0) issue_b(nxt, N{}, w_over);
     __builtin_amdgcn_sched_barrier(0);
     read_frag(C{}, I1{}, ga, gb);
     mma(fa, fb);
-    if (SPLIT == 1) {
-      __builtin_amdgcn_sched_barrier(0);
-      issue_b(nxt, N{}, w_over);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (SPLIT == 3) {
-      __builtin_amdgcn_sched_barrier(0);
-      issue_b(nxt, N{}, w_over, 0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (SPLIT == 4) {
-      __builtin_amdgcn_sched_barrier(0);
-      issue_a(nxt, N{}, a_over, 2, 4);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (A_DMA) issue_b(nxt, N{}, 0, 2);  // all-DMA loop: half of the weight tile here, half after k-step 1
+    else issue_b(nxt, N{});
+    __builtin_amdgcn_sched_barrier(0);
     read_frag(C{}, I2{}, fa, fb);
     mma(ga, gb);
     __builtin_amdgcn_sched_barrier(0);
-    if (SPLIT == 2 || SPLIT == 4) {
-      issue_b(nxt, N{}, w_over);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (SPLIT == 3) {
-      issue_b(nxt, N{}, w_over, 2, 4);
+    if constexpr (A_DMA) {
+      issue_b(nxt, N{}, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
     }
     read_frag(C{}, I3{}, ga, gb);
@@ -383,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
               // first 16 of k-step 2's 32 MFMAs (three quarters of a slab to land)
       mma_rows(fa, fb, I0{});
       __builtin_amdgcn_sched_barrier(0);
-      pin_a(integral_constant<int, (SPLIT == 1 ? 4 : 0)>{});
+      pin_a(integral_constant<int, 4>{});
       mma_rows(fa, fb, I1{});
       commit_a(N{});
     }
@@ -397,49 +364,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_dma_kernel(const GemmParams p)
     mma(ga, gb);
   };
   read_frag(I0{}, I0{}, fa, fb);
-  if constexpr (!PERSIST) {
-    int s = 0;
-    for (; s + 1 < nslab; s += 2) {
-      slab(s, I0{});
-      slab(s + 1, I1{});
-    }
-    if (s < nslab) slab(s, I0{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
-  } else {
-    // nslab is even (launcher): a tile's last slab sits in buffer 1 and stages the next tile's slab 0 into buffer 0; after
-    // its barrier the fragments of that slab's first k-step are read (fa, fb) while the tile's last MFMAs run - the next
-    // tile's loop continues from there.  The epilogue (E_STORE without statistics, E_ROWDOT) does not touch the LDS.
-    for (;;) {
-      int ntm_ = 0, ntn_ = 0;
-      const int nb = vb + (int)gridDim.x;
-      has_next = nb < p.nvb && tile_coords<BM, BN>(p, ntm_, ntn_, nb);
-      if (has_next) {
-        a_next = p.A + (long)ntm_ * BM * p.lda;
-        w_next = p.W + (long)ntn_ * BN * p.ldw;
-      }
-      for (int s = 0; s < nslab; s += 2) {
-        slab(s, I0{});
-        slab(s + 1, I1{});
-      }
-      gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
-      if (!has_next) break;
-      vb = nb;
-      tile_m = ntm_;
-      tile_n = ntn_;
-      row0 = tile_m * BM;
-      col0 = tile_n * BN;
-      a_tile = a_next;
-      w_tile = w_next;
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    }
+  int s = 0;
+  for (; s + 1 < nslab; s += 2) {
+    slab(s, I0{});
+    slab(s + 1, I1{});
   }
+  if (s < nslab) slab(s, I0{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
 }
 
 constexpr int GEMM_DMA_LDS_BYTES = 2 * 2 * 256 * 32 * (int)sizeof(float);  // 128 KiB

@@ -93,7 +93,6 @@ struct GemmParams {
   uint16_t* wsplit;      // optional scratch, 2 * N * Kseg bf16: bf16x3 mode pre-splits W into hi / lo planes there and
   const uint16_t* w_hi;  // stages them by LDS-DMA (set by the launcher from wsplit)
   const uint16_t* w_lo;
-  int nvb;             // persistent kernels: number of virtual blocks (the grid a one-tile-per-workgroup launch would have)
   int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
 };
 
@@ -138,8 +137,8 @@ __device__ __forceinline__ void pin4(float4& v) {
 // on its 32 CUs) at a time: inside a block each A row-panel is shared by bc and each W column-panel by br
 // workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
 template <int BM, int BN>
-__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n, int bid = -1) {
-  if (bid < 0) bid = blockIdx.x;  // (persistent kernels pass the virtual block id of the tile they are about to compute)
+__device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n) {
+  const int bid = blockIdx.x;
   const int ntn = (p.Nstore + BN - 1) / BN;
   if (PN_XCD && p.xcd_bc > 0) {
     const int ntm = (p.M + BM - 1) / BM;

@@ -12,7 +12,6 @@
 #include "gemm_dma.hpp"
 #include "gemm_conv_dma.hpp"
 #include "gemm_tn_fast.hpp"
-#include "gemm_b3_fast.hpp"
 #include "train_kernels.hpp"
 
 using namespace pn;
@@ -329,15 +328,10 @@ extern "C" int pn_set_math_mode(int mode) {
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
 
-// bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; PN_B3_DMA=0 keeps the register path
-static int g_b3_dma = -1;
-static bool use_b3_dma() {
-  if (g_b3_dma < 0) {
-    const char* e = getenv("PN_B3_DMA");
-    g_b3_dma = (e == nullptr || atoi(e) != 0) ? 1 : 0;
-  }
-  return g_b3_dma == 1;
-}
+// bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; pn_set_b3_dma(0) keeps the register
+// path (the bit-identity test compares the two)
+static int g_b3_dma = 1;
+static bool use_b3_dma() { return g_b3_dma == 1; }
 extern "C" int pn_set_b3_dma(int on) {
   g_b3_dma = on ? 1 : 0;
   return 0;
@@ -350,23 +344,14 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
     if (p.wsplit != nullptr && use_b3_dma() && p.Nstore == p.N)
       return launch_gemm_bf16x3<AK, EK, WAVES_N, WN, GEN, true>(p, st);
   }
-  // PN_B3_FAST=1: BDMA pair-grid launches take the experimental low-VALU kernel (gemm_b3_fast.hpp).  Bit-identical, 1.3-1.8
-  // instead of 3.5 VALU per MFMA - but measured SLOWER so far (matrix pipe 0.50 busy at 2.0-2.1 GHz against 0.62-0.70 at
-  // 1.85 GHz: every k-step's 12 fragment reads are waited for in full before its first MFMA), so it is off by default
-  static const bool b3_fast = [] { const char* e = getenv("PN_B3_FAST"); return e != nullptr && atoi(e) != 0; }();
-  const bool fast = BDMA && b3_fast && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0 &&
-                    (AK != A_PAIRSUM_RELU || ((long)(p.M / p.pairB + 1) * p.lda2 * 4 < (1L << 32) && p.lda2 % 4 == 0));
-  void (*kern)(const GemmParams) = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
-  if constexpr (BDMA) {
-    if (fast) kern = gemm_nt_b3_fast_kernel<AK, EK>;
-  }
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
   constexpr int LDS_BYTES = BDMA ? 2 * (256 * 36 + 2 * 256 * 16) * (int)sizeof(float) : Cfg::LDS_BYTES;
-  static bool attr_done[2][64] = {{false}};
+  static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
-  if (dev < 64 && !attr_done[fast ? 1 : 0][dev]) {
+  if (dev < 64 && !attr_done[dev]) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_done[fast ? 1 : 0][dev] = true;
+    attr_done[dev] = true;
   }
   if (p.M <= 0 || p.Nstore <= 0) return 0;
   if (p.Kseg % 4 != 0) return fail("gemm: K segment %d not a multiple of 4", p.Kseg);
@@ -399,54 +384,22 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   return finish_col_stats(p, tm, st);
 }
 
-// f32 pair-grid GEMMs with LDS-DMA operand staging (gemm_dma.hpp); PN_F32_DMA=0 selects the register-staged engine
-static int g_f32_dma = -1;
-static bool use_f32_dma() {
-  if (g_f32_dma < 0) {
-    const char* e = getenv("PN_F32_DMA");
-    g_f32_dma = (e == nullptr || atoi(e) != 0) ? 1 : 0;
-  }
-  return g_f32_dma == 1;
-}
+// f32 pair-grid GEMMs with LDS-DMA operand staging (gemm_dma.hpp); pn_set_f32_dma(0) selects the register-staged engine
+// (the bit-identity tests compare the two)
+static int g_f32_dma = 1;
+static bool use_f32_dma() { return g_f32_dma == 1; }
 
 extern "C" int pn_set_f32_dma(int on) {
   g_f32_dma = on ? 1 : 0;
   return 0;
 }
 
-// smallest M for which an NT GEMM takes the 256-tile LDS-DMA kernel (PN_DMA_MIN_ROWS; A/B switch for measurements)
-static int g_dma_min_rows = [] {
-  const char* e = getenv("PN_DMA_MIN_ROWS");
-  return e ? atoi(e) : 16384;
-}();
+// smallest M for which an NT GEMM takes the 256-tile LDS-DMA kernel
+static const int g_dma_min_rows = 16384;
 
-// PN_PERSIST=1: persistent workgroups for the plain-operand NT launches (gemm_nt_dma_kernel<.., PERSIST>).  Measured SLOWER
-// (nt:plain 149.8 -> 147.3 TFLOP/s) and therefore off: stores and loads share vmcnt on this chip and the counter is in
-// order, so the wait that publishes the next tile's second slab also waits for the 256 KB of epilogue stores every CU has
-// just issued at the same moment (a 64 MB burst, ~10 us to drain) - a fresh workgroup starts with fresh counters and
-// overlaps that drain with its first slabs, which is worth more than the 7.9 us of launch + first-slab latency it costs.
-static bool persist_on() {
-  static const int on = [] { const char* e = getenv("PN_PERSIST"); return e ? atoi(e) : 0; }();
-  return on != 0;
-}
-static int cu_count() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return v;
-  }();
-  return n;
-}
-
-template <int AK, int EK, bool DROP = false, bool PERSIST = false>
+template <int AK, int EK, bool DROP = false>
 static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
-  if constexpr (!PERSIST && !DROP && AK == A_PLAIN && (EK == E_STORE || EK == E_ROWDOT)) {
-    // persistent variant: the epilogue must not use the LDS (no column statistics), whole row tiles, even slab count
-    if (persist_on() && p.col_part == nullptr && p.col_sum == nullptr && p.M % 256 == 0 && (p.Kseg / 32) % 2 == 0 &&
-        cu_count() > 0 && cu_count() % 8 == 0 && (long)(p.M / 256) * (p.N / 256) >= 4L * cu_count())
-      return launch_gemm_dma<AK, EK, DROP, true>(p, st);
-  }
-  auto kern = gemm_nt_dma_kernel<AK, EK, DROP, PERSIST>;
+  auto kern = gemm_nt_dma_kernel<AK, EK, DROP>;
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -466,8 +419,6 @@ static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
     grid = ((nblk_ + 7) / 8) * 8 * 32;
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
-  pp.nvb = (int)grid;
-  if (PERSIST) grid = cu_count();  // one workgroup per CU (128 KiB of LDS each), ids keep their XCD: 256 % 8 == 0
   {
     ProfScope ps(AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), GEMM_DMA_LDS_BYTES, st, pp);
@@ -1304,16 +1255,6 @@ static int tn_pick_split(long R, int M, int N, size_t part_cap_floats, int tile,
   return (int)ns;
 }
 
-// PN_TN_FAST=0 keeps the generic big TN kernel (A/B measurements)
-static bool tn_fast_on() {
-  static const int on = [] { const char* e = getenv("PN_TN_FAST"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
-// PN_TN_TASKS=0 restores the per-split XCD regions (A/B measurements: tools/pmc_tn_tasks.sh)
-static bool tn_task_map() {
-  static const int on = [] { const char* e = getenv("PN_TN_TASKS"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
 
 template <int TA, int TB, bool BIG, bool ADMA = false, bool DROP = false>
 static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
@@ -1343,7 +1284,7 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
   const unsigned tiles = (unsigned)(((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE));
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
-  if (BIG && tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {  // 12 x 12 tiles: 32-workgroup region tasks
+  if (BIG && p.M == 3072 && p.N == 3072 && ns >= 2) {  // 12 x 12 tiles: 32-workgroup region tasks
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
   }
@@ -1390,14 +1331,13 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
   p.task_sync = nullptr;
-  if (tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {
+  if (p.M == 3072 && p.N == 3072 && ns >= 2) {
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
     // arrival counters of the region tasks (gemm_tn_fast.hpp): 16 KB per device, allocated once by the library itself -
     // the one buffer that is not part of a caller-provided workspace (it carries no result, only pacing)
     static int* ctr[64] = {nullptr};
-    static const bool sync_on = [] { const char* e = getenv("PN_TN_SYNC"); return e == nullptr || atoi(e) != 0; }();
-    if (SYNC && sync_on && dev < 64) {
+    if (SYNC && dev < 64) {
       if (ctr[dev] == nullptr && hipMalloc((void**)&ctr[dev], 4096 * sizeof(int)) != hipSuccess) ctr[dev] = nullptr;
       if (ctr[dev] != nullptr && ns * 4 * 4 <= 4096) {
         HIP_OK(hipMemsetAsync(ctr[dev], 0, (size_t)ns * 4 * 4 * sizeof(int), st));
@@ -1445,7 +1385,7 @@ static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_
   const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
-  if (tn_task_map() && p.M == 3072 && p.N == 3072 && ns >= 2) {
+  if (p.M == 3072 && p.N == 3072 && ns >= 2) {
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
   }
@@ -1488,7 +1428,7 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
         // the low-VALU kernel: 32-bit per-lane offsets, and for the pair sum a slab inside one label
         const bool fits = (long)8 * p.ldb * 4 < (1L << 31) && p.ldb % 4 == 0 && (TB != TB_AFFINE_RELU || p.b_s != nullptr);
         const bool pair_ok = TB != TB_PAIRSUM_RELU || (p.pairB % 32 == 0 && p.ldb2 % 4 == 0);
-        if (tn_fast_on() && fits && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
+        if (fits && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
       }
       return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
     }
@@ -1664,7 +1604,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
 
 // PN_MLP_MAT=0 / pn_set_mlp_materialize(0): the row-MLP backward regenerates dY in the operand loaders for every row count
 // (the path the small-size oracle tests pin) - an A/B switch for tests and measurements
-static int g_mlp_mat = [] { const char* e = getenv("PN_MLP_MAT"); return e ? atoi(e) : 1; }();
+static int g_mlp_mat = 1;
 extern "C" int pn_set_mlp_materialize(int on) {
   g_mlp_mat = on ? 1 : 0;
   return 0;

@@ -232,6 +232,9 @@ class ProtNote(nn.Module):
         unchanged; train()/eval() switches clear it.  A fresh tensor per call simply recomputes, as the reference does."""
         cache = self.__dict__.setdefault("_pn_le_cache", {})
         t = label_embeddings
+        if int(self.label_projection_cache_size) <= 0:  # cache off: recompute per call, like the reference
+            cache.clear()
+            return self._project_eval(self.W_l, t.detach().float().contiguous())
         key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
         state = (t._version, self._w_l_state_key())
         hit = cache.get(key)

@@ -49,9 +49,12 @@ def train_step(model, loss_fn, optimizer, batch, *, world_size=1, counts=None, t
         broadcast_buffers(model)
     if counts is not None and hasattr(loss_fn, "metric_counts"):
         loss_fn.metric_counts, loss_fn.decision_threshold = counts, threshold  # counted inside the loss pass
+    # tokenized_labels: LABEL_EMBEDDING_POOLING_METHOD 'all' reads its attention mask (ProtNoteTrainer.py:712-729 passes the
+    # whole batch dict to the model)
     logits, _ = model(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
                       label_embeddings=batch["label_embeddings"],
-                      label_token_counts=batch.get("label_token_counts"))
+                      label_token_counts=batch.get("label_token_counts"),
+                      tokenized_labels=batch.get("tokenized_labels"))
     loss = loss_fn(logits, batch["label_multihots"])
     if gradient_accumulation_steps > 1:
         loss = loss / gradient_accumulation_steps
@@ -140,7 +143,8 @@ class Trainer:
             y = batch["label_multihots"]
             logits, _ = self.model(sequence_onehots=batch["sequence_onehots"],
                                    sequence_lengths=batch["sequence_lengths"],
-                                   label_embeddings=batch["label_embeddings"])
+                                   label_embeddings=batch["label_embeddings"],
+                                   tokenized_labels=batch.get("tokenized_labels"))
             if represented_label_mask is not None:
                 if keep is None:
                     keep = torch.as_tensor(represented_label_mask, dtype=torch.bool, device=y.device).nonzero().flatten()
@@ -158,6 +162,8 @@ class Trainer:
                         ap = DeviceBinnedAUPRC(y.shape[1], y.device, threshold=map_thresholds)
                     else:
                         total = len(loader.dataset) if hasattr(loader, "dataset") else 0
+                        if self.world_size > 1:  # a rank only scores its 1/W shard of the set (the accumulator can grow)
+                            total = -(-total // self.world_size)
                         ap = DeviceAveragePrecision(y.shape[1], max(total, y.shape[0]), y.device, growable=True)
                 ap.update(torch.sigmoid(logits), y)   # the reference scores probabilities (:521-523)
         out = self._metrics(counts, loss_sum, n)

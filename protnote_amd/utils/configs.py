@@ -106,12 +106,21 @@ def build_training(config: dict, model, world_size: int = 1):
     if name not in ("Adam", "AdamW"):
         raise NotImplementedError(f"OPTIMIZER={name}: the fused optimiser implements Adam and AdamW")
     params = list(trainable_parameters(model))  # heads (+ raw_attn_scorer with LABEL_EMBEDDING_POOLING_METHOD: all)
-    if p.get("TRAIN_SEQUENCE_ENCODER", False):
+    train_enc = bool(p.get("TRAIN_SEQUENCE_ENCODER", False))
+    if train_enc:
         params += list(model.sequence_encoder.trunk_parameters())
+    # requires_grad as _set_optimizer leaves it (ProtNoteTrainer.py:210-226), then the ids torch.optim.Adam would give the
+    # parameters: position in named_parameters() filtered by requires_grad (sequence_encoder - classifier included - before
+    # W_p, W_l, raw_attn_scorer, output_layer), so optimizer_state_dict of a reference checkpoint loads by id
+    for n_, q_ in model.named_parameters():
+        if n_.startswith("sequence_encoder"):
+            q_.requires_grad = train_enc
+    order = {id(q_): k for k, q_ in enumerate(q_ for _, q_ in model.named_parameters() if q_.requires_grad)}
     clip = p.get("CLIP_VALUE", 1)
     opt = FusedClipAdam(params, lr=p.get("LEARNING_RATE", 3e-4),
                         weight_decay=p.get("WEIGHT_DECAY", 0.0) if name == "AdamW" else 0.0,
-                        max_norm=None if clip is None else float(clip))
+                        max_norm=None if clip is None else float(clip),
+                        param_ids=[order[id(q_)] for q_ in params], n_param_ids=len(order))
     th = p.get("DECISION_TH", 0.5)
     trainer = Trainer(model, loss_fn, opt, world_size=world_size, threshold=0.5 if th is None else th,
                       gradient_accumulation_steps=p.get("GRADIENT_ACCUMULATION_STEPS", 1))

@@ -125,6 +125,9 @@ def sync_initial_state(model, optimizer=None, src: int = 0):
     forever (gradients are averaged, parameters are not)."""
     if not active():
         return
+    from .optim import _bump_generation
+
+    _bump_generation()  # weights change under caches of weight-derived tensors (the eval-mode L_e cache)
     if optimizer is not None and hasattr(optimizer, "flat_w"):
         for name in ("flat_w", "flat_m", "flat_v"):
             t = getattr(optimizer, name)

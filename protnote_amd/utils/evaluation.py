@@ -149,19 +149,28 @@ class DeviceAveragePrecision:
         if not micro:
             return out
         # ---- micro AP: sample sort by the upper 16 key bits (u32 keys live in int32 storage)
+        # (memory: beside the 5 B / pair accumulator this holds 4 B (hi16, transient) + 1 B (dest) + 1 B (one mask at a time)
+        #  + the 5 B / pair send buffers - not W masks and int64 temporaries)
         kf, hf = k_loc.reshape(-1), h_loc.reshape(-1)
-        hi16 = (kf.long() & 0xFFFFFFFF) >> 16
+        hi16 = torch.bitwise_and(torch.bitwise_right_shift(kf, 16), 0xFFFF)  # int32, like the keys' storage
         hist = torch.bincount(hi16, minlength=65536)
         dist.all_reduce(hist)
         top = hist.flip(0)  # descending key order: range 0 holds the best-ranked pairs
         before = torch.cumsum(top, 0) - top
         lut = torch.clamp((before * W) // torch.clamp(top.sum(), min=1), max=W - 1).flip(0)
+        lut = lut.to(torch.uint8 if W <= 255 else torch.int32)
         dest = lut[hi16]
         del hi16
-        sel = [dest == v for v in range(W)]
-        mk = torch.cat(self._exchange([kf[m] for m in sel]))
-        mh = torch.cat(self._exchange([hf[m] for m in sel]))
-        del sel, dest
+        send_k, send_h = [], []
+        for v in range(W):
+            m = dest == v
+            send_k.append(kf[m])
+            send_h.append(hf[m])
+            del m
+        del dest
+        mk = torch.cat(self._exchange(send_k))
+        mh = torch.cat(self._exchange(send_h))
+        del send_k, send_h
         tot = torch.stack([mh.sum(dtype=torch.int64), torch.tensor(mk.numel(), dtype=torch.int64, device=dev)])
         tots = [torch.empty_like(tot) for _ in range(W)]
         dist.all_gather(tots, tot)

@@ -24,10 +24,28 @@ def _bump_generation():
 
 
 class FusedClipAdam:
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
+                 param_ids=None, n_param_ids=None):
+        """`param_ids[i]` = the id parameter i carries in state_dict() / load_state_dict() and `n_param_ids` the length of
+        the id space: the position of the parameter in the list the REFERENCE builds its torch.optim.Adam from
+        (model.named_parameters() filtered by requires_grad, ProtNoteTrainer.py:199-231), which may hold parameters this
+        optimiser does not own (e.g. the ProteInfer classifier under TRAIN_SEQUENCE_ENCODER: trainable there, never
+        reached by get_embeddings, so torch keeps no state for it).  Default: position in `params`."""
+        params = list(params)
+        keep = [i for i, p in enumerate(params) if p.requires_grad]
+        self.params = [params[i] for i in keep]
         if not self.params:
             raise ValueError("no trainable parameters")
+        if param_ids is not None:
+            if len(param_ids) != len(params):
+                raise ValueError("param_ids must have one entry per parameter")
+            self.param_ids = [int(param_ids[i]) for i in keep]
+            self.n_param_ids = int(n_param_ids) if n_param_ids is not None else max(self.param_ids) + 1
+            if len(set(self.param_ids)) != len(self.param_ids) or max(self.param_ids) >= self.n_param_ids:
+                raise ValueError("param_ids must be distinct and below n_param_ids")
+        else:
+            self.param_ids = list(range(len(self.params)))
+            self.n_param_ids = len(self.params)
         dev = self.params[0].device
         L.require_hip(*self.params)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
@@ -91,19 +109,19 @@ class FusedClipAdam:
 
     # ---- checkpoint interchange with torch.optim.Adam / AdamW (reference utils/models.py:304-321,366-367) ----
     def state_dict(self):
-        """The layout torch.optim.Adam.state_dict() produces for the same parameter list (ids = position in the
-        list the optimiser was built from), so `optimizer_state_dict` of a checkpoint moves both ways between this
-        optimiser and the reference's Adam."""
+        """The layout torch.optim.Adam.state_dict() produces for the reference's parameter list (ids = `param_ids`, see
+        __init__), so `optimizer_state_dict` of a checkpoint moves both ways between this optimiser and the reference's
+        Adam."""
         state = {}
         if self.step_count > 0:
-            for i, (p, off) in enumerate(self._offsets()):
+            for i, (p, off) in zip(self.param_ids, self._offsets()):
                 n = p.numel()
                 state[i] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
                             "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-                 "fused": None, "params": list(range(len(self.params)))}
+                 "fused": None, "params": list(range(self.n_param_ids))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
@@ -113,8 +131,9 @@ class FusedClipAdam:
             self.flat_v.copy_(sd["exp_avg_sq"])
             return
         ids = [i for g in sd["param_groups"] for i in g["params"]]
-        if len(ids) != len(self.params):
-            raise ValueError(f"optimizer state has {len(ids)} parameters, this optimiser {len(self.params)}")
+        if len(ids) != self.n_param_ids:
+            raise ValueError(f"optimizer state has {len(ids)} parameters, this optimiser's id space {self.n_param_ids}")
+        _bump_generation()
         g0 = sd["param_groups"][0]
         self.lr, self.betas, self.eps = g0["lr"], tuple(g0["betas"]), g0["eps"]
         self.weight_decay = g0.get("weight_decay", 0.0)
@@ -122,7 +141,8 @@ class FusedClipAdam:
         with torch.no_grad():
             self.flat_m.zero_()
             self.flat_v.zero_()
-            for pid, (p, off) in zip(ids, self._offsets()):
+            for k, (p, off) in zip(self.param_ids, self._offsets()):
+                pid = ids[k]
                 st = sd["state"].get(pid)
                 if st is None:
                     continue

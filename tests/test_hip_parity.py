@@ -366,6 +366,71 @@ def test_save_embeddings_and_attention_pooling(golden_dir, fusion):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
 
 
+def test_label_projection_cache_and_named_tables(golden_dir):
+    """Eval-mode L_e = W_l(label table) is cached per table object and label tables are swapped by name
+    (ProtNote._label_projection_eval / set_label_table; the reference recomputes W_l(L_f) on every call,
+    ProtNote.py:192-196,270-271): logits bit-identical with and without the cache; a hit costs no W_l projection; an
+    in-place edit of the table, an optimiser step through the flat weight buffer and a train()/eval() switch each
+    invalidate it."""
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    g = _g(golden_dir, "protnote_small_concatenation.npz")
+    model, sd = make_protnote(g, DEV)
+    model.inference_descriptions_per_label = 2
+    model.eval()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    go = torch.from_numpy(g["label_embeddings"]).to(DEV)
+    ec = (go.flip(0) * 0.5 + 0.1).contiguous()
+    calls = []
+    real = model._project_eval
+    model._project_eval = lambda seq, t: (calls.append(seq is model.W_l), real(seq, t))[1]
+
+    def fwd(table):
+        with torch.no_grad():
+            return model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=table)[0]
+
+    a0 = fwd(go)
+    a1 = fwd(go)
+    assert sum(calls) == 1 and torch.equal(a0, a1)               # second call: no W_l projection
+    model.label_projection_cache_size = 0                          # cache off: the reference's behaviour
+    assert torch.equal(fwd(go), a0) and sum(calls) == 2
+    model.label_projection_cache_size = 4
+    ref = O.protnote_forward(sd, x.cpu(), lens.cpu(), go.cpu(), fusion="concatenation", descriptions_per_label=2)
+    assert (a0.cpu() - ref).abs().max().item() < 5e-4
+    # GO -> EC -> GO by name: one projection per table, then lookups only
+    model.set_label_table("GO", go)
+    model.set_label_table("EC", ec)
+    n0 = sum(calls)
+    b_go, b_ec, b_go2, b_ec2 = fwd("GO"), fwd("EC"), fwd("GO"), fwd("EC")
+    assert sum(calls) == n0 + 2 and torch.equal(b_go, a0) and torch.equal(b_go2, a0) and torch.equal(b_ec, b_ec2)
+    assert not torch.equal(b_ec, a0)
+    with pytest.raises(KeyError):
+        fwd("nope")
+    # an in-place edit of the table bumps its version counter -> recomputed
+    n0 = sum(calls)
+    ec.mul_(2.0)
+    c = fwd("EC")
+    assert sum(calls) == n0 + 1 and not torch.equal(c, b_ec)
+    assert torch.equal(c, fwd(ec.clone()))                         # a fresh tensor object: plain recompute, same logits
+    # an optimiser step rewrites W_l through the flat buffer (no tensor version changes): generation counter
+    for n_, q_ in model.named_parameters():
+        if n_.startswith("sequence_encoder"):
+            q_.requires_grad = False
+    opt = FusedClipAdam(head_parameters(model), lr=1e-2, max_norm=None)
+    before = fwd("GO")
+    opt.flat_g.fill_(1e-3)
+    opt.step()
+    n0 = sum(calls)
+    after = fwd("GO")
+    assert sum(calls) == n0 + 1 and not torch.equal(after, before)
+    # train()/eval() switches clear the cache (train-mode forwards move W_l's BatchNorm buffers in place)
+    model.train()
+    model.eval()
+    n0 = sum(calls)
+    assert torch.equal(fwd("GO"), after) and sum(calls) == n0 + 1
+
+
 def test_full_size_eval_properties():
     """BASELINE configs[1] size (B=256, L=512, N_L=32102, full-width model) through size-independent properties
     (the oracle cannot run this size): in eval mode a pair's logit depends only on that protein and that label, so

@@ -906,6 +906,52 @@ def test_optimizer_state_interchange_with_torch_adam(golden_dir):
     resumed.step()
 
 
+def test_build_training_optimizer_ids_follow_the_reference_order(golden_dir):
+    """The reference builds torch.optim.Adam from model.named_parameters() filtered by requires_grad
+    (ProtNoteTrainer.py:199-231): sequence_encoder (classifier included) before W_p, W_l, raw_attn_scorer, output_layer.
+    build_training gives the fused optimiser's state the same ids, so with LABEL_EMBEDDING_POOLING_METHOD 'all' and
+    TRAIN_SEQUENCE_ENCODER a reference `optimizer_state_dict` loads into it by id (and the other way round) although the
+    fused optimiser's own flat layout orders the tensors differently and does not own the never-trained classifier.
+    Also: the Trainer passes tokenized_labels through, so the pooling-'all' configuration trains end to end."""
+    from protnote_amd.utils.configs import build_training
+
+    g = _g(golden_dir, "protnote_small_attention.npz")
+    model, _ = make_protnote(g, DEV, train_sequence_encoder=True)
+    cfg = {"params": {"LOSS_FN": "BCE", "BCE_POS_WEIGHT": 1, "OPTIMIZER": "Adam", "LEARNING_RATE": 1e-3, "CLIP_VALUE": 1,
+                      "GRADIENT_ACCUMULATION_STEPS": 1, "DECISION_TH": 0.5, "TRAIN_SEQUENCE_ENCODER": True}}
+    loss_fn, opt, trainer = build_training(cfg, model)
+    ref_list = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    names = [n for n, _ in ref_list]
+    assert names[0].startswith("sequence_encoder.") and "sequence_encoder.output_layer.weight" in names
+    assert names.index("raw_attn_scorer.weight") < names.index("output_layer.0.weight")
+    pos = {id(p): k for k, (_, p) in enumerate(ref_list)}
+    assert opt.n_param_ids == len(ref_list) and [pos[id(p)] for p in opt.params] == opt.param_ids
+    batch = {"sequence_onehots": torch.from_numpy(g["x"]).to(DEV), "sequence_lengths": torch.from_numpy(g["lens"]).to(DEV),
+             "label_embeddings": torch.from_numpy(g["hidden"]).to(DEV),
+             "tokenized_labels": {"attention_mask": torch.from_numpy(g["attention_mask"]).to(DEV)},
+             "label_multihots": torch.from_numpy(g["multihots"]).float().to(DEV)}
+    out = trainer.train_one_epoch([batch])  # pooling 'all' through the Trainer (needs the attention mask)
+    assert np.isfinite(out["loss"]) and opt.step_count == 1
+    ev = trainer.evaluate([batch], estimate_map=True)
+    assert 0.0 <= ev["map_micro"] <= 1.0
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["params"] == list(range(len(ref_list)))
+    cls = [k for k, (n, _) in enumerate(ref_list) if n.startswith("sequence_encoder.output_layer.")]
+    assert cls and all(k not in sd["state"] for k in cls)  # torch keeps no state for parameters that never get a gradient
+    for k, (n, p) in enumerate(ref_list):
+        if k not in cls:
+            assert tuple(sd["state"][k]["exp_avg"].shape) == tuple(p.shape), n
+    # the reference's own optimiser over the same list accepts it, and its state loads back by id
+    tref = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for _, p in ref_list], lr=1e-3)
+    tref.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                          "param_groups": sd["param_groups"]})
+    back = tref.state_dict()
+    m0 = opt.flat_m.clone()
+    opt.flat_m.zero_()
+    opt.load_state_dict(back)
+    assert torch.equal(opt.flat_m, m0) and opt.step_count == 1
+
+
 @pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("fusion", ["concatenation", "concatenation_prod", "similarity"])
 def test_train_step_bit_reproducible(golden_dir, fusion, math_mode):
