@@ -255,6 +255,168 @@ def train_forward_chunked(sd: SD, P_f: Tensor, L_f: Tensor, *, fusion: str = "co
     return logits
 
 
+def train_grads_chunked(sd: SD, P_f: Tensor, L_f: Tensor, multihots: Tensor, *, fusion: str = "concatenation",
+                        label_chunk: int = 512, loss: str = "BCE", momentum: float = 0.1, eps: float = 1e-5,
+                        **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
+    """Forward + backward of the train step's heads (ProtNoteTrainer.py:728-738 over ProtNote.py:270-309) for pair grids
+    too large to materialise - the backward twin of train_forward_chunked, same naive formulation in label chunks.
+    BatchNorm1d's backward over ALL B*N_L rows, dz = gamma/sigma (du - mean(du) - xhat mean(du xhat)), needs the two
+    global means of a layer before any row of its dz exists, and du of a layer depends on dz of the layer above: one pass
+    per hidden layer, top down, each recomputing the chunk's forward chain and the backward chain above it; a last pass
+    accumulates the weight gradients (float64 accumulators) and the gradients wrt P_e / L_e, which then flow through W_p /
+    W_l by plain autograd.  Plain torch, device-agnostic: pinned on CPU to train_step's autograd (and through it to the
+    reference goldens); on the GPU it is the independent reference of the full-size HIP train step.
+    Returns (logits [B, N_L], loss, {parameter name: gradient}) for every trainable head parameter; `sd` buffers advance."""
+    head = [k for k in trainable_names(sd) if k.startswith(("W_p.", "W_l."))]
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in head}
+    work = dict(sd)
+    work.update(leaves)
+    P_e_g = mlp_rows(work, "W_p.", P_f, True)
+    L_e_g = mlp_rows(work, "W_l.", L_f, True)
+    P_e, L_e = P_e_g.detach(), L_e_g.detach()
+    b, n, d = P_e.shape[0], L_e.shape[0], P_e.shape[1]
+    rows = b * n
+    dev, dt = P_e.device, P_e.dtype
+    lin = _linear_indices(sd, "output_layer.")
+    hidden, out_i = lin[:-1], lin[-1]
+    nl = len(hidden)
+    W = [sd[f"output_layer.{i}.weight"] for i in hidden]
+    bias = [sd.get(f"output_layer.{i}.bias") for i in hidden]
+    has_bn = [f"output_layer.{i + 1}.running_mean" in sd for i in hidden]
+    w_out, b_out = sd[f"output_layer.{out_i}.weight"], sd.get(f"output_layer.{out_i}.bias")
+    fstat = [None] * nl  # (mean, invstd, gamma, beta) per BatchNorm
+
+    def forward_chunk(j0, j1, upto, keep=False):
+        """-> (x, zs, us): joint rows, pre-BatchNorm z_m and pre-ReLU u_m of hidden layers < upto (kept when asked),
+        and the last tensor computed (z of layer `upto`, or the logits)."""
+        x = joint_embeddings(P_e, L_e[j0:j1], fusion)
+        zs, us = [], []
+        h = x
+        for m in range(min(upto, nl)):
+            z = F.linear(h, W[m], bias[m])
+            if has_bn[m]:
+                mean, invstd, gamma, beta = fstat[m]
+                u = (z - mean) * (invstd * gamma) + beta
+            else:
+                u = z
+            if keep:
+                zs.append(z)
+                us.append(u)
+            h = F.relu(u)
+        if upto < nl:
+            last = F.linear(h, W[upto], bias[upto])
+        else:
+            last = F.linear(h, w_out, b_out)
+        return x, zs, us, h, last
+
+    # ---- forward statistics, layer by layer (as train_forward_chunked)
+    for m in range(nl):
+        if not has_bn[m]:
+            continue
+        pre = f"output_layer.{hidden[m] + 1}."
+        s1 = torch.zeros(W[m].shape[0], dtype=torch.float64, device=dev)
+        s2 = torch.zeros_like(s1)
+        for j0 in range(0, n, label_chunk):
+            z = forward_chunk(j0, min(n, j0 + label_chunk), m)[4].double()
+            s1 += z.sum(0)
+            s2 += (z * z).sum(0)
+        mean = s1 / rows
+        var = (s2 / rows - mean * mean).clamp_min(0.0)
+        fstat[m] = (mean.to(dt), (1.0 / torch.sqrt(var + eps)).to(dt), sd[pre + "weight"], sd[pre + "bias"])
+        sd[pre + "running_mean"].mul_(1 - momentum).add_(mean.to(dt), alpha=momentum)
+        sd[pre + "running_var"].mul_(1 - momentum).add_((var * (rows / max(rows - 1, 1))).to(dt), alpha=momentum)
+        if pre + "num_batches_tracked" in sd:
+            sd[pre + "num_batches_tracked"] += 1
+    logits = torch.empty(b, n, dtype=dt, device=dev)
+    for j0 in range(0, n, label_chunk):
+        j1 = min(n, j0 + label_chunk)
+        logits[:, j0:j1] = forward_chunk(j0, j1, nl)[4].reshape(b, j1 - j0)
+    lg = logits.detach().clone().requires_grad_(True)
+    y = multihots.to(dt)
+    l = bce_loss(lg, y, **loss_kw) if loss == "BCE" else focal_loss(lg, y, **loss_kw)
+    dl = torch.autograd.grad(l, lg)[0]  # [B, N_L]
+
+    # ---- backward: S1 / S2 of each BatchNorm top down, then the accumulating pass
+    S1 = [None] * nl
+    S2 = [None] * nl
+
+    def backward_chunk(j0, j1, down_to, final=False, acc=None):
+        """du of layer `down_to` for labels [j0, j1) (and, in the final pass, every gradient contribution)."""
+        x, zs, us, h_top, _ = forward_chunk(j0, j1, nl, keep=True)
+        g = dl[:, j0:j1].reshape(-1, 1)  # rows i * nj + j, like the joint rows
+        if final:
+            acc["w_out"] += (g * h_top).sum(0, keepdim=True).double()
+            acc["b_out"] += g.sum().double()
+        du = (g * w_out) * (us[nl - 1] > 0)
+        dz = None
+        for m in range(nl - 1, -1, -1):
+            if m < down_to:
+                break
+            if m == down_to and not final:
+                return du, zs[m]
+            if has_bn[m]:
+                mean, invstd, gamma, _ = fstat[m]
+                xhat = (zs[m] - mean) * invstd
+                dz = (gamma * invstd) * (du - (S1[m] / rows).to(dt) - xhat * (S2[m] / rows).to(dt))
+            else:
+                dz = du
+            if final:
+                h_prev = F.relu(us[m - 1]) if m > 0 else x
+                acc["W"][m] += (dz.t() @ h_prev).double()
+                if not has_bn[m] and bias[m] is not None:
+                    acc["bias"][m] += dz.sum(0).double()
+            if m > 0:
+                du = (dz @ W[m]) * (us[m - 1] > 0)
+        dx = dz @ W[0]  # [rows, in_dim]
+        nj = j1 - j0
+        dx = dx.reshape(b, nj, -1)
+        dP = dx[:, :, :d].sum(1).double()
+        dL = dx[:, :, d:2 * d].sum(0).double()
+        if fusion == "concatenation_diff":
+            dP += dx[:, :, 2 * d:].sum(1).double()
+            dL -= dx[:, :, 2 * d:].sum(0).double()
+        if fusion == "concatenation_prod":
+            dP += (dx[:, :, 2 * d:] * L_e[None, j0:j1, :]).sum(1).double()
+            dL += (dx[:, :, 2 * d:] * P_e[:, None, :]).sum(0).double()
+        acc["dP"] += dP
+        acc["dL"][j0:j1] += dL
+        return None, None
+
+    for m in range(nl - 1, -1, -1):
+        if not has_bn[m]:
+            continue
+        s1 = torch.zeros(W[m].shape[0], dtype=torch.float64, device=dev)
+        s2 = torch.zeros_like(s1)
+        mean, invstd, _, _ = fstat[m]
+        for j0 in range(0, n, label_chunk):
+            du, z = backward_chunk(j0, min(n, j0 + label_chunk), m)
+            s1 += du.double().sum(0)
+            s2 += (du * ((z - mean) * invstd)).double().sum(0)
+        S1[m], S2[m] = s1, s2
+    acc = {"W": [torch.zeros(w.shape, dtype=torch.float64, device=dev) for w in W],
+           "bias": [torch.zeros(w.shape[0], dtype=torch.float64, device=dev) for w in W],
+           "w_out": torch.zeros(w_out.shape, dtype=torch.float64, device=dev),
+           "b_out": torch.zeros((), dtype=torch.float64, device=dev),
+           "dP": torch.zeros(P_e.shape, dtype=torch.float64, device=dev),
+           "dL": torch.zeros(L_e.shape, dtype=torch.float64, device=dev)}
+    for j0 in range(0, n, label_chunk):
+        backward_chunk(j0, min(n, j0 + label_chunk), 0, final=True, acc=acc)
+    grads = {}
+    for m, i in enumerate(hidden):
+        grads[f"output_layer.{i}.weight"] = acc["W"][m].to(dt)
+        if has_bn[m]:
+            grads[f"output_layer.{i + 1}.weight"] = S2[m].to(dt)  # dgamma = sum du * xhat
+            grads[f"output_layer.{i + 1}.bias"] = S1[m].to(dt)    # dbeta  = sum du
+        elif bias[m] is not None:
+            grads[f"output_layer.{i}.bias"] = acc["bias"][m].to(dt)
+    grads[f"output_layer.{out_i}.weight"] = acc["w_out"].to(dt)
+    if b_out is not None:
+        grads[f"output_layer.{out_i}.bias"] = acc["b_out"].to(dt).reshape(b_out.shape)
+    gl = torch.autograd.grad([P_e_g, L_e_g], [leaves[k] for k in head], grad_outputs=[acc["dP"].to(dt), acc["dL"].to(dt)])
+    grads.update(dict(zip(head, gl)))
+    return logits, l.detach(), grads
+
+
 # ------------------------------------------------------------------------------------------------
 # losses / metrics / optimiser step
 # ------------------------------------------------------------------------------------------------

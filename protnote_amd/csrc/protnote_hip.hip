@@ -1739,6 +1739,8 @@ static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& 
 struct PairTrainWs {
   double *sumA, *sqA, *sumB, *sqB, *S1, *S2, *dwacc, *scal, *s12;
   float *cs, *p, *q, *WT, *weff, *dweff, *part, *dA1, *dB1;
+  float* m1part;  // B <= 256: per-label-chunk partials of M1 (k_pair_mask_reduce_fused), [m1_chunks][B][h]
+  int m1_chunks;
   size_t part_floats;
   ColScr colscr;
   StatScr statscr;
@@ -1769,6 +1771,12 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   w.part = bp.take<float>(w.part_floats);
   w.dA1 = bp.take<float>((size_t)B * h);
   w.dB1 = bp.take<float>((size_t)NL * h);
+  // label chunks of k_pair_mask_reduce_fused: about 256 labels each (the f32 run length of the two-pass kernels), at most
+  // 128 chunks (the partial buffer is chunks x B x h floats: 0.4 GB at the bench size)
+  w.m1_chunks = (NL + 255) / 256;
+  if (w.m1_chunks < 1) w.m1_chunks = 1;
+  if (w.m1_chunks > 128) w.m1_chunks = 128;
+  w.m1part = (B <= 256 && hd->fusion != 2) ? bp.take<float>((size_t)w.m1_chunks * B * h) : nullptr;
   colscr_carve(bp, (long)B * NL, h, w.colscr);
   statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
@@ -2039,9 +2047,17 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     rp.A = sv.A1; rp.lda = h; rp.Bm = sv.B1; rp.ldb = h;
     rp.s = sv.s[0]; rp.t = sv.t[0];
     rp.out = w.dB1; rp.ldo = h;
-    hipLaunchKernelGGL((k_pair_mask_reduce<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
-    rp.out = w.dA1;
-    hipLaunchKernelGGL((k_pair_mask_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+    if (w.m1part != nullptr) {  // B <= 256: both tables from one pass over the gradient
+      const int per = (NL + w.m1_chunks - 1) / w.m1_chunks;
+      const int nch = (NL + per - 1) / per;
+      hipLaunchKernelGGL(k_pair_mask_reduce_fused, dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part, per);
+      hipLaunchKernelGGL(k_pair_m1_reduce, dim3(nblk((long)B * h / 4, 256)), dim3(256), 0, st, (const float*)w.m1part, nch,
+                         (long)B * h, h, w.dA1, (long)h);
+    } else {
+      hipLaunchKernelGGL((k_pair_mask_reduce<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
+      rp.out = w.dA1;
+      hipLaunchKernelGGL((k_pair_mask_reduce<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+    }
     const int per_chunk = (NL + RED_CHUNKS - 1) / RED_CHUNKS;
     const int nchunk = (NL + per_chunk - 1) / per_chunk;
     hipLaunchKernelGGL(k_pair_colsums, dim3(nblk(h, 256), nchunk), dim3(256), 0, st, (const float*)w.dB1, (long)h,

@@ -384,9 +384,11 @@ struct PairRedParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Layer-1 backward in TWO passes over the upstream gradient instead of three.  With du = (s*z1+t > 0 ? g : 0):
-//   M0[j][c] = sum_i du   (k_pair_mask_reduce<0>, rows of one label are contiguous)
-//   M1[i][c] = sum_j du   (k_pair_mask_reduce<1>)
+// Layer-1 backward from two small tables of the upstream gradient.  With du = (s*z1+t > 0 ? g : 0):
+//   M0[j][c] = sum_i du   (rows of one label are contiguous)
+//   M1[i][c] = sum_j du
+// k_pair_mask_reduce_fused produces both in ONE pass over the gradient (B <= 256); k_pair_mask_reduce<0|1> are the
+// two-pass form for larger batches.
 // everything BatchNorm-backward needs follows from these two small tables, because z1 = A[i] + Bm[j] is separable:
 //   S1 = sum du = sum_j M0[j],   sum du*z1 = sum_i A[i] M1[i] + sum_j Bm[j] M0[j],   S2 = invstd (sum du*z1 - mean S1)
 //   dBm[j] = sum_i dz1 = cs M0[j] + B p + q (sum_i A[i] + B Bm[j]),   dA[i] = cs M1[i] + NL p + q (NL A[i] + sum_j Bm[j])
@@ -422,6 +424,106 @@ __global__ __launch_bounds__(256) void k_pair_mask_reduce(const PairRedParams P)
   d0 += a0; d1 += a1; d2 += a2; d3 += a3;
   *reinterpret_cast<float4*>(P.out + (long)fixed * P.ldo + c) =
       make_float4((float)d0, (float)d1, (float)d2, (float)d3);
+}
+
+// Both reductions in ONE pass over the gradient (round 3; B <= 256).  A workgroup of 512 threads = 16 protein groups x 32
+// column quads owns a 128-column strip and a chunk of labels: thread (ig, cq) keeps A[i][c..c+3] and the M1 accumulators of
+// its 16 proteins i = ig + 16 k in registers, streams the label's rows (a wave reads 2 rows x 512 B), and the per-label sum
+// over proteins M0[j] is closed over the 16 protein groups through the LDS, two labels per barrier pair.  M1 leaves as one
+// partial per label chunk ([chunk][B][C] f32, at most 256 labels each - the f32 run length of the two-pass kernels), added
+// in chunk order by k_pair_m1_reduce: deterministic, no atomics.  Reads the 101 GB gradient once instead of twice.
+constexpr int PMR_JB = 2;   // labels per barrier pair
+constexpr int PMR_IG = 16;  // protein groups: 512 threads = 16 groups x 32 column quads, 16 proteins per thread
+__global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const PairRedParams P, float* __restrict__ m1part,
+                                                                        int labels_per_chunk) {
+  constexpr int RPT = 256 / PMR_IG;  // proteins per thread
+  __shared__ float4 red[PMR_JB][PMR_IG][32];
+  const int tid = threadIdx.x;
+  const int cq = tid & 31, ig = tid >> 5;
+  const int c_raw = blockIdx.x * 128 + cq * 4;
+  const bool live = c_raw < P.C;
+  const int c = live ? c_raw : 0;  // dead column quads compute on column 0 and store nothing (they must meet the barriers)
+  const int j0 = blockIdx.y * labels_per_chunk;
+  int j1 = j0 + labels_per_chunk;
+  if (j1 > P.NL) j1 = P.NL;
+  const float4 s = ld4(P.s + c), t = ld4(P.t + c);
+  float4 a[RPT], m1[RPT];
+  unsigned roff[RPT];  // element offset of protein i's row inside one label's block of the gradient (< 2^31: B * ldh)
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int i = ig + PMR_IG * k;
+    // proteins past the batch: NaN pre-activation -> the "> 0" test below is false whatever the sign of s (branch-free)
+    const float qn = __builtin_nanf("");
+    a[k] = i < P.B ? ld4(P.A + (long)i * P.lda + c) : make_float4(qn, qn, qn, qn);
+    m1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    roff[k] = (unsigned)((long)(i < P.B ? i : 0) * P.ldh + c);
+  }
+  for (int j = j0; j < j1; j += PMR_JB) {
+#pragma unroll 1
+    for (int jj = 0; jj < PMR_JB; ++jj) {
+      float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j + jj < j1) {
+        const float4 zb = ld4(P.Bm + (long)(j + jj) * P.ldb + c);
+        const float* base = P.DH + (long)(j + jj) * P.B * P.ldh;  // uniform
+#pragma unroll
+        for (int k0 = 0; k0 < RPT; k0 += 8) {  // eight 16-byte loads in flight per thread
+          float4 g[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[k] = ld4(base + roff[k0 + k]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float4 av = a[k0 + k];
+            const float dx = fmaf(av.x + zb.x, s.x, t.x) > 0.f ? g[k].x : 0.f;
+            const float dy = fmaf(av.y + zb.y, s.y, t.y) > 0.f ? g[k].y : 0.f;
+            const float dz = fmaf(av.z + zb.z, s.z, t.z) > 0.f ? g[k].z : 0.f;
+            const float dw = fmaf(av.w + zb.w, s.w, t.w) > 0.f ? g[k].w : 0.f;
+            m0.x += dx; m0.y += dy; m0.z += dz; m0.w += dw;
+            float4& acc = m1[k0 + k];
+            acc.x += dx; acc.y += dy; acc.z += dz; acc.w += dw;
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the next batch of loads behind this batch's arithmetic (registers)
+        }
+      }
+      red[jj][ig][cq] = m0;
+    }
+    __syncthreads();
+    if (tid < PMR_JB * 32) {  // fixed-order sum over the protein groups
+      const int jj = tid >> 5, q = tid & 31;
+      const int cc = blockIdx.x * 128 + q * 4;
+      if (j + jj < j1 && cc < P.C) {
+        float4 v = red[jj][0][q];
+#pragma unroll
+        for (int g2 = 1; g2 < PMR_IG; ++g2) {
+          const float4 w = red[jj][g2][q];
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<float4*>(P.out + (long)(j + jj) * P.ldo + cc) = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+    float* dst = m1part + ((long)blockIdx.y * P.B) * P.C + c;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int i = ig + PMR_IG * k;
+      if (i < P.B) *reinterpret_cast<float4*>(dst + (long)i * P.C) = m1[k];
+    }
+  }
+}
+
+// M1[i][c] = sum over the label chunks of k_pair_mask_reduce_fused's partials, in chunk order (f64)
+__global__ void k_pair_m1_reduce(const float* __restrict__ part, int nchunk, long BC, int C, float* __restrict__ out, long ldo) {
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (e >= BC) return;
+  double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float4 v = ld4(part + (long)k * BC + e);
+    d0 += v.x; d1 += v.y; d2 += v.z; d3 += v.w;
+  }
+  const long i = e / C;
+  const int c = (int)(e - i * C);
+  *reinterpret_cast<float4*>(out + i * ldo + c) = make_float4((float)d0, (float)d1, (float)d2, (float)d3);
 }
 
 // per column and label chunk: sum_j M0[j], sum_j Bm[j] M0[j], sum_j Bm[j]  -> out[chunk][3][C] (f64)

@@ -143,9 +143,8 @@ class ProteInfer(torch.nn.Module):
         return emb
 
     def _bump_batches_tracked(self):
-        for blk in self.resnet_blocks:
-            blk.bn_activation_1[0].num_batches_tracked += 1
-            blk.bn_activation_2[0].num_batches_tracked += 1
+        torch._foreach_add_([bn.num_batches_tracked for blk in self.resnet_blocks
+                             for bn in (blk.bn_activation_1[0], blk.bn_activation_2[0])], 1)  # one multi-tensor launch
 
     def forward(self, x, sequence_lengths):
         """Reference protein_encoders.py:120-123: Linear(C -> num_labels) on the pooled features."""

@@ -84,11 +84,11 @@ class _HeadsTrainFn(torch.autograd.Function):
         P_e = mlp_fwd(mp, P_f, "W_p")
         L_e = mlp_fwd(ml, L_f, "W_l")
         ctx.P_e, ctx.L_e = P_e, L_e
-        for _, bn in lp + ll:
-            if bn is not None:
-                bn.num_batches_tracked += 1
+        # BatchNorm bookkeeping of all three stacks in ONE multi-tensor add (was one tiny launch per BatchNorm)
+        tracked = [bn.num_batches_tracked for _, bn in lp + ll if bn is not None]
 
         if model.feature_fusion == "similarity":
+            torch._foreach_add_(tracked, 1)
             return model._similarity(P_e, L_e)
         hd, hl = model._pair_desc(seed)
         chunk = model._train_chunk(B, NL)
@@ -98,9 +98,9 @@ class _HeadsTrainFn(torch.autograd.Function):
         pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
         L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
                                           L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), st))
-        for _, bn in hl[:-1]:
-            if bn is not None:
-                bn.num_batches_tracked += 1
+        tracked += [bn.num_batches_tracked for _, bn in hl[:-1] if bn is not None]
+        if tracked:
+            torch._foreach_add_(tracked, 1)
         logits = torch.empty(B, NL, dtype=torch.float32, device=dev)
         L.check(lib.pn_transpose(L.ptr(pairs), B, NL, B, L.ptr(logits), NL, st))
         return logits

@@ -136,7 +136,7 @@ def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
 
 
 @pytest.mark.parametrize("B,NL,chunk", [(8, 40, 3), (130, 40, 7), (8, 9, None), (100, 660, 256), (256, 512, 100),
-                                        (8, 16400, None)])
+                                        (8, 16400, None), (300, 24, 5)])
 def test_train_real_width_vs_oracle(B, NL, chunk):
     """d=1024 / h=3072 / 3 hidden layers / 4-layer projection heads: logits, loss and every gradient of one
     train-mode step against the oracle's autograd on the same seeded inputs.  The 100 x 660 grid (66 000 pair rows,
@@ -146,7 +146,9 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
     weight-gradient kernel (B % 32 == 0, whole-slab splits), the top layer's dh written in six label chunks over its
     own consumed rows (the last one ragged), 131 072 pair rows.  8 x 16 400 takes the label table past 16 384 rows:
     the W_l backward on the materialised-dY path (256-tile NT / big TN kernels) - the two regimes of the full-size step
-    that were only ever compared with themselves.  (f64 oracle: ~35 GB of host memory, ~1 min on the GPU box's host.)"""
+    that were only ever compared with themselves.  (f64 oracle: ~35 GB of host memory, ~1 min on the GPU box's host.)
+    300 x 24: more than 256 proteins - the layer-1 backward takes its two-pass reductions (k_pair_mask_reduce<0|1>)
+    instead of the single-pass kernel every B <= 256 grid above runs (k_pair_mask_reduce_fused)."""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
@@ -200,8 +202,9 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
         # backward subtracts (du - mean(du)): whatever element-wise f32 noise dL_e carries is amplified ~10x behind that
         # BatchNorm while a noise component common to all labels cancels - W_l.12 / W_l.9 in front of it sit at 1.5x / 1.9x
         # like everything else, and 100 x 660 / 8 x 16400 (smaller B) show no such step.  Still the f32 class (< 4e-3);
-        # the factor for those five tensors on that grid is 6.
-        factor = 6 if (B >= 256 and name.startswith("W_l.") and int(name.split(".")[1]) <= 8) else 4
+        # the factor for those tensors (and W_l.9.bias, the same BatchNorm's d beta = sum_j du: 4.4x) on that grid is 6.
+        behind = name.startswith("W_l.") and (int(name.split(".")[1]) <= 8 or name == "W_l.9.bias")
+        factor = 6 if (B >= 256 and behind) else 4
         if not (rel < max(factor * rel_cpu, 1e-6) and rel < 4e-3):
             bad.append((name, rel, rel_cpu))
     assert not bad, bad
@@ -357,17 +360,20 @@ def test_full_size_train_step_properties():
         assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
 
 
-def test_full_size_train_forward_vs_chunked_torch():
-    """BASELINE configs[2] at its REAL size (B=256, N_L=32102, full-width model) against the reference algorithm: the
-    oracle's label-chunked restatement of the naive train-mode forward (joint rows -> Linear -> BatchNorm1d over all
-    8.2 M rows -> ReLU, ProtNote.py:112-152,286-293,337-378; O.train_forward_chunked, pinned on CPU to the reference's own
-    golden logits) evaluated with stock torch ops on the device - one pass per BatchNorm for its global column statistics.
-    Held to it: all 8.2 M train-mode logits (5e-4; north star 1e-3), the BCE loss, and running_mean / running_var of
-    every BatchNorm of W_p, W_l and the output MLP; the opt-in bf16x3 arithmetic is held to the same reference (1e-3).
-    The encoder is not part of this check (its own full-size parity: test_full_size_eval_properties); both sides start
-    from the same [256, 1100] sequence embeddings."""
+def test_full_size_train_step_vs_chunked_torch():
+    """BASELINE configs[2] at its REAL size (B=256, N_L=32102, full-width model) against the reference algorithm, forward
+    AND backward: the oracle's label-chunked restatement of the naive train step (joint rows -> Linear -> BatchNorm1d over
+    all 8.2 M rows -> ReLU, ProtNote.py:112-152,286-293,337-378, BCE, and the multi-pass BatchNorm backward;
+    O.train_grads_chunked, pinned on CPU to the reference's own golden logits and gradients) evaluated with stock torch ops
+    on the device, once in float64 (ground truth) and once in float32 (the error scale of an f32 implementation).  Held to
+    the float64 run: all 8.2 M train-mode logits (5e-4; north star 1e-3), the BCE loss, running_mean / running_var of every
+    BatchNorm of W_p, W_l and the output MLP, and all 31 gradient tensors (Frobenius error at most 4x that of the float32
+    run of the reference itself - the criterion of test_train_real_width_vs_oracle); the opt-in bf16x3 arithmetic is held
+    to the same reference (logits 1e-3, gradients 4x as well).  The encoder is not part of this check (its
+    own full-size parity: test_full_size_eval_properties); both sides start from the same [256, 1100] embeddings."""
     import protnote_amd
     from bench import build_model, synthetic_batch
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
 
     dev = torch.device(DEV)
     model = build_model(dev, unit_scale_weights=True)
@@ -384,32 +390,66 @@ def test_full_size_train_forward_vs_chunked_torch():
         model.load_state_dict(sd0, strict=False)
         protnote_amd.set_math_mode(mode)
         try:
+            for p in model.parameters():
+                p.grad = None
             logits, _ = model(sequence_embeddings=P_f, label_embeddings=batch["label_embeddings"])
-            got[mode] = (logits.detach().clone(),
-                         {k: v.detach().clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))
-                          and not k.startswith("sequence_encoder.")})
+            loss = BCEWithLogitsLoss()(logits, y)
+            loss.backward()
+            got[mode] = (logits.detach().clone(), float(loss),
+                         {k: v.detach().clone() for k, v in model.state_dict().items()
+                          if k.endswith(("running_mean", "running_var")) and not k.startswith("sequence_encoder.")},
+                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
         finally:
             protnote_amd.set_math_mode("f32")
-    del logits
+    del logits, loss
+    for p in model.parameters():
+        p.grad = None
     model.__dict__.pop("_pn_train_save", None)  # 2 x 101 GB of stored pre-activations: not needed beside the reference
     protnote_amd.free_workspaces()
     torch.cuda.empty_cache()
 
-    sd = {k: v.clone() for k, v in sd0.items()}
-    with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):  # torch's native BatchNorm kernels, not MIOpen
-        ref = O.train_forward_chunked(sd, P_f, batch["label_embeddings"], label_chunk=1024)
-    ref_loss = O.bce_loss(ref.double(), y.double()).item()
-    assert ref.abs().max().item() > 1.0 and float(ref.std()) > 0.1
-    for mode, tol in (("f32", 5e-4), ("bf16x3", 1e-3)):
-        lg, bufs = got[mode]
-        err = (lg - ref).abs().max().item()
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(lg.double(), y.double()).item()
-        print(f"full-size train forward [{mode}]: max |logit - chunked torch reference| = {err:.2e}, loss {loss:.7f} vs {ref_loss:.7f}")
-        assert err < tol, (mode, err)
-        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    # the reference twice: float64 = ground truth, float32 = the error scale of an f32 implementation of the same
+    # algorithm in another summation order (what the small-grid tests take from the CPU oracle's f32 run)
+    def reference(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        with torch.backends.cudnn.flags(enabled=False):  # torch's native BatchNorm kernels, not MIOpen
+            lg_, loss_, grads_ = O.train_grads_chunked(sd, P_f.to(dtype), batch["label_embeddings"].to(dtype), y.to(dtype),
+                                                       label_chunk=1024)
+        return lg_, float(loss_), grads_, sd
+
+    ref, ref_loss, ref_grads, sd = reference(torch.float64)
+    ref32, _, ref32_grads, _ = reference(torch.float32)
+    assert ref.abs().max().item() > 1.0 and float(ref.std()) > 0.1 and len(ref_grads) == 31
+    f32_logit_err = (ref32.double() - ref).abs().max().item()
+    del ref32
+    scale = {n: max(ref_grads[n].norm().item(), 1e-30) for n in ref_grads}
+    f32_err = {n: (ref32_grads[n].double() - ref_grads[n]).norm().item() / scale[n] for n in ref_grads}
+    bad = []
+    # measured (round 3): logits 2.2e-4 (f32) / 2.4e-4 (bf16x3) against 1.05e-4 for torch's own f32 run; every gradient
+    # 0.2x..1.9x the torch-f32 run's error in BOTH modes (W_p.* ~1e-2 for HIP and torch alike: with 32 102 labels per protein
+    # the protein-side gradient is all common mode, see test_train_real_width_vs_oracle)
+    for mode, tol, factor, cap in (("f32", 5e-4, 4.0, 2e-2), ("bf16x3", 1e-3, 4.0, 2e-2)):
+        lg, loss, bufs, grads = got[mode]
+        err = (lg.double() - ref).abs().max().item()
+        assert err < tol, (mode, err, f32_logit_err)
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (mode, loss, ref_loss)
         assert len(bufs) == 2 * (3 + 3 + 3)
         for k, v in bufs.items():
-            np.testing.assert_allclose(v.cpu().numpy(), sd[k].cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=f"{mode} {k}")
+            np.testing.assert_allclose(v.cpu().numpy(), sd[k].float().cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=f"{mode} {k}")
+        assert set(grads) == set(ref_grads)
+        worst = ("", 0.0, 0.0)
+        for n, gr in grads.items():
+            rel = (gr.double() - ref_grads[n]).norm().item() / scale[n]
+            print(f"full-size grad-err [{mode}] {n}: hip {rel:.2e} torch-f32 {f32_err[n]:.2e} ratio {rel / max(f32_err[n], 1e-30):.2f}")
+            if rel / max(f32_err[n], 1e-30) > worst[2]:
+                worst = (n, rel, rel / max(f32_err[n], 1e-30))
+            # same criterion as the small-grid tests: within `factor` x the error of an f32 run of the reference algorithm
+            # itself against float64, and an absolute cap
+            if not (rel < max(factor * f32_err[n], 1e-6) and rel < cap):
+                bad.append((mode, n, rel, f32_err[n]))
+        print(f"full-size train step [{mode}]: max |logit - f64 reference| = {err:.2e} (torch-f32 reference: {f32_logit_err:.2e}), "
+              f"loss {loss:.7f} vs {ref_loss:.7f}, worst gradient ratio {worst[0]}: {worst[1]:.2e} = {worst[2]:.2f} x torch-f32")
+    assert not bad, bad
 
 
 def test_trainer_learns_synthetic_task():

@@ -134,6 +134,35 @@ def test_chunked_train_forward_matches_reference_golden(golden_dir, name, fusion
     assert n > 0
 
 
+@pytest.mark.parametrize("name,fusion", [("protnote_small_concatenation.npz", "concatenation"),
+                                         ("protnote_small_concatenation_diff.npz", "concatenation_diff"),
+                                         ("protnote_small_concatenation_prod.npz", "concatenation_prod"),
+                                         ("protnote_small_concatenation_nobn.npz", "concatenation")])
+@pytest.mark.parametrize("loss", ["BCE", "FocalLoss"])
+def test_chunked_train_gradients_match_reference_golden(golden_dir, name, fusion, loss):
+    """O.train_grads_chunked (label-chunked forward + backward with the multi-pass BatchNorm backward; the independent
+    reference of the full-size HIP train step on the GPU) reproduces the REFERENCE's own gradients, loss and logits on the
+    golden inputs - ragged chunks of 3 labels - for every trainable head tensor."""
+    g = _load(golden_dir, name)
+    sd = O.as_torch_sd(g, "sd/")
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous()
+    u = torch.from_numpy(g["train/noise_u"])
+    L_f = O.noised_label_embeddings(lab, float(g["head_cfg_label_embedding_noising_alpha"]), u)
+    with torch.no_grad():
+        P_f = O.proteinfer_get_embeddings(sd, x, lens, True, 3, "sequence_encoder.")
+    logits, l, grads = O.train_grads_chunked(sd, P_f, L_f, torch.from_numpy(g["multihots"]), fusion=fusion, label_chunk=3,
+                                             loss=loss)
+    p = f"train_{loss}/"
+    np.testing.assert_allclose(logits.numpy(), g[p + "logits"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(float(l), float(g[p + "loss"]), rtol=1e-5)
+    keys = [k for k in g.files if k.startswith(p + "grad/")]
+    assert len(keys) == len(grads) and len(keys) > 20
+    for k in keys:
+        ref = g[k]
+        np.testing.assert_allclose(grads[k[len(p + "grad/"):]].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=k)
+
+
 def test_losses_and_metrics(golden_dir):
     g = _load(golden_dir, "losses_metrics.npz")
     logits = torch.from_numpy(g["logits"])
