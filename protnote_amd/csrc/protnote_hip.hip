@@ -1926,6 +1926,12 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
                        sv.mean[l], sv.invstd[l]));
     HIP_OK(hipGetLastError());
   }
+  if (h <= 3072) {
+    const int rpw = 32;  // rows per wave: 128 rows (1.5 MB) per workgroup
+    hipLaunchKernelGGL(k_rowdot_rows_reg, dim3(nblk(R, 4 * rpw)), dim3(256), 0, st,
+                       (const float*)(sv.zbuf[n - 1] + (size_t)S * h), (long)h, R, h, (const float*)sv.s[n - 1],
+                       (const float*)sv.t[n - 1], hd->w_out, hd->b_out, logits_pairs, rpw);
+  } else
   hipLaunchKernelGGL(k_rowdot_rows, dim3(nblk(R, 4)), dim3(256), 0, st,
                      (const float*)(sv.zbuf[n - 1] + (size_t)S * h), (long)h, R, h, (const float*)sv.s[n - 1],
                      (const float*)sv.t[n - 1], hd->w_out, hd->b_out, logits_pairs);

@@ -667,6 +667,54 @@ __global__ __launch_bounds__(256) void k_rowdot_rows(const float* __restrict__ Z
   if (lane == 0) out[r] = a + b[0];
 }
 
+// The same for C <= 3072 with the three per-column vectors held in registers (round 3): the kernel above re-reads s, t, w
+// (36 KB) from the L1 for every 12 KB row - three of its four load instructions - and starts a 4-row workgroup per 48 KB.
+// Here a wave keeps its 12 column quads of s, t, w (144 registers), walks `rows_per_wave` rows with the whole next row in
+// flight, and only the row itself is loaded.  Same products in the same order: bit-identical logits.
+// [measured] 22.6 -> 16.3 ms for the 101 GB of z3 (6.2 TB/s).
+__global__ __launch_bounds__(256) void k_rowdot_rows_reg(const float* __restrict__ Z, long ldz, long R, int C,
+                                                          const float* __restrict__ s, const float* __restrict__ t,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out, int rows_per_wave) {
+  constexpr int NQ = 12;
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long r0 = wave * rows_per_wave;
+  if (r0 >= R) return;
+  long r1 = r0 + rows_per_wave;
+  if (r1 > R) r1 = R;
+  float4 sv[NQ], tv[NQ], wv[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int c = lane * 4 + 256 * k;
+    const bool in = c < C;  // columns past C: weight 0 (and the row loads are clamped to column 0)
+    sv[k] = in ? ld4(s + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    tv[k] = in ? ld4(t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    wv[k] = in ? ld4(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float bias = b[0];
+  float4 z[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) z[k] = ld4(Z + r0 * ldz + (lane * 4 + 256 * k < C ? lane * 4 + 256 * k : 0));
+  for (long r = r0; r < r1; ++r) {
+    float a = 0.f;
+    const long rn = r + 1 < r1 ? r + 1 : r;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const float4 zc = z[k];
+      z[k] = ld4(Z + rn * ldz + (lane * 4 + 256 * k < C ? lane * 4 + 256 * k : 0));  // the next row, behind this one's math
+      if (lane * 4 + 256 * k < C) {
+        a = fmaf(relu(fmaf(zc.x, sv[k].x, tv[k].x)), wv[k].x, a);
+        a = fmaf(relu(fmaf(zc.y, sv[k].y, tv[k].y)), wv[k].y, a);
+        a = fmaf(relu(fmaf(zc.z, sv[k].z, tv[k].z)), wv[k].z, a);
+        a = fmaf(relu(fmaf(zc.w, sv[k].w, tv[k].w)), wv[k].w, a);
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) out[r] = a + bias;
+  }
+}
+
 // dst[c][r] (ld = ldd) = src[r][c] (ld = lds); 32x32 LDS tiles
 __global__ void k_transpose(const float* __restrict__ src, long lds_, int rows, int cols, float* __restrict__ dst,
                             long ldd) {
