@@ -78,3 +78,93 @@ class DistributedWeightedSampler:
         idx = torch.multinomial(self.weights, self.total_size, replacement=self.replacement, generator=g)
         mine = idx[self.rank:self.total_size:self.world_size]
         return iter(mine[torch.randperm(len(mine), generator=g)].tolist())
+
+
+class GeneralDistributedSampler:
+    """Rank shard of ANY sampler's index stream (reference protnote/data/samplers.py:15-63: a DistributedSampler with
+    shuffle=False over `list(sampler)`): the stream is padded by repeating its head to a multiple of the world size
+    (or cut to one with drop_last) and rank r keeps indices r, r + world, ..."""
+
+    def __init__(self, sampler, num_replicas: int, rank: int, seed: int = 0, drop_last: bool = False):
+        import math
+
+        n = len(sampler)
+        assert n > num_replicas, "Total samples must be > num replicas"
+        self.sampler, self.num_replicas, self.rank, self.seed, self.drop_last = sampler, num_replicas, rank, seed, drop_last
+        self.epoch = 0
+        if drop_last and n % num_replicas != 0:  # torch DistributedSampler: drop the tail
+            self.num_samples = math.ceil((n - num_replicas) / num_replicas)
+        else:
+            self.num_samples = math.ceil(n / num_replicas)
+        self.total_size = self.num_samples * num_replicas
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def __iter__(self):
+        import math
+
+        import torch
+
+        torch.manual_seed(self.epoch + self.seed)  # as the reference does: the wrapped sampler may draw from torch's RNG
+        indices = list(self.sampler)
+        if not self.drop_last:
+            pad = self.total_size - len(indices)
+            if pad <= len(indices):
+                indices += indices[:pad]
+            else:
+                indices += (indices * math.ceil(pad / len(indices)))[:pad]
+        else:
+            indices = indices[:self.total_size]
+        assert len(indices) == self.total_size
+        return iter(indices[self.rank:self.total_size:self.num_replicas])
+
+
+class GridBatchSampler:
+    """Batches over the (observation batch) x (label batch) grid (reference protnote/data/samplers.py:127-224, the
+    `grid_sampler` option of create_multiple_loaders, datasets.py:609-618): every epoch shuffles the label indices with
+    Python's `random`, cuts observations and labels into batches, takes their product - optionally shuffled - and yields,
+    per grid cell, the list [(observation index, label batch), ...].  A dataset item built from such an index carries
+    `label_idxs` = the label batch (datasets.py:412-423), which the collator's grid path reads from batch[0]
+    (collators.py:56-70 / protnote_amd.data.collators.sample_label_indices).  Same draws from `random` in the same order
+    as the reference: identical streams for identical seeds."""
+
+    def __init__(self, observation_sampler, observations_batch_size: int, drop_last_observation_batch: bool,
+                 num_labels: int, labels_batch_size: int, shuffle_grid: bool = True):
+        self.observation_sampler = observation_sampler
+        self.observations_batch_size = observations_batch_size
+        self.drop_last_observation_batch = drop_last_observation_batch
+        self.num_labels, self.labels_batch_size, self.shuffle_grid = num_labels, labels_batch_size, shuffle_grid
+        self.labels_idxs = list(range(num_labels))
+        n_lab = -(-num_labels // labels_batch_size)
+        n_obs = (len(observation_sampler) // observations_batch_size if drop_last_observation_batch
+                 else -(-len(observation_sampler) // observations_batch_size))
+        self.total_num_batches = int(n_lab * n_obs)
+
+    def __len__(self) -> int:
+        return self.total_num_batches
+
+    def get_label_batches(self):
+        return [self.labels_idxs[i:i + self.labels_batch_size] for i in range(0, self.num_labels, self.labels_batch_size)]
+
+    def get_observation_batches(self):
+        idx = list(self.observation_sampler)
+        bs = self.observations_batch_size
+        full = len(idx) // bs * bs
+        batches = [idx[i:i + bs] for i in range(0, full, bs)]
+        if not self.drop_last_observation_batch and full < len(idx):
+            batches.append(idx[full:])
+        return batches
+
+    def __iter__(self):
+        from itertools import product
+
+        random.shuffle(self.labels_idxs)
+        cells = list(product(self.get_observation_batches(), self.get_label_batches()))
+        if self.shuffle_grid:
+            random.shuffle(cells)
+        for observation_batch, label_batch in cells:
+            yield list(product(observation_batch, [label_batch]))

@@ -642,6 +642,41 @@ def golden_samplers():
     print("samplers.npz", len(out))
 
 
+def golden_grid_samplers():
+    """Index streams of protnote/data/samplers.py::GridBatchSampler (Python `random`, seeded) and
+    ::GeneralDistributedSampler (rank shards of an arbitrary sampler's stream)."""
+    import random
+
+    from protnote.data.samplers import GeneralDistributedSampler, GridBatchSampler
+
+    out = {}
+    obs = [5, 3, 8, 0, 9, 1, 7, 2, 6, 4, 10]
+    for drop in (False, True):
+        for shuf in (True, False):
+            random.seed(5)
+            s = GridBatchSampler(obs, 4, drop, num_labels=7, labels_batch_size=3, shuffle_grid=shuf)
+            for epoch in (0, 1):  # the label permutation carries over between epochs (shuffled in place)
+                cells = list(iter(s))
+                o = np.full((len(cells), 4), -1, dtype=np.int64)
+                l = np.full((len(cells), 3), -1, dtype=np.int64)
+                for k, cell in enumerate(cells):
+                    ob = [c[0] for c in cell]
+                    assert all(c[1] is cell[0][1] or c[1] == cell[0][1] for c in cell)
+                    o[k, :len(ob)] = ob
+                    l[k, :len(cell[0][1])] = cell[0][1]
+                out[f"grid/drop{int(drop)}/shuf{int(shuf)}/e{epoch}/obs"] = o
+                out[f"grid/drop{int(drop)}/shuf{int(shuf)}/e{epoch}/labels"] = l
+            out[f"grid/drop{int(drop)}/shuf{int(shuf)}/len"] = np.array(len(s))
+    stream = [11, 4, 7, 0, 2, 9, 5, 13, 1, 8]
+    for drop in (False, True):
+        for rank in range(3):
+            g = GeneralDistributedSampler(stream, num_replicas=3, rank=rank, drop_last=drop)
+            out[f"general/drop{int(drop)}/r{rank}"] = np.array(list(iter(g)))
+            out[f"general/drop{int(drop)}/r{rank}/len"] = np.array(len(g))
+    np.savez_compressed(os.path.join(OUT, "grid_samplers.npz"), **out)
+    print("grid_samplers.npz", len(out))
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
@@ -649,7 +684,7 @@ if __name__ == "__main__":
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
-            "samplers": golden_samplers, "attention": golden_attention_pooling}
+            "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -98,3 +98,44 @@ def test_distributed_weighted_sampler_streams(golden_dir):
                 for epoch in (0, 1):
                     s.set_epoch(epoch)
                     assert list(iter(s)) == g[f"repl{int(repl)}/w{world}/r{rank}/e{epoch}"].tolist()
+
+
+def test_grid_and_general_distributed_sampler_streams(golden_dir):
+    """GridBatchSampler / GeneralDistributedSampler (protnote/data/samplers.py:15-63,127-224) against streams generated
+    by the reference classes: same `random` seed -> the same grid cells in the same order over two epochs (drop_last and
+    shuffle_grid on / off), the same rank shards; and the collator's grid path picks the cell's label batch."""
+    import random
+
+    from protnote_amd.data.collators import collate_variable_sequence_length
+    from protnote_amd.data.samplers import GeneralDistributedSampler, GridBatchSampler
+
+    g = np.load(os.path.join(golden_dir, "grid_samplers.npz"))
+    obs = [5, 3, 8, 0, 9, 1, 7, 2, 6, 4, 10]
+    for drop in (False, True):
+        for shuf in (True, False):
+            random.seed(5)
+            s = GridBatchSampler(obs, 4, drop, num_labels=7, labels_batch_size=3, shuffle_grid=shuf)
+            assert len(s) == int(g[f"grid/drop{int(drop)}/shuf{int(shuf)}/len"])
+            for epoch in (0, 1):
+                cells = list(iter(s))
+                ro, rl = g[f"grid/drop{int(drop)}/shuf{int(shuf)}/e{epoch}/obs"], g[f"grid/drop{int(drop)}/shuf{int(shuf)}/e{epoch}/labels"]
+                assert len(cells) == len(ro)
+                for k, cell in enumerate(cells):
+                    assert [c[0] for c in cell] == [v for v in ro[k].tolist() if v >= 0]
+                    assert all(c[1] == [v for v in rl[k].tolist() if v >= 0] for c in cell)
+    stream = [11, 4, 7, 0, 2, 9, 5, 13, 1, 8]
+    for drop in (False, True):
+        for rank in range(3):
+            d = GeneralDistributedSampler(stream, num_replicas=3, rank=rank, drop_last=drop)
+            assert list(iter(d)) == g[f"general/drop{int(drop)}/r{rank}"].tolist()
+            assert len(d) == int(g[f"general/drop{int(drop)}/r{rank}/len"])
+    # a grid cell through the collator: items carry label_idxs = the cell's label batch (datasets.py:412-423)
+    random.seed(1)
+    cell = next(iter(GridBatchSampler([0, 1, 2], 2, False, num_labels=5, labels_batch_size=2)))
+    emb = torch.arange(5 * 3, dtype=torch.float32).reshape(5, 3)
+    items = [{"sequence_onehots": torch.eye(20)[:, :4], "sequence_id": f"s{i}", "sequence_length": torch.tensor(4),
+              "label_multihots": torch.tensor([1, 0, 1, 0, 1]), "label_embeddings": emb,
+              "label_idxs": torch.tensor(lab), "label_token_counts": torch.arange(5)} for i, lab in cell]
+    out = collate_variable_sequence_length(items, label_sample_size=2, grid_sampler=True)
+    lab = torch.tensor(cell[0][1])
+    assert torch.equal(out["label_embeddings"], emb[lab]) and torch.equal(out["label_multihots"][0], items[0]["label_multihots"][lab])
