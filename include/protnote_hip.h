@@ -318,7 +318,9 @@ int pn_set_math_mode(int mode);
  * (sum, sum of squares) and in the backward (sum du, sum du*xhat; dgamma / dbeta stay rank-local, as in torch's
  * SyncBatchNorm).  The library calls hook(n, user) whenever the first n doubles of `stage` (device memory) must be
  * summed over the ranks, in place and ordered on the stream the library was called on; it returns 0 on success.
- * `world` = number of ranks; every rank must run the same batch shape.  hook == NULL switches back to per-rank
+ * `world` = number of ranks.  The ranks' batches may differ in shape (each collator pads to its own batch maximum,
+ * collators.py:40; ragged last batch): every reduction carries the rank's row count as one more double and the global
+ * count is the sum of the local ones, as torch.nn.SyncBatchNorm gathers them.  hook == NULL switches back to per-rank
  * statistics (the default, SYNC_BN: False). */
 /* Row-MLP backward over >= 16384 rows (W_l over the label table): 1 (default) materialises dY once and runs the 256-tile
  * kernels, 0 regenerates it in the operand loaders of the 128-tile engine (A/B switch; no reference counterpart). */

@@ -51,14 +51,14 @@ def stale() -> bool:
 
 
 def csrc_hash() -> str:
-    """sha256 over the device sources (csrc/*.hip, csrc/*.hpp, the C-ABI header), file names included: profiles that
-    describe kernel behaviour (profiles/*_hbm_traffic.json) are stamped with it so bench.py can tell when they no longer
-    belong to the kernels it is running (.git does not travel to the GPU box)."""
+    """sha256 over the device sources (csrc/*.hip, csrc/*.hpp), file names included: profiles that describe kernel
+    behaviour (profiles/*_hbm_traffic.json) are stamped with it so bench.py can tell when they no longer belong to the
+    kernels it is running (.git does not travel to the GPU box)."""
     import hashlib
 
     h = hashlib.sha256()
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
-    for f in [os.path.join(CSRC, f) for f in files] + [API]:
+    for f in [os.path.join(CSRC, f) for f in files]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
