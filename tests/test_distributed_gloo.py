@@ -163,3 +163,27 @@ def test_two_rank_variable_exchange():
     r0, r1 = res[0][1], res[1][1]
     assert r0[0].tolist() == [0] and r0[1].tolist() == []                      # from rank 0: 1 element; from rank 1: empty
     assert r1[0].tolist() == [10, 11] and r1[1].tolist() == [110, 111, 112]    # from rank 0: 2; from rank 1: 3
+
+
+def test_zero_shot_dealing_balances_eight_ranks():
+    """bench.py's configs[4] workload at 8 ranks (no GPU needed for the dealing itself): SEQUENCES are dealt rank-strided
+    within every length bucket, weak scaling - every rank holds 512 sequences +-1 per bucket, at least 4 batches, the same
+    mix of lengths (padded residues within 6 % of each other), and the ranks partition the set.  Round 2 dealt whole
+    batches and left ranks 6 and 7 without work."""
+    import bench
+
+    world, per_rank = 8, 512
+    shares, seen = [], []
+    for r in range(world):
+        zb, residues, n_seq, mine = bench.zero_shot_batches(per_rank, 128, r, world, "cpu")
+        assert n_seq == world * per_rank
+        padded = sum(x.shape[0] * x.shape[2] for x, _ in zb)
+        shares.append((mine, len(zb), padded))
+        seen.append(sum(int(l.numel()) for _, l in zb))
+        for x, l in zb:  # a batch never mixes buckets: its padded length is its bucket
+            assert x.shape[2] in bench.BUCKETS and int(l.max()) <= x.shape[2] and x.shape[0] <= 128
+    assert sum(seen) == world * per_rank
+    assert all(abs(m - per_rank) <= len(bench.BUCKETS) for m, _, _ in shares), shares
+    assert min(b for _, b, _ in shares) >= 4, shares
+    pads = [p for _, _, p in shares]
+    assert max(pads) <= 1.06 * min(pads), pads
