@@ -601,7 +601,9 @@ def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
     layer's gradient and of everything upstream.  tools/relu_flip_probe.py reproduces exactly this with the f64
     oracle plus 1e-6 relative noise on the conv outputs (steps of 1e-3 .. 5e-3 from the last block towards conv1), and
     The HIP path shows the same staircase (1e-5 at the last block, measured in round 1).  Hence a norm-wise 1e-2
-    bound at full width.  (B >= 4: with B = 2 the batch-statistics BatchNorm in W_p is singular.)"""
+    bound at full width - which is NOT the class of the reference's f32 CPU run at this size (that run has no flip at all,
+    see the comment at the assertion): TRAIN_SEQUENCE_ENCODER (non-default) gradients carry the f32-MFMA accumulation
+    noise of a K = 9900 contraction.  (B >= 4: with B = 2 the batch-statistics BatchNorm in W_p is singular.)"""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.protein_encoders import ProteInfer
     from protnote_amd.utils.losses import BCEWithLogitsLoss
@@ -620,6 +622,9 @@ def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
     osd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     _, l64, g64, _ = O.train_step(osd, x.double(), lens, lab.double(), y.double(), loss="BCE", apply_update=False,
                                   train_sequence_encoder=True)
+    # the reference algorithm's own f32 CPU run gives the error scale (as in test_train_real_width_vs_oracle)
+    _, _, g32, _ = O.train_step({k: v.clone() for k, v in sd.items()}, x, lens, lab, y, loss="BCE", apply_update=False,
+                                train_sequence_encoder=True)
     enc = ProteInfer(activation=torch.nn.ReLU, **ecfg)
     model = ProtNote(protein_embedding_dim=C, sequence_encoder=enc, latent_dim=64,
                      output_mlp_hidden_dim_scale_factor=2, output_mlp_num_layers=2, projection_head_num_layers=2,
@@ -637,8 +642,18 @@ def test_train_sequence_encoder_wide_vs_oracle(C, lens, tol):
         ref = g64[name]
         # absolute floor: the last conv bias only shifts every P_f row equally, which W_p's BatchNorm removes - its
         # true gradient is exactly 0 and the f32 result is rounding noise
+        floor = 1e-6 * gmax * ref.numel() ** 0.5
         err = (p.grad.cpu().double() - ref).norm().item()
-        assert err <= tol * ref.norm().item() + 1e-6 * gmax * ref.numel() ** 0.5, (name, err, ref.norm().item())
+        err32 = (g32[name].double() - ref).norm().item()
+        print(f"enc-grad-err C={C} {name}: gpu {err / max(ref.norm().item(), 1e-30):.2e} cpu32 {err32 / max(ref.norm().item(), 1e-30):.2e}")
+        # Measured (round 3, printed above): at C = 1100 the reference algorithm's own f32 CPU run is 2e-6 .. 4e-6 from f64 on
+        # conv1.weight - NO ReLU-mask flip among its 2e7 pre-activations (expected number at the CPU's ~1e-7 relative
+        # pre-activation error: ~1) - while the HIP path is 3e-3 .. 5e-3: ~50 flips, i.e. a pre-activation error of ~3e-6.
+        # That is the k-ordered accumulation chain of v_mfma_f32_32x32x2_f32 over K = 9 x 1100 = 9900 products per
+        # convolution output (sqrt(4950) half-ulp steps; the CPU's vectorised kernels sum in 16+ interleaved chains and a
+        # tree).  The forward stays far inside its bound (embeddings 1e-4, logits 2e-4 of the oracle); the gradient is
+        # discontinuous in those masks, so it is held to the norm-wise cap only, NOT to a multiple of the CPU-f32 error.
+        assert err <= tol * ref.norm().item() + floor, (name, err, ref.norm().item(), err32)
 
 
 def test_gradient_accumulation_matches_single_step(golden_dir):
