@@ -642,6 +642,65 @@ def golden_samplers():
     print("samplers.npz", len(out))
 
 
+def golden_config0_full_width():
+    """BASELINE configs[0] shape at the REAL width (ProteInfer 1100 channels / 5 blocks, d = 1024, h = 3072, 4-layer
+    projections, 3-layer output MLP): the REFERENCE's object graph (ProteInfer -> ProtNote -> get_loss -> the train-step body
+    ProtNoteTrainer.py:728-755 with ONE Adam across the epoch) on tests.helpers.config0_case() - 4 steps, label noise fed
+    from the case's seeded draws.  Stored: the loss trajectory, gradient norms, step-1 logits, every BatchNorm buffer after the
+    epoch, and for every trained tensor its norm and first 256 entries (the weights themselves are regenerated from the seed)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tests.helpers import config0_case
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.losses import get_loss
+    import protnote.models.ProtNote as PN
+    from torch.nn.utils import clip_grad_norm_
+
+    c = config0_case()
+    enc = ProteInfer(activation=torch.nn.ReLU, **c["ecfg"])
+    model = ProtNote(sequence_encoder=enc, label_encoder=None, protein_embedding_dim=1100, label_embedding_dim=1024,
+                     latent_dim=1024, output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                     projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
+                     label_embedding_noising_alpha=20.0, feature_fusion="concatenation")
+    model.load_state_dict(c["sd"])
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+    model.train()
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4)
+    out = {"losses": [], "grad_norms": []}
+    real = torch.rand_like
+    try:
+        for k in range(c["n_steps"]):
+            x, lens, y = c["batch"](k)
+            u = c["noises"][k]
+            PN.torch.rand_like = lambda t, *a, **kw: u.clone()
+            logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=c["lab"],
+                              label_token_counts=c["cnt"])
+            loss = loss_fn(logits, y.float())
+            loss.backward()
+            out["grad_norms"].append(float(clip_grad_norm_(model.parameters(), max_norm=1.0)))
+            opt.step()
+            opt.zero_grad()
+            out["losses"].append(float(loss.detach()))
+            if k == 0:
+                out["step0/logits"] = logits.detach().numpy().copy()
+    finally:
+        PN.torch.rand_like = real
+    out["losses"] = np.array(out["losses"], dtype=np.float64)
+    out["grad_norms"] = np.array(out["grad_norms"], dtype=np.float64)
+    for k, v in model.state_dict().items():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            out["after/buffer/" + k] = v.detach().numpy().copy()
+        elif not k.startswith("sequence_encoder"):
+            flat = v.detach().reshape(-1)
+            out["after/param_head/" + k] = flat[:256].numpy().copy()
+            out["after/param_norm/" + k] = np.array(float(flat.double().norm()))
+    np.savez_compressed(os.path.join(OUT, "config0_full_width.npz"), **out)
+    print("config0_full_width.npz", os.path.getsize(os.path.join(OUT, "config0_full_width.npz")) // 1024, "KiB", out["losses"])
+
+
 def golden_grid_samplers():
     """Index streams of protnote/data/samplers.py::GridBatchSampler (Python `random`, seeded) and
     ::GeneralDistributedSampler (rank shards of an arbitrary sampler's stream)."""
@@ -684,7 +743,8 @@ if __name__ == "__main__":
     jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
-            "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers}
+            "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers,
+            "config0": golden_config0_full_width}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -91,3 +91,34 @@ def random_head_sd(gen, pdim, ldim, d, h_proj, n_proj, h_out, n_out, in_mult=2):
         idx += 4 if i < n_out - 1 else 3
     lin(f"output_layer.{idx}", 1, h_out, bias=True)
     return sd
+
+
+def config0_case():
+    """BASELINE configs[0] shape at the REAL model width, fully seeded: 64 synthetic sequences (20 <= L <= 128), 256
+    labels, batch 16 -> one epoch = 4 optimisation steps with label noise.  Shared by tests/golden/make_golden.py (which
+    runs the REFERENCE on it and stores losses / logits / buffers / parameter samples in config0_full_width.npz) and by the
+    oracle and HIP tests, so that all three see the same weights and data."""
+    gen = torch.Generator().manual_seed(77)
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
+                num_resnet_blocks=5, bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
+    NSEQ, LMAX, NL, BS = 64, 128, 256, 16
+    lens_all = torch.randint(20, LMAX + 1, (NSEQ,), generator=gen)
+    ids = torch.randint(0, 20, (NSEQ, LMAX), generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    cnt = torch.randint(3, 30, (NL,), generator=gen)
+    y_all = (torch.rand(NSEQ, NL, generator=gen) < 0.05).to(torch.int64)
+    noises = [torch.rand(NL, 1024, generator=gen) for _ in range(NSEQ // BS)]
+
+    def batch(k):
+        sl = slice(k * BS, (k + 1) * BS)
+        lens = lens_all[sl]
+        lmax = int(lens.max())  # the collator pads to the batch maximum
+        x = torch.nn.functional.one_hot(ids[sl, :lmax], 20).permute(0, 2, 1).float().contiguous()
+        for b in range(BS):
+            x[b, :, lens[b]:] = 0
+        return x, lens, y_all[sl]
+
+    return dict(ecfg=ecfg, sd=sd, lab=lab, cnt=cnt, y_all=y_all, noises=noises, batch=batch, n_steps=NSEQ // BS, NL=NL,
+                BS=BS)

@@ -215,39 +215,23 @@ def test_train_real_width_vs_oracle(B, NL, chunk):
             np.testing.assert_allclose(got[k].numpy(), v.detach().float().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
 
 
-def test_config0_shape_one_epoch_vs_oracle():
+def test_config0_shape_one_epoch_vs_oracle(golden_dir):
     """BASELINE configs[0] shape: 64 synthetic sequences (L <= 128), 256 labels, batch 16, one epoch = 4
     optimisation steps with label noise, BCE, clip 1, Adam 3e-4 - the object graph bin/main.py builds
     (ProteInfer -> ProtNote -> get_loss -> train-step body), full-width model.  HIP vs the CPU oracle after the
-    whole epoch: loss trajectory, parameters, BN buffers of the (train-mode) frozen encoder."""
+    whole epoch: loss trajectory, parameters, BN buffers of the (train-mode) frozen encoder - AND vs the REFERENCE itself
+    run on the same seeded case at this width (tests/golden/config0_full_width.npz, generated by make_golden.py)."""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.protein_encoders import ProteInfer
     from protnote_amd.models.ProtNoteTrainer import train_step
     from protnote_amd.models.train_path import head_parameters
     from protnote_amd.utils.losses import get_loss
     from protnote_amd.utils.optim import FusedClipAdam
+    from tests.helpers import config0_case
 
-    gen = torch.Generator().manual_seed(77)
-    ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3,
-                num_resnet_blocks=5, bottleneck_factor=0.5)
-    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
-    sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3))
-    NSEQ, LMAX, NL, BS = 64, 128, 256, 16
-    lens_all = torch.randint(20, LMAX + 1, (NSEQ,), generator=gen)
-    ids = torch.randint(0, 20, (NSEQ, LMAX), generator=gen)
-    lab = torch.randn(NL, 1024, generator=gen)
-    cnt = torch.randint(3, 30, (NL,), generator=gen)
-    y_all = (torch.rand(NSEQ, NL, generator=gen) < 0.05).to(torch.int64)
-    noises = [torch.rand(NL, 1024, generator=gen) for _ in range(NSEQ // BS)]
-
-    def batch(k):
-        sl = slice(k * BS, (k + 1) * BS)
-        lens = lens_all[sl]
-        lmax = int(lens.max())  # collator pads to the batch maximum
-        x = torch.nn.functional.one_hot(ids[sl, :lmax], 20).permute(0, 2, 1).float().contiguous()
-        for b in range(BS):
-            x[b, :, lens[b]:] = 0
-        return x, lens, y_all[sl]
+    c = config0_case()
+    ecfg, sd, lab, cnt, y_all, noises, batch = c["ecfg"], c["sd"], c["lab"], c["cnt"], c["y_all"], c["noises"], c["batch"]
+    NSEQ, NL, BS = c["n_steps"] * c["BS"], c["NL"], c["BS"]
 
     # ---- oracle epoch ----
     osd = {k: v.clone() for k, v in sd.items()}
@@ -310,6 +294,27 @@ def test_config0_shape_one_epoch_vs_oracle():
             assert d.max().item() <= 2 * 3e-4 * 4 + 1e-5, (k, d.max().item())
             assert d.mean().item() <= 0.25 * 3e-4 * 4, (k, d.mean().item())
     assert float(counts.sum()) > 0 and float(counts[0].sum() + counts[1].sum()) == float(y_all.sum())
+    # ---- the same epoch as the REFERENCE ran it (real width; reference-generated vectors) ----
+    g = _g(golden_dir, "config0_full_width.npz")
+    np.testing.assert_allclose(losses[:2], g["losses"][:2], rtol=1e-4)
+    np.testing.assert_allclose(losses, g["losses"], rtol=6e-3)
+    n_par = 0
+    for key in g.files:
+        if key.startswith("after/buffer/"):
+            name = key[len("after/buffer/"):]
+            if name.endswith("num_batches_tracked"):
+                assert int(got[name]) == int(g[key]), name
+            elif name.startswith("sequence_encoder"):
+                np.testing.assert_allclose(got[name].numpy(), g[key], atol=2e-6, rtol=1e-5, err_msg=name)
+            else:
+                d = np.abs(got[name].numpy() - g[key])
+                assert d.mean() < 2e-3 * max(np.abs(g[key]).mean(), 1.0), name
+        elif key.startswith("after/param_head/"):
+            name = key[len("after/param_head/"):]
+            d = np.abs(got[name].reshape(-1)[:256].numpy() - g[key])
+            assert d.max() <= 2 * 3e-4 * 4 + 1e-5 and d.mean() <= 0.25 * 3e-4 * 4, (name, d.max(), d.mean())
+            n_par += 1
+    assert n_par == 31
 
 
 def test_full_size_train_step_properties():

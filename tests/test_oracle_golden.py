@@ -163,6 +163,52 @@ def test_chunked_train_gradients_match_reference_golden(golden_dir, name, fusion
         np.testing.assert_allclose(grads[k[len(p + "grad/"):]].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=k)
 
 
+def test_oracle_config0_full_width_vs_reference(golden_dir):
+    """The oracle at the REAL model width (1100-channel ProteInfer, d = 1024, h = 3072) against the reference itself:
+    BASELINE configs[0] shape (64 sequences, 256 labels, batch 16, one epoch = 4 optimisation steps with label noise, ONE Adam
+    across the epoch) run through the reference's object graph by tests/golden/make_golden.py on tests.helpers.config0_case().
+    Loss trajectory, gradient norms, step-1 logits, every BatchNorm buffer and the trained parameters after the epoch."""
+    from tests.helpers import config0_case
+
+    g = _load(golden_dir, "config0_full_width.npz")
+    c = config0_case()
+    sd = {k: v.clone() for k, v in c["sd"].items()}
+    st = {}
+    losses, norms = [], []
+    for k in range(c["n_steps"]):
+        x, lens, y = c["batch"](k)
+        logits, l, _, gn = O.train_step(sd, x, lens, c["lab"], y, loss="BCE", noise_alpha=20.0, noise_u=c["noises"][k],
+                                        label_token_counts=c["cnt"], adam_state=st)
+        losses.append(float(l))
+        norms.append(float(gn))
+        if k == 0:
+            np.testing.assert_allclose(logits.numpy(), g["step0/logits"], atol=2e-4, rtol=1e-4)
+    # (tiny-batch BatchNorm + Adam amplify f32 reassociation step over step; steps 1-2 are tight)
+    np.testing.assert_allclose(losses[:2], g["losses"][:2], rtol=1e-5)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(norms[:1], g["grad_norms"][:1], rtol=1e-4)
+    n_buf = n_par = 0
+    for key in g.files:
+        if key.startswith("after/buffer/"):
+            name = key[len("after/buffer/"):]
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == int(g[key]), name
+            elif name.startswith("sequence_encoder"):
+                np.testing.assert_allclose(sd[name].numpy(), g[key], atol=2e-6, rtol=1e-5, err_msg=name)
+            else:
+                d = np.abs(sd[name].numpy() - g[key])
+                assert d.mean() < 2e-3 * max(np.abs(g[key]).mean(), 1.0), name
+            n_buf += 1
+        elif key.startswith("after/param_head/"):
+            name = key[len("after/param_head/"):]
+            d = np.abs(sd[name].reshape(-1)[:256].numpy() - g[key])
+            # Adam turns f32-noise-level gradients into +-lr moves of arbitrary sign: hard bound 2 lr steps, mean well below
+            assert d.max() <= 2 * 3e-4 * 4 + 1e-5 and d.mean() <= 0.25 * 3e-4 * 4, (name, d.max(), d.mean())
+            np.testing.assert_allclose(float(sd[name].double().norm()), float(g["after/param_norm/" + name]), rtol=2e-3)
+            n_par += 1
+    assert n_buf > 40 and n_par == 31
+
+
 def test_losses_and_metrics(golden_dir):
     g = _load(golden_dir, "losses_metrics.npz")
     logits = torch.from_numpy(g["logits"])
