@@ -666,10 +666,20 @@ def golden_config0_full_width():
     for n, p in model.named_parameters():
         if n.startswith("sequence_encoder"):
             p.requires_grad = False
+    out = {"losses": [], "grad_norms": []}
+    # inference before any training: the 256 label rows read as 128 labels x 2 descriptions, ensembled (ProtNote.py:313-322)
+    model.eval()
+    model.inference_descriptions_per_label = 2
+    with torch.no_grad():
+        x0, lens0, _ = c["batch"](0)
+        out["eval0/logits_ens2"] = model(sequence_onehots=x0, sequence_lengths=lens0, label_embeddings=c["lab"])[0].numpy().copy()
+        out["eval0/P_f"] = model.sequence_encoder.get_embeddings(x0, lens0).numpy().copy()
+        model.inference_descriptions_per_label = 1
+        out["eval0/logits_raw"] = model(sequence_onehots=x0, sequence_lengths=lens0, label_embeddings=c["lab"])[0].numpy().copy()
+    model.inference_descriptions_per_label = 1
     model.train()
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4)
-    out = {"losses": [], "grad_norms": []}
     real = torch.rand_like
     try:
         for k in range(c["n_steps"]):

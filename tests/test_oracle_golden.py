@@ -173,6 +173,14 @@ def test_oracle_config0_full_width_vs_reference(golden_dir):
     g = _load(golden_dir, "config0_full_width.npz")
     c = config0_case()
     sd = {k: v.clone() for k, v in c["sd"].items()}
+    # inference at the real width (eval-mode BatchNorm, two descriptions per label ensembled), before any training
+    x0, lens0, _ = c["batch"](0)
+    np.testing.assert_allclose(O.proteinfer_get_embeddings(sd, x0, lens0, prefix="sequence_encoder.").numpy(), g["eval0/P_f"],
+                               atol=2e-5, rtol=1e-5)
+    raw = O.protnote_forward(sd, x0, lens0, c["lab"], fusion="concatenation")
+    np.testing.assert_allclose(raw.numpy(), g["eval0/logits_raw"], atol=2e-4, rtol=1e-5)
+    ens = O.protnote_forward(sd, x0, lens0, c["lab"], fusion="concatenation", descriptions_per_label=2)
+    np.testing.assert_allclose(ens.numpy(), g["eval0/logits_ens2"], atol=2e-4, rtol=1e-4)
     st = {}
     losses, norms = [], []
     for k in range(c["n_steps"]):
