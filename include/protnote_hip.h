@@ -155,7 +155,10 @@ int pn_similarity_fwd(const float* P_e, const float* L_e, int B, int NL, int d, 
 
 /* ================================ training path ================================ */
 
-/* gradient destinations (device pointers, each the shape of the matching parameter; NULL = not wanted) */
+/* gradient destinations (device pointers, each the shape of the matching parameter).  NULL = the parameter is frozen
+ * (requires_grad False - e.g. TRAIN_PROJECTION_HEAD: False freezes output_layer.*, ProtNoteTrainer.py:221-222): its
+ * gradient is not computed at all - for a weight that is one whole TN GEMM less - while the data gradient still flows
+ * through the layer to whatever is trainable below it. */
 typedef struct pn_mlp_grads {
   float* dw[PN_MAX_LAYERS];
   float* dgamma[PN_MAX_LAYERS];
@@ -251,6 +254,13 @@ int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* tar
 int pn_clip_adam_step(float* w, const float* g, float* m, float* v, long n, float max_norm, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, float* norm_out, void* ws,
                       size_t ws_bytes, void* stream);
+
+/* OPTIMIZER: SGD (ProtNoteTrainer.py:238-243: torch.optim.SGD(lr, weight_decay), momentum 0) after the same
+ * clip_grad_norm_: g' = coef g + weight_decay w; with momentum != 0 (not used by the reference; torch semantics,
+ * dampening 0, no Nesterov) momentum_buf [n] holds the velocity (step == 1 initialises it), else it may be NULL.
+ * ws: >= PN_ADAM_WS_BYTES. */
+int pn_clip_sgd_step(float* w, const float* g, float* momentum_buf, long n, float max_norm, float lr, float momentum,
+                     float weight_decay, int step, float* norm_out, void* ws, size_t ws_bytes, void* stream);
 
 /* dst[c][r] = src[r][c] (pair-grid <-> [B][N] re-layout of logits / dlogits) */
 int pn_transpose(const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst, void* stream);

@@ -507,9 +507,12 @@ def f1_micro(tp, fn, fp):
     return f1_per_label(tp.sum(), fn.sum(), fp.sum())
 
 
-def trainable_names(sd: SD, train_sequence_encoder: bool = False):
+def trainable_names(sd: SD, train_sequence_encoder: bool = False, train_projection_head: bool = True):
     """ProtNoteTrainer.py:199-226: heads trainable; the encoder only with TRAIN_SEQUENCE_ENCODER (its classifier
-    `sequence_encoder.output_layer` is never reached by get_embeddings, so it gets no gradient either way)."""
+    `sequence_encoder.output_layer` is never reached by get_embeddings, so it gets no gradient either way).
+    TRAIN_PROJECTION_HEAD: False (:216-222) freezes every `output_layer.*` parameter; the reference's other test,
+    name.startswith("W_p.weight") / ("W_l.weight"), is kept literally - no parameter is called that (they are
+    W_p.0.weight, ...), so the projection heads go on training."""
     skip = ("running_mean", "running_var", "num_batches_tracked")
     out = []
     for k in sd:
@@ -518,6 +521,10 @@ def trainable_names(sd: SD, train_sequence_encoder: bool = False):
         if k.startswith("sequence_encoder."):
             if not train_sequence_encoder or k.startswith("sequence_encoder.output_layer."):
                 continue
+        if (k.startswith("W_p.weight") or k.startswith("W_l.weight")) and not train_projection_head:
+            continue
+        if k.startswith("output_layer") and not train_projection_head:
+            continue
         out.append(k)
     return out
 
@@ -528,12 +535,14 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                clip: Optional[float] = 1.0, lr: float = 3e-4, dilation_base: int = 3,
                adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
                train_sequence_encoder: bool = False, attention_mask: Optional[Tensor] = None,
-               dropout_masks: Optional[dict] = None, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
-    """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU).
+               dropout_masks: Optional[dict] = None, train_projection_head: bool = True, optimizer: str = "Adam",
+               weight_decay: float = 0.0, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+    """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU) with the optimiser
+    _set_optimizer built (:230-243): Adam(lr) | AdamW(lr, weight_decay) | SGD(lr, weight_decay) at torch's defaults.
 
-    Updates `sd` in place (params by Adam, BN buffers by the train-mode forward).
+    Updates `sd` in place (params by the optimiser, BN buffers by the train-mode forward).
     Returns (logits, loss, grads, total_grad_norm)."""
-    names = trainable_names(sd, train_sequence_encoder)
+    names = trainable_names(sd, train_sequence_encoder, train_projection_head)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
     work = dict(sd)
     work.update(leaves)
@@ -557,6 +566,11 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
         b1, b2, eps = 0.9, 0.999, 1e-8
         for k, g in grads.items():
             g = g * coef
+            if optimizer == "SGD":  # torch.optim.SGD, momentum 0: p -= lr (g + wd p)
+                sd[k] = sd[k] - lr * (g + weight_decay * sd[k])
+                continue
+            if optimizer == "AdamW":  # decoupled decay before the Adam update
+                sd[k] = sd[k] * (1 - lr * weight_decay)
             m = st.setdefault("m/" + k, torch.zeros_like(g))
             v = st.setdefault("v/" + k, torch.zeros_like(g))
             m.mul_(b1).add_(g, alpha=1 - b1)

@@ -130,6 +130,8 @@ _SIGS = {
     "pn_clip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "pn_clip_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_transpose": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     "pn_gemm_tn": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int,
                              C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -76,6 +76,7 @@ struct Bump {
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing of the GEMM kernels (hipEvents on the launch stream; bench.py roofline)
 // ------------------------------------------------------------------------------------------------
+#include <mutex>
 #include <vector>
 struct ProfRec {
   int kind;  // family*100 + operand kind*10 + epilogue kind  (family 0: NT engine, 1: TN engine)
@@ -84,8 +85,25 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;  // launches may come from several host threads (one stream each)
+
+// HBM-bound streaming passes are timed the same way under kinds >= 2000; their `flops` field carries the pass's
+// ALGORITHMIC BYTES per launch (SURVEY 8d / DESIGN 4.3: what the pass must read + write once), so bench.py can put
+// every stage next to the 8 TB/s HBM roofline.
+enum {
+  ST_CONV1 = 2001,        // K2: one-hots -> conv1 output (NCL->NLC re-layout + the 20-channel conv)
+  ST_POOL = 2002,         // K6: masked mean-pool
+  ST_LOSS = 2003,         // K13/K14: loss + dlogits + TP/FN/FP in one pass
+  ST_CLIP_OPT = 2004,     // K16: sum of squares + clip + Adam / SGD
+  ST_DZ_APPLY = 2005,     // BatchNorm/ReLU backward applied in place
+  ST_BN_BWD_STATS = 2006, // sum du, sum du*xhat over the stored pre-activations
+  ST_PAIR_MASK_REDUCE = 2007,  // layer-1 backward: M0 / M1 tables from one pass over the gradient
+  ST_ROWDOT = 2008,       // logits from the stored top pre-activation
+  ST_CONV_STAGE = 2009    // relu(bn(x)) staged once per convolution for the all-DMA conv kernel
+};
 
 extern "C" int pn_prof_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     hipEventDestroy(r.e0);
     hipEventDestroy(r.e1);
@@ -97,6 +115,7 @@ extern "C" int pn_prof_begin(void) {
 
 // Stops recording and aggregates per kernel kind.  Caller must have synchronised the stream(s).
 extern "C" int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = false;
   int n = 0;
   for (auto& r : g_prof) {
@@ -127,7 +146,7 @@ struct ProfScope {
   bool on;
   ProfRec r;
   hipStream_t st;
-  ProfScope(int kind, double flops, hipStream_t s) : on(g_prof_on && g_prof.size() < 100000), st(s) {
+  ProfScope(int kind, double flops, hipStream_t s) : on(g_prof_on), st(s) {
     if (on) {
       r.kind = kind;
       r.flops = flops;
@@ -139,7 +158,9 @@ struct ProfScope {
   ~ProfScope() {
     if (on) {
       hipEventRecord(r.e1, st);
-      g_prof.push_back(r);
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      if (g_prof.size() < 100000) g_prof.push_back(r);
+      else { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     }
   }
 };
@@ -829,8 +850,6 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   float* x0 = sv ? sv->x0 : w.x0;
 
   hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, lens32, B);
-  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
-                     L, ldi);
   HIP_OK(hipGetLastError());
 
   auto conv = [&](const float* in, int ld_in, const float* wpk, const float* bias, int Cout, int ld_out, float* out,
@@ -849,8 +868,11 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       const int Kpad = round_up(ld_in, 32), G = (ntap / 2) * dil, Lp = L + G, Cpad = round_up(Cout, 192);
       hipLaunchKernelGGL(k_conv_relay_weight, dim3(nblk((long)Cpad * ntap * Kpad, 256)), dim3(256), 0, st, wpk, Cout, ntap,
                          ld_in, w.Wr, Cpad, Kpad);
-      hipLaunchKernelGGL(k_conv_stage_act, dim3(nblk(((long)G + (long)B * Lp) * (Kpad / 4), 256)), dim3(256), 0, st, in,
-                         (long)ld_in, s, t, (const int*)lens32, w.H, Kpad, B, L, Lp, G, ld_in);
+      {  // reads the activation once, writes its staged image (guard rows and K padding included)
+        ProfScope ps(ST_CONV_STAGE, 4.0 * ((double)P * ld_in + ((double)G + (double)B * Lp) * Kpad), st);
+        hipLaunchKernelGGL(k_conv_stage_act, dim3(nblk(((long)G + (long)B * Lp) * (Kpad / 4), 256)), dim3(256), 0, st, in,
+                           (long)ld_in, s, t, (const int*)lens32, w.H, Kpad, B, L, Lp, G, ld_in);
+      }
       HIP_OK(hipGetLastError());
       p.A = w.H + (long)G * Kpad; p.lda = Kpad; p.a_scale = nullptr; p.a_shift = nullptr;
       p.W = w.Wr; p.ldw = (long)ntap * Kpad; p.Kseg = Kpad;
@@ -862,8 +884,14 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   // conv1: MaskedConv1D(Cin -> C, k, dil 1), no BN/ReLU in front (protein_encoders.py:84-91,110)
   float* x = sv ? sv->X[0] : w.xa;
   float* xn = w.xb;
-  PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
-             training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+  {  // K2: 4 B x Cin read + 4 B x C written per residue
+    ProfScope ps(ST_CONV1, (double)P * 4.0 * (e->Cin + e->C), st);
+    hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
+                       L, ldi);
+    HIP_OK(hipGetLastError());
+    PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
+               training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+  }
 
   int dil = 1;
   for (int i = 0; i < e->nblocks; ++i) {
@@ -905,8 +933,11 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     }
     dil *= e->dil_base;
   }
-  hipLaunchKernelGGL(k_pool, dim3(nblk(e->C, 256), B), dim3(256), 0, st, (const float*)x, (const int*)lens32, emb, L,
-                     e->C, ldc, ld_emb);
+  {  // K6: 4 B x C read per residue
+    ProfScope ps(ST_POOL, (double)P * 4.0 * e->C, st);
+    hipLaunchKernelGGL(k_pool, dim3(nblk(e->C, 256), B), dim3(256), 0, st, (const float*)x, (const int*)lens32, emb, L,
+                       e->C, ldc, ld_emb);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1302,6 +1333,8 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
 }
 
 // the specialised f32 kernel of the big weight gradients (gemm_tn_fast.hpp); preconditions checked by launch_tn
+static const int TN_SYNC_INTS = 4096;  // arrival counters of the paced TN kernel: [splits][4 regions][4 rotating]
+
 template <int TB>
 static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   // pacing only for the kind whose second operand streams from HBM too (the pair-sum kind's tables are L2-resident: 0.22 TB)
@@ -1330,19 +1363,16 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
+  int* sync_ws = p.task_sync;  // TN_SYNC_INTS ints of the CALLER's workspace (or NULL: unpaced)
   p.task_sync = nullptr;
   if (p.M == 3072 && p.N == 3072 && ns >= 2) {
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
-    // arrival counters of the region tasks (gemm_tn_fast.hpp): 16 KB per device, allocated once by the library itself -
-    // the one buffer that is not part of a caller-provided workspace (it carries no result, only pacing)
-    static int* ctr[64] = {nullptr};
-    if (SYNC && dev < 64) {
-      if (ctr[dev] == nullptr && hipMalloc((void**)&ctr[dev], 4096 * sizeof(int)) != hipSuccess) ctr[dev] = nullptr;
-      if (ctr[dev] != nullptr && ns * 4 * 4 <= 4096) {
-        HIP_OK(hipMemsetAsync(ctr[dev], 0, (size_t)ns * 4 * 4 * sizeof(int), st));
-        p.task_sync = ctr[dev];
-      }
+    // arrival counters of the region tasks (gemm_tn_fast.hpp): pacing only, they carry no result.  They live in the
+    // workspace of the call that launches the kernel, so two streams (two workspaces) never share them
+    if (SYNC && sync_ws != nullptr && ns * 4 * 4 <= TN_SYNC_INTS) {
+      HIP_OK(hipMemsetAsync(sync_ws, 0, (size_t)ns * 4 * 4 * sizeof(int), st));
+      p.task_sync = sync_ws;
     }
   }
   {
@@ -1495,6 +1525,7 @@ struct MlpTrainWs {
   size_t part_floats;
   ColScr colscr;
   StatScr statscr;
+  int* tnsync;  // pacing counters of the big weight-gradient kernel (launch_tn_fast)
 };
 static const long MLP_STATS_ROWS = 1024;
 
@@ -1520,6 +1551,7 @@ static bool mlp_train_ws_carve(const pn_mlp* m, int rows, Bump& bp, MlpTrainWs& 
   w.part = bp.take<float>(w.part_floats);
   colscr_carve(bp, rows, hmax, w.colscr);
   statscr_carve(bp, rows, MLP_STATS_ROWS, hmax, w.statscr);
+  w.tnsync = bp.take<int>(TN_SYNC_INTS);
   return bp.ok;
 }
 
@@ -1667,7 +1699,7 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
       hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(N, 1024), nblk(rows, 512)), dim3(256), 0, st, dp);
       HIP_OK(hipGetLastError());
     }
-    // dW_l[N][K] = dY_l^T X_l
+    // dW_l[N][K] = dY_l^T X_l   (gr->dw[l] == NULL: frozen weight, no gradient GEMM; the data gradient still flows)
     TnParams tp = tn_zero();
     tp.R = rows; tp.M = N; tp.N = K;
     if (last || mat) {
@@ -1676,16 +1708,20 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
       tp.A = sv.Y[l]; tp.lda = N; tp.G = G; tp.ldg = ldg;
       tp.m_s = sv.s[l]; tp.m_t = sv.t[l]; tp.m_cs = w.cs; tp.m_p = w.p; tp.m_q = w.q;
     }
-    if (l == 0 || drop) {  // plain B operand: the input rows, or the materialised dropped activation H_{l-1}
+    if (gr->dw[l] == nullptr) {
+    } else if (l == 0 || drop) {  // plain B operand: the input rows, or the materialised dropped activation H_{l-1}
       tp.B = l == 0 ? x : sv.H[l - 1]; tp.ldb = l == 0 ? ldx : K;
       if (last || mat) PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
       else PN_OK((launch_tn<TA_DZ_ELEM, TB_PLAIN>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
     } else {
-      tp.B = sv.Y[l - 1]; tp.ldb = K; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
+      tp.B = sv.Y[l - 1]; tp.ldb = K; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1]; tp.task_sync = w.tnsync;
       if (last || mat) PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
       else PN_OK((launch_tn<TA_DZ_ELEM, TB_AFFINE_RELU>(tp, gr->dw[l], K, w.part, w.part_floats, st)));
     }
-    // dX_l[rows][K] = dY_l W_l   (NT engine against W_l^T)
+    // dX_l[rows][K] = dY_l W_l   (NT engine against W_l^T); nothing below this layer wants a gradient -> done
+    bool below = dx != nullptr;
+    for (int k = 0; k < l; ++k) below = below || gr->dw[k] || gr->dgamma[k] || gr->dbeta[k];
+    if (!below) break;
     if (l > 0 || dx != nullptr) {
       PN_OK(transpose_into(m->w[l], K, N, K, w.WT, N, st));  // WT[K][N]
       GemmParams p = gp_zero();
@@ -1745,6 +1781,7 @@ struct PairTrainWs {
   ColScr colscr;
   StatScr statscr;
   uint16_t* wsplit;  // bf16x3 mode: hi / lo planes of the weight operand of the current pair-grid GEMM
+  int* tnsync;       // pacing counters of the big weight-gradient kernel (launch_tn_fast)
 };
 static const long PAIR_STATS_ROWS = 4096;
 static const int SUM_BLOCKS = 1024;
@@ -1780,6 +1817,7 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   colscr_carve(bp, (long)B * NL, h, w.colscr);
   statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
+  w.tnsync = bp.take<int>(TN_SYNC_INTS);
   return bp.ok;
 }
 
@@ -1928,6 +1966,7 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
   }
   if (h <= 3072) {
     const int rpw = 32;  // rows per wave: 128 rows (1.5 MB) per workgroup
+    ProfScope ps(ST_ROWDOT, (double)R * (4.0 * h + 4.0), st);
     hipLaunchKernelGGL(k_rowdot_rows_reg, dim3(nblk(R, 4 * rpw)), dim3(256), 0, st,
                        (const float*)(sv.zbuf[n - 1] + (size_t)S * h), (long)h, R, h, (const float*)sv.s[n - 1],
                        (const float*)sv.t[n - 1], hd->w_out, hd->b_out, logits_pairs, rpw);
@@ -1956,10 +1995,15 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   if (!pair_train_ws_carve(hd, B, NL, bw, w)) return fail("pairhead bwd: workspace too small");
 
   // d b_out = sum_r dl[r]
-  hipLaunchKernelGGL(k_sum, dim3(SUM_BLOCKS), dim3(256), 0, st, dl_pairs, R, w.scal + 4);
-  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(w.scal + 4), SUM_BLOCKS, w.scal);
-  hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)w.scal, gr->db_out, 1, 1.f);
-  HIP_OK(hipGetLastError());
+  // (a NULL destination in `gr` = that parameter is frozen, e.g. TRAIN_PROJECTION_HEAD: False freezes output_layer.*,
+  //  ProtNoteTrainer.py:221-222: its gradient is not computed - for a weight that is one whole pair-grid TN GEMM less -
+  //  while the data gradient dh still flows through the layer)
+  if (gr->db_out != nullptr) {
+    hipLaunchKernelGGL(k_sum, dim3(SUM_BLOCKS), dim3(256), 0, st, dl_pairs, R, w.scal + 4);
+    hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(w.scal + 4), SUM_BLOCKS, w.scal);
+    hipLaunchKernelGGL(k_d2f, dim3(1), dim3(64), 0, st, (const double*)w.scal, gr->db_out, 1, 1.f);
+    HIP_OK(hipGetLastError());
+  }
 
   const float* G = nullptr;  // gradient wrt relu(bn(z_l)) for the layer being processed (rows [0,R) of a zbuf)
   const long stats_rows = PAIR_STATS_ROWS;
@@ -1975,11 +2019,17 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     const dim3 sg(nblk(h, 1024), nblk(R, stats_rows));
     if (top) {
       sp.gvec = dl_pairs; sp.w = hd->w_out;
-      hipLaunchKernelGGL((k_bn_bwd_stats<1, 0>), sg, dim3(256), 0, st, sp);
+      {
+        ProfScope ps(ST_BN_BWD_STATS, (double)R * (4.0 * h + 4.0), st);  // reads z (+ one dl per row)
+        hipLaunchKernelGGL((k_bn_bwd_stats<1, 0>), sg, dim3(256), 0, st, sp);
+      }
       PN_OK(reduce_parts<double>(w.statscr.part, sg.y, 3 * h, h, w.S1, w.S2, w.dwacc, w.statscr.red, st));
     } else {
       sp.G = G; sp.ldg = h;
-      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), sg, dim3(256), 0, st, sp);
+      {
+        ProfScope ps(ST_BN_BWD_STATS, (double)R * 8.0 * h, st);  // reads z and the incoming gradient
+        hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), sg, dim3(256), 0, st, sp);
+      }
       PN_OK(reduce_parts<double>(w.statscr.part, sg.y, 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
     }
     PN_OK(bwd_finalize(st, (const double*)w.S1,
@@ -2000,9 +2050,11 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       const dim3 dg(nblk(h, 1024), nblk(R, 512));
       if (top) {
         dp.gvec = dl_pairs; dp.out = z; dz = z;
+        ProfScope ps(ST_DZ_APPLY, (double)R * (8.0 * h + 4.0), st);  // z read, dz written over it
         hipLaunchKernelGGL((k_dz_apply<1>), dg, dim3(256), 0, st, dp);
       } else {
         dp.G = G; dp.ldg = h; dp.out = const_cast<float*>(G); dz = const_cast<float*>(G);
+        ProfScope ps(ST_DZ_APPLY, (double)R * 12.0 * h, st);  // z and G read, dz written over G
         hipLaunchKernelGGL((k_dz_apply<0>), dg, dim3(256), 0, st, dp);
       }
       HIP_OK(hipGetLastError());
@@ -2014,11 +2066,14 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     tp.A = dz; tp.lda = h;
     const DropSpec ds_in = drop_spec(hd->dropout_p, hd->dropout_seed, DROP_STREAM_PAIR + (l - 1));
     tp.drop_seed = ds_in.seed; tp.drop_thresh = ds_in.thresh; tp.drop_scale = ds_in.scale;
-    if (l == 1 && hd->fusion != 2) {
+    if (gr->dw[l] == nullptr) {
+      // frozen weight: no dW GEMM
+    } else if (l == 1 && hd->fusion != 2) {
       tp.B = sv.Ap; tp.ldb = h; tp.B2 = sv.Bp; tp.ldb2 = h; tp.pairB = B;
       PN_OK((launch_tn<TA_PLAIN, TB_PAIRSUM_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
     } else {
       tp.B = sv.zbuf[l - 1] + (size_t)S * h; tp.ldb = h; tp.b_s = sv.s[l - 1]; tp.b_t = sv.t[l - 1];
+      tp.task_sync = w.tnsync;
       PN_OK((launch_tn<TA_PLAIN, TB_AFFINE_RELU>(tp, gr->dw[l], h, w.part, w.part_floats, st)));
     }
 
@@ -2056,7 +2111,10 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     if (w.m1part != nullptr) {  // B <= 256: both tables from one pass over the gradient
       const int per = (NL + w.m1_chunks - 1) / w.m1_chunks;
       const int nch = (NL + per - 1) / per;
-      hipLaunchKernelGGL(k_pair_mask_reduce_fused, dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part, per);
+      {
+        ProfScope ps(ST_PAIR_MASK_REDUCE, (double)R * 4.0 * h, st);  // one read of the 101 GB gradient
+        hipLaunchKernelGGL(k_pair_mask_reduce_fused, dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part, per);
+      }
       hipLaunchKernelGGL(k_pair_m1_reduce, dim3(nblk((long)B * h / 4, 256)), dim3(256), 0, st, (const float*)w.m1part, nch,
                          (long)B * h, h, w.dA1, (long)h);
     } else {
@@ -2117,10 +2175,12 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
                        (const float*)nullptr, 0L, w.dA1, (long)h, 0);
     HIP_OK(hipGetLastError());
     // dW1c[n][k] = sum_r dz1[r][n] * P_e[i][k] * L_e[j][k]
-    TnParams tp = tn_zero();
-    tp.R = R; tp.M = h; tp.N = d; tp.A = dz0; tp.lda = h;
-    tp.B = P_e; tp.ldb = d; tp.B2 = L_e; tp.ldb2 = d; tp.pairB = B;
-    PN_OK((launch_tn<TA_PLAIN, TB_PAIRPROD>(tp, gr->dw[0] + 2 * d, hd->in_dim, w.part, w.part_floats, st)));
+    if (gr->dw[0] != nullptr) {
+      TnParams tp = tn_zero();
+      tp.R = R; tp.M = h; tp.N = d; tp.A = dz0; tp.lda = h;
+      tp.B = P_e; tp.ldb = d; tp.B2 = L_e; tp.ldb2 = d; tp.pairB = B;
+      PN_OK((launch_tn<TA_PLAIN, TB_PAIRPROD>(tp, gr->dw[0] + 2 * d, hd->in_dim, w.part, w.part_floats, st)));
+    }
     // dQ = dz1 W1c  ([R][d], over the dead z1 buffer)
     dQ = sv.zbuf[0];
     PN_OK(transpose_into(hd->w[0] + 2 * d, hd->in_dim, h, d, w.WT, h, st));  // WT[d][h]
@@ -2132,7 +2192,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   // dW_0: [h][in_dim];  concatenation: [dA1^T P_e | dB1^T L_e]
   float* dwa = hd->fusion == 1 ? w.dweff : gr->dw[0];
   const long ldd = hd->fusion == 1 ? 2 * d : hd->in_dim;
-  {
+  if (gr->dw[0] != nullptr) {
     TnParams tp = tn_zero();
     tp.R = B; tp.M = h; tp.N = d; tp.A = w.dA1; tp.lda = h; tp.B = P_e; tp.ldb = d;
     PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, dwa, ldd, w.part, w.part_floats, st)));
@@ -2142,8 +2202,9 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   const float* w1 = hd->w[0];
   long ldw1 = hd->in_dim;
   if (hd->fusion == 1) {
-    hipLaunchKernelGGL(k_diff_weight_grad, dim3(nblk((long)h * d, 256)), dim3(256), 0, st, (const float*)w.dweff,
-                       gr->dw[0], h, d);
+    if (gr->dw[0] != nullptr)
+      hipLaunchKernelGGL(k_diff_weight_grad, dim3(nblk((long)h * d, 256)), dim3(256), 0, st, (const float*)w.dweff,
+                         gr->dw[0], h, d);
     hipLaunchKernelGGL(k_diff_weight, dim3(nblk((long)h * 2 * d, 256)), dim3(256), 0, st, hd->w[0], w.weff, h, d);
     HIP_OK(hipGetLastError());
     w1 = w.weff;
@@ -2212,7 +2273,10 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
       p.row_w = row_w;
     }
   }
-  hipLaunchKernelGGL(k_loss, lgrid, dim3(256), 0, st, p);
+  {  // K13/K14: 4 B logit + target (1 B algorithmically; this ABI takes f32 or i64) read, 4 B gradient written
+    ProfScope ps(ST_LOSS, (double)B * (double)N * (dlogits ? 9.0 : 5.0), st);
+    hipLaunchKernelGGL(k_loss, lgrid, dim3(256), 0, st, p);
+  }
   hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)lpart, (int)(lgrid.x * lgrid.y), acc);
   if (rgd_temperature >= 0.f)
     hipLaunchKernelGGL(k_rgd_scale, dim3(dlogits ? 1024 : 1), dim3(256), 0, st, (const double*)acc,
@@ -2261,12 +2325,30 @@ extern "C" int pn_clip_adam_step(float* w, const float* g, float* m, float* v, l
   if (ws_bytes < PN_ADAM_WS_BYTES) return fail("adam: workspace too small (need %d bytes)", PN_ADAM_WS_BYTES);
   if (step < 1) return fail("adam: step must be >= 1");
   double* acc = (double*)ws;  // [0] sum of squares, [32..) one partial per workgroup of k_sumsq
+  ProfScope ps(ST_CLIP_OPT, 28.0 * (double)n, st);  // K16: p, g, m, v read (16 B) + p, m, v written (12 B) per parameter
   hipLaunchKernelGGL(k_sumsq, dim3(2048), dim3(256), 0, st, g, n, acc + 32);
   hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(acc + 32), 2048, acc);
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(k_adam, dim3(2048), dim3(256), 0, st, w, g, m, v, n, (const double*)acc, max_norm, lr, beta1,
                      beta2, eps, bc1, bc2s, weight_decay, norm_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_clip_sgd_step(float* w, const float* g, float* momentum_buf, long n, float max_norm, float lr,
+                                float momentum, float weight_decay, int step, float* norm_out, void* ws,
+                                size_t ws_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ws_bytes < PN_ADAM_WS_BYTES) return fail("sgd: workspace too small (need %d bytes)", PN_ADAM_WS_BYTES);
+  if (step < 1) return fail("sgd: step must be >= 1");
+  if (momentum != 0.f && momentum_buf == nullptr) return fail("sgd: momentum %g needs a momentum buffer", momentum);
+  double* acc = (double*)ws;
+  ProfScope ps(ST_CLIP_OPT, (momentum != 0.f ? 20.0 : 12.0) * (double)n, st);  // p, g (, buf) read + p (, buf) written
+  hipLaunchKernelGGL(k_sumsq, dim3(2048), dim3(256), 0, st, g, n, acc + 32);
+  hipLaunchKernelGGL(k_scalar_final, dim3(1), dim3(256), 0, st, (const double*)(acc + 32), 2048, acc);
+  hipLaunchKernelGGL(k_sgd, dim3(2048), dim3(256), 0, st, w, g, momentum != 0.f ? momentum_buf : (float*)nullptr, n,
+                     (const double*)acc, max_norm, lr, momentum, weight_decay, step == 1 ? 1 : 0, norm_out);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -1002,4 +1002,27 @@ __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float
   }
 }
 
+// torch.optim.SGD(lr, momentum, weight_decay) after the same clipping (ProtNoteTrainer.py:238-243 builds it with the
+// defaults momentum = 0, dampening = 0, nesterov = False): g' = coef g + wd w; buf = g' on the first step, else
+// momentum buf + g'; w -= lr (buf | g').
+__global__ void k_sgd(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ buf, long n,
+                      const double* sumsq, float max_norm, float lr, float momentum, float weight_decay, int first,
+                      float* norm_out) {
+  float coef = 1.f;
+  const float norm = sumsq ? (float)sqrt(*sumsq) : 0.f;
+  if (sumsq && max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float wi = w[i];
+    float gi = g[i] * coef;
+    if (weight_decay != 0.f) gi = gi + weight_decay * wi;
+    if (buf != nullptr) {
+      gi = first ? gi : momentum * buf[i] + gi;
+      buf[i] = gi;
+    }
+    w[i] = wi - lr * gi;
+  }
+}
+
 }  // namespace pn

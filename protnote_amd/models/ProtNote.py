@@ -220,7 +220,10 @@ class ProtNote(nn.Module):
     def _w_l_state_key(self):
         from ..utils.optim import weights_generation
 
-        vs = tuple((t.data_ptr(), t._version) for t in list(self.W_l.parameters()) + list(self.W_l.buffers()))
+        ts = list(self.W_l.parameters()) + list(self.W_l.buffers())
+        if any(t.is_inference() for t in ts):  # no version counters (model built under torch.inference_mode()): no cache
+            return None
+        vs = tuple((t.data_ptr(), t._version) for t in ts)
         return (weights_generation(), L.get_math_mode(), vs)
 
     def _label_projection_eval(self, label_embeddings):
@@ -232,11 +235,17 @@ class ProtNote(nn.Module):
         unchanged; train()/eval() switches clear it.  A fresh tensor per call simply recomputes, as the reference does."""
         cache = self.__dict__.setdefault("_pn_le_cache", {})
         t = label_embeddings
-        if int(self.label_projection_cache_size) <= 0:  # cache off: recompute per call, like the reference
-            cache.clear()
+        if int(self.label_projection_cache_size) <= 0 or t.is_inference():
+            # cache off: recompute per call, like the reference.  Tensors created under torch.inference_mode() carry no
+            # version counter, so an in-place edit of such a table could not be noticed: never cached
+            if int(self.label_projection_cache_size) <= 0:
+                cache.clear()
             return self._project_eval(self.W_l, t.detach().float().contiguous())
         key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
-        state = (t._version, self._w_l_state_key())
+        wkey = self._w_l_state_key()
+        if wkey is None:
+            return self._project_eval(self.W_l, t.detach().float().contiguous())
+        state = (t._version, wkey)
         hit = cache.get(key)
         if hit is not None and hit[0] is t and hit[1] == state:
             cache[key] = cache.pop(key)  # most recently used last

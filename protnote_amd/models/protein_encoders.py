@@ -67,10 +67,11 @@ class ProteInfer(torch.nn.Module):
     # ---- weight packing: torch [Cout][Cin][k] -> [Cout][k][ld4(Cin)] (pn_pack_conv_weight) ----
     def _pack(self, name: str, conv: torch.nn.Conv1d) -> torch.Tensor:
         w = conv.weight
-        key = (w._version, w.data_ptr(), w.device)
+        # (inference tensors carry no version counter: repacked on every call, 11 small launches)
+        key = None if w.is_inference() else (w._version, w.data_ptr(), w.device)
         hit = self._packed.get(name)
         # a trainable weight may be updated through raw pointers (FusedClipAdam) without a version bump: repack
-        if hit is not None and hit[0] == key and not w.requires_grad:
+        if key is not None and hit is not None and hit[0] == key and not w.requires_grad:
             return hit[1]
         cout, cin, k = w.shape
         packed = torch.empty(cout, k, _ld4(cin), dtype=torch.float32, device=w.device)
@@ -143,8 +144,10 @@ class ProteInfer(torch.nn.Module):
         return emb
 
     def _bump_batches_tracked(self):
-        torch._foreach_add_([bn.num_batches_tracked for blk in self.resnet_blocks
-                             for bn in (blk.bn_activation_1[0], blk.bn_activation_2[0])], 1)  # one multi-tensor launch
+        tracked = [bn.num_batches_tracked for blk in self.resnet_blocks
+                   for bn in (blk.bn_activation_1[0], blk.bn_activation_2[0])]
+        if tracked:  # num_resnet_blocks == 0: no BatchNorm at all
+            torch._foreach_add_(tracked, 1)  # one multi-tensor launch
 
     def forward(self, x, sequence_lengths):
         """Reference protein_encoders.py:120-123: Linear(C -> num_labels) on the pooled features."""

@@ -88,7 +88,8 @@ class _HeadsTrainFn(torch.autograd.Function):
         tracked = [bn.num_batches_tracked for _, bn in lp + ll if bn is not None]
 
         if model.feature_fusion == "similarity":
-            torch._foreach_add_(tracked, 1)
+            if tracked:  # PROJECTION_HEAD_NUM_LAYERS: 1 -> no BatchNorm in W_p / W_l
+                torch._foreach_add_(tracked, 1)
             return model._similarity(P_e, L_e)
         hd, hl = model._pair_desc(seed)
         chunk = model._train_chunk(B, NL)
@@ -124,8 +125,13 @@ class _HeadsTrainFn(torch.autograd.Function):
         dlogits = dlogits.contiguous().float()
 
         grads = {}
+        # parameters with requires_grad False (TRAIN_PROJECTION_HEAD: False -> output_layer.*, ProtNoteTrainer.py:221-222,
+        # or frozen by hand) get a NULL destination: the C side then skips their gradient GEMMs / reductions entirely
+        wanted = {id(p) for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]) if need}
 
         def gbuf(p):
+            if id(p) not in wanted:
+                return None
             g = torch.empty_like(p, memory_format=torch.contiguous_format)
             grads[id(p)] = g
             return g.data_ptr()

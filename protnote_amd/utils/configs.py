@@ -82,16 +82,16 @@ def build_models(config: dict, num_labels: int = None, label_encoder=None, featu
 
 def build_training(config: dict, model, world_size: int = 1):
     """Loss, optimiser and epoch driver from the `params` section, as ProtNoteTrainer.__init__ / _set_optimizer read it
-    (ProtNoteTrainer.py:89-245): LOSS_FN (+ FOCAL_LOSS_*, BCE_POS_WEIGHT, LABEL_SMOOTHING), OPTIMIZER (Adam | AdamW;
-    WEIGHT_DECAY only for AdamW), LEARNING_RATE, CLIP_VALUE (null = no clipping), GRADIENT_ACCUMULATION_STEPS,
-    DECISION_TH.  The encoder joins the optimiser's parameter list only with TRAIN_SEQUENCE_ENCODER.
+    (ProtNoteTrainer.py:89-245): LOSS_FN (+ FOCAL_LOSS_*, BCE_POS_WEIGHT, LABEL_SMOOTHING), OPTIMIZER (Adam | AdamW | SGD;
+    WEIGHT_DECAY for AdamW and SGD), LEARNING_RATE, CLIP_VALUE (null = no clipping), GRADIENT_ACCUMULATION_STEPS,
+    DECISION_TH, TRAIN_SEQUENCE_ENCODER, TRAIN_PROJECTION_HEAD (False freezes output_layer.* only, as in the reference).
     Returns (loss_fn, optimizer, trainer); `trainer.evaluate(loader, estimate_map=params['ESTIMATE_MAP'])`."""
     import torch
 
     from ..models.ProtNoteTrainer import Trainer
     from ..models.train_path import trainable_parameters
     from .losses import get_loss
-    from .optim import FusedClipAdam
+    from .optim import FusedClipAdam, FusedClipSGD
 
     p = config["params"]
     if p.get("SYNC_BN", False) and world_size > 1:
@@ -103,24 +103,36 @@ def build_training(config: dict, model, world_size: int = 1):
             raise RuntimeError("SYNC_BN: True with world_size > 1 needs an initialised torch.distributed process group")
     loss_fn = get_loss(config, bce_pos_weight=torch.tensor(float(p.get("BCE_POS_WEIGHT", 1))))
     name = p.get("OPTIMIZER", "Adam")
-    if name not in ("Adam", "AdamW"):
-        raise NotImplementedError(f"OPTIMIZER={name}: the fused optimiser implements Adam and AdamW")
+    if name not in ("Adam", "AdamW", "SGD"):
+        raise ValueError("Unsupported optimizer name")  # ProtNoteTrainer.py:244-245
     params = list(trainable_parameters(model))  # heads (+ raw_attn_scorer with LABEL_EMBEDDING_POOLING_METHOD: all)
     train_enc = bool(p.get("TRAIN_SEQUENCE_ENCODER", False))
     if train_enc:
         params += list(model.sequence_encoder.trunk_parameters())
-    # requires_grad as _set_optimizer leaves it (ProtNoteTrainer.py:210-226), then the ids torch.optim.Adam would give the
-    # parameters: position in named_parameters() filtered by requires_grad (sequence_encoder - classifier included - before
-    # W_p, W_l, raw_attn_scorer, output_layer), so optimizer_state_dict of a reference checkpoint loads by id
+    # requires_grad as _set_optimizer leaves it (ProtNoteTrainer.py:210-226) - that loop only ever clears the flag - then
+    # the ids torch.optim.Adam would give the parameters: position in named_parameters() filtered by requires_grad
+    # (sequence_encoder - classifier included - before W_p, W_l, raw_attn_scorer, output_layer), so optimizer_state_dict
+    # of a reference checkpoint loads by id.
+    # TRAIN_PROJECTION_HEAD: False freezes exactly what the reference freezes: every output_layer.* parameter (:221-222).
+    # Its other test, name.startswith("W_p.weight") / ("W_l.weight") (:216-219), matches no parameter of the model (the
+    # names are W_p.0.weight ...), so W_p and W_l KEEP training - reproduced as is.
+    train_head = bool(p.get("TRAIN_PROJECTION_HEAD", True))
     for n_, q_ in model.named_parameters():
-        if n_.startswith("sequence_encoder"):
-            q_.requires_grad = train_enc
+        if n_.startswith("sequence_encoder") and not train_enc:
+            q_.requires_grad = False
+        if (n_.startswith("W_p.weight") or n_.startswith("W_l.weight")) and not train_head:
+            q_.requires_grad = False
+        if n_.startswith("output_layer") and not train_head:
+            q_.requires_grad = False
+    params = [q_ for q_ in params if q_.requires_grad]  # the frozen stacks cost nothing: no gradient GEMMs, no state
     order = {id(q_): k for k, q_ in enumerate(q_ for _, q_ in model.named_parameters() if q_.requires_grad)}
     clip = p.get("CLIP_VALUE", 1)
-    opt = FusedClipAdam(params, lr=p.get("LEARNING_RATE", 3e-4),
-                        weight_decay=p.get("WEIGHT_DECAY", 0.0) if name == "AdamW" else 0.0,
-                        max_norm=None if clip is None else float(clip),
-                        param_ids=[order[id(q_)] for q_ in params], n_param_ids=len(order))
+    common = dict(lr=p.get("LEARNING_RATE", 3e-4), max_norm=None if clip is None else float(clip),
+                  param_ids=[order[id(q_)] for q_ in params], n_param_ids=len(order))
+    if name == "SGD":  # torch.optim.SGD(trainable, lr, weight_decay=WEIGHT_DECAY), :238-243
+        opt = FusedClipSGD(params, weight_decay=p.get("WEIGHT_DECAY", 0.0), **common)
+    else:              # Adam ignores WEIGHT_DECAY (:230-231), AdamW decouples it (:232-237)
+        opt = FusedClipAdam(params, weight_decay=p.get("WEIGHT_DECAY", 0.0) if name == "AdamW" else 0.0, **common)
     th = p.get("DECISION_TH", 0.5)
     trainer = Trainer(model, loss_fn, opt, world_size=world_size, threshold=0.5 if th is None else th,
                       gradient_accumulation_steps=p.get("GRADIENT_ACCUMULATION_STEPS", 1))

@@ -131,8 +131,15 @@ class FusedClipAdam:
             self.flat_v.copy_(sd["exp_avg_sq"])
             return
         ids = [i for g in sd["param_groups"] for i in g["params"]]
-        if len(ids) != self.n_param_ids:
-            raise ValueError(f"optimizer state has {len(ids)} parameters, this optimiser's id space {self.n_param_ids}")
+        if len(ids) == self.n_param_ids:
+            slots = self.param_ids  # the reference's id space (position in its requires_grad-filtered parameter list)
+        elif len(ids) == len(self.params):
+            # rounds 1-2 of this framework numbered the parameters by their position in ITS OWN list; the two spaces only
+            # differ under TRAIN_SEQUENCE_ENCODER (the reference's list also holds the never-trained ProteInfer classifier)
+            slots = list(range(len(self.params)))
+        else:
+            raise ValueError(f"optimizer state has {len(ids)} parameters; expected {self.n_param_ids} (the reference's "
+                             f"parameter list) or {len(self.params)} (this optimiser's own, the pre-round-3 layout)")
         _bump_generation()
         g0 = sd["param_groups"][0]
         self.lr, self.betas, self.eps = g0["lr"], tuple(g0["betas"]), g0["eps"]
@@ -141,7 +148,7 @@ class FusedClipAdam:
         with torch.no_grad():
             self.flat_m.zero_()
             self.flat_v.zero_()
-            for k, (p, off) in zip(self.param_ids, self._offsets()):
+            for k, (p, off) in zip(slots, self._offsets()):
                 pid = ids[k]
                 st = sd["state"].get(pid)
                 if st is None:
@@ -155,3 +162,64 @@ class FusedClipAdam:
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused step keeps one count")
         self.step_count = steps.pop() if steps else 0
+
+
+class FusedClipSGD(FusedClipAdam):
+    """OPTIMIZER: SGD - clip_grad_norm_ + torch.optim.SGD(lr, weight_decay) (reference ProtNoteTrainer.py:238-243, which
+    leaves momentum / dampening / nesterov at torch's defaults 0 / 0 / False) on the same flat buffers: two kernels per
+    step, one RCCL all-reduce of the flat gradient.  `momentum` != 0 follows torch (velocity in flat_m)."""
+
+    def __init__(self, params, lr=3e-4, momentum=0.0, weight_decay=0.0, max_norm=1.0, param_ids=None, n_param_ids=None):
+        super().__init__(params, lr=lr, weight_decay=weight_decay, max_norm=max_norm, param_ids=param_ids,
+                         n_param_ids=n_param_ids)
+        self.momentum = float(momentum)
+        self.flat_v = None  # no second moment
+        if self.momentum == 0.0:
+            self.flat_m = None
+
+    def step(self):
+        for p, off in self._offsets():
+            if p.data_ptr() != self.flat_w.data_ptr() + 4 * off:
+                raise RuntimeError("FusedClipSGD: a parameter no longer aliases the flat weight buffer (the model was "
+                                   "moved / cast / re-assigned after the optimiser was built); rebuild the optimiser, "
+                                   "or call repack()")
+        self.step_count += 1
+        _bump_generation()
+        ws = L.workspace(L.PN_ADAM_WS_BYTES, self.flat_w.device, "adam")
+        max_norm = -1.0 if self.max_norm is None else float(self.max_norm)
+        L.check(L.lib().pn_clip_sgd_step(L.ptr(self.flat_w), L.ptr(self.flat_g), L.ptr(self.flat_m),
+                                         self.flat_w.numel(), max_norm, float(self.lr), self.momentum,
+                                         float(self.weight_decay), self.step_count, L.ptr(self.last_grad_norm),
+                                         L.ptr(ws), ws.numel(), L.stream_ptr()))
+
+    def state_dict(self):
+        """torch.optim.SGD.state_dict() layout for the reference's parameter list."""
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in zip(self.param_ids, self._offsets()):
+                buf = None if self.flat_m is None else self.flat_m[off:off + p.numel()].view_as(p).clone()
+                state[i] = {"momentum_buffer": buf}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
+                 "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(self.n_param_ids))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != self.n_param_ids:
+            raise ValueError(f"optimizer state has {len(ids)} parameters, this optimiser's id space {self.n_param_ids}")
+        g0 = sd["param_groups"][0]
+        if float(g0.get("momentum", 0.0)) != self.momentum:
+            raise ValueError(f"optimizer state was written with momentum {g0.get('momentum')}, this one has {self.momentum}")
+        self.lr, self.weight_decay = g0["lr"], g0.get("weight_decay", 0.0)
+        seen = False
+        with torch.no_grad():
+            for k, (p, off) in zip(self.param_ids, self._offsets()):
+                st = sd["state"].get(ids[k])
+                if st is None:
+                    continue
+                seen = True
+                if self.flat_m is not None and st.get("momentum_buffer") is not None:
+                    self.flat_m[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
+        # torch's SGD keeps no step count; the fused kernel only needs "first step or not" for the velocity
+        self.step_count = 1 if seen else 0

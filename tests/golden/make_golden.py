@@ -711,6 +711,154 @@ def golden_config0_full_width():
     print("config0_full_width.npz", os.path.getsize(os.path.join(OUT, "config0_full_width.npz")) // 1024, "KiB", out["losses"])
 
 
+def golden_optimizer_branches():
+    """Every branch of ProtNoteTrainer._set_optimizer (ProtNoteTrainer.py:199-245) driven by the REFERENCE'S OWN trainer:
+    the real ProtNoteTrainer is constructed from a config dict (so _set_optimizer picks what is frozen and which torch
+    optimiser is built) and its real train_one_epoch (:675-825) runs 10 batches - TRAIN_PROJECTION_HEAD True / False x
+    OPTIMIZER Adam / AdamW / SGD (WEIGHT_DECAY 0.01), clip 1, label noise fed from seeded draws.  Stored per case: the
+    names the reference left trainable, the first batch's logits, every batch's loss, the epoch's train metrics and the
+    whole state dict after the epoch.  (torcheval's Mean / sync_and_compute and the torchmetrics collection - absent
+    here, off the arithmetic path - are stood in by a running mean and an empty collection.)"""
+    import json
+    import logging
+    import tempfile
+    import warnings
+
+    import torch.distributed as dist
+
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.losses import get_loss
+    import protnote.models.ProtNote as PN
+    import protnote.models.ProtNoteTrainer as PT
+
+    class _Mean:
+        def __init__(self, device=None):
+            self.s, self.n = 0.0, 0
+
+        def update(self, v):
+            self.s += float(v)
+            self.n += 1
+
+        def compute(self):
+            return torch.tensor(self.s / max(self.n, 1))
+
+    class _NoMetrics(dict):
+        def reset(self):
+            pass
+
+        def __call__(self, *a, **k):
+            pass
+
+        def compute(self):
+            return {}
+
+    PT.Mean = _Mean
+    PT.sync_and_compute = lambda m: m.compute()
+
+    enc_cfg = dict(num_labels=7, input_channels=20, output_channels=28, kernel_size=9,
+                   dilation_base=3, num_resnet_blocks=2, bottleneck_factor=0.5)
+    head_cfg = dict(protein_embedding_dim=28, label_embedding_dim=24, latent_dim=16,
+                    output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                    outout_mlp_add_batchnorm=True, projection_head_num_layers=4,
+                    projection_head_hidden_dim_scale_factor=3, dropout=0.0,
+                    label_embedding_noising_alpha=20.0, temperature=0.07)
+    g = torch.Generator().manual_seed(2024)
+    torch.manual_seed(5)
+
+    def build():
+        return ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg), label_encoder=torch.nn.Identity(),
+                        feature_fusion="concatenation", inference_descriptions_per_label=1, **head_cfg)
+
+    model0 = build()
+    randomize_(model0, g)
+    n_batches, B, n_labels, lmax = 10, 6, 12, 40
+    lab = torch.randn(n_labels, 24, generator=g)
+    cnt = torch.randint(3, 30, (n_labels,), generator=g)
+    batches, noises = [], []
+    for k in range(n_batches):
+        lens = torch.randint(1, lmax + 1, (B,), generator=g)
+        lens[0] = lmax
+        x, _ = onehots(g, lens.tolist(), lmax)
+        y = (torch.rand(B, n_labels, generator=g) < 0.3).to(torch.int64)
+        batches.append({"sequence_onehots": x, "sequence_lengths": lens, "label_multihots": y, "label_embeddings": lab,
+                        "label_token_counts": cnt})
+        noises.append(torch.rand(lab.shape, generator=g))
+
+    class _Loader(list):
+        pass
+
+    out = {"n_batches": np.array(n_batches)}
+    out.update({"enc_cfg_" + k: np.array(v) for k, v in enc_cfg.items()})
+    out.update({"head_cfg_" + k: np.array(v) for k, v in head_cfg.items()})
+    out["fusion"] = np.array("concatenation")
+    out.update(sd_np(model0, "sd/"))
+    out["label_embeddings"], out["label_token_counts"] = lab.numpy(), cnt.numpy()
+    for k, b in enumerate(batches):
+        out[f"batch{k}/x"], out[f"batch{k}/lens"], out[f"batch{k}/multihots"] = (
+            b["sequence_onehots"].numpy(), b["sequence_lengths"].numpy(), b["label_multihots"].numpy())
+        out[f"batch{k}/noise_u"] = noises[k].numpy()
+
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "parenthood.json"), "w") as f:
+        json.dump({}, f)
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(tmp, "pg"), rank=0, world_size=1)
+    real_rand_like = torch.rand_like
+    cases = {"adam": ("Adam", True), "adam_frozen_head": ("Adam", False), "adamw": ("AdamW", True),
+             "sgd": ("SGD", True), "sgd_frozen_head": ("SGD", False)}
+    try:
+        for case, (opt_name, train_head) in cases.items():
+            params = {"NUM_EPOCHS": 1, "TRAIN_SEQUENCE_ENCODER": False, "LABEL_ENCODER_NUM_TRAINABLE_LAYERS": 0,
+                      "TRAIN_PROJECTION_HEAD": train_head, "NORMALIZE_PROBABILITIES": False, "EPOCHS_PER_VALIDATION": 1,
+                      "GRADIENT_ACCUMULATION_STEPS": 1, "CLIP_VALUE": 1, "LORA": False, "LABEL_EMBEDDING_DIM": 24,
+                      "OPTIMIZER": opt_name, "LEARNING_RATE": 0.003, "WEIGHT_DECAY": 0.01, "DECISION_TH": 0.5,
+                      "LOSS_FN": "BCE", "BCE_POS_WEIGHT": 1}
+            cfg = {"params": params, "paths": {"PARENTHOOD_LIB_PATH": os.path.join(tmp, "parenthood.json"),
+                                               "OUTPUT_MODEL_DIR": os.path.join(tmp, "ckpt")}}
+            model = build()
+            model.load_state_dict(model0.state_dict())
+            loss_fn = get_loss(cfg, bce_pos_weight=torch.tensor(1.0))
+            losses, first_logits = [], []
+
+            class _Rec(torch.nn.Module):
+                def forward(self, logits, targets):
+                    l = loss_fn(logits, targets)
+                    losses.append(float(l.detach()))
+                    if not first_logits:
+                        first_logits.append(logits.detach().numpy().copy())
+                    return l
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                trainer = PT.ProtNoteTrainer(model=model, device="cpu", rank=0, config=cfg, logger=logging.getLogger("g"),
+                                             timestamp="t", run_name="golden", loss_fn=_Rec(), is_master=False)
+                trainer.training_step = 0
+                queue = [u.clone() for u in noises]
+                PN.torch.rand_like = lambda t, *a, **k: queue.pop(0)
+                loader = _Loader(batches)
+                loader.dataset = types.SimpleNamespace(label_vocabulary=list(range(n_labels)))
+                model.train()
+                metrics = trainer.train_one_epoch(loader, _NoMetrics())
+            PN.torch.rand_like = real_rand_like
+            p = case + "/"
+            out[p + "params_json"] = np.array(json.dumps(params))
+            out[p + "trainable_names"] = np.array(trainer.trainable_params_names)
+            out[p + "optimizer_class"] = np.array(type(trainer.optimizer).__name__)
+            out[p + "n_optimizer_params"] = np.array(len(trainer.optimizer.param_groups[0]["params"]))
+            out[p + "first_logits"] = first_logits[0]
+            out[p + "losses"] = np.array(losses, dtype=np.float64)
+            for mk, mv in metrics.items():
+                out[p + "metrics/" + mk] = np.array(float(mv))
+            out.update(sd_np(model, p + "sd_after/"))
+            print(case, type(trainer.optimizer).__name__, len(trainer.trainable_params_names), "trainable,",
+                  "losses", [round(v, 5) for v in losses[:3]], "...", metrics)
+    finally:
+        PN.torch.rand_like = real_rand_like
+    np.savez_compressed(os.path.join(OUT, "optimizer_branches.npz"), **out)
+    print("optimizer_branches.npz", os.path.getsize(os.path.join(OUT, "optimizer_branches.npz")) // 1024, "KiB")
+
+
 def golden_grid_samplers():
     """Index streams of protnote/data/samplers.py::GridBatchSampler (Python `random`, seeded) and
     ::GeneralDistributedSampler (rank shards of an arbitrary sampler's stream)."""
@@ -754,7 +902,7 @@ if __name__ == "__main__":
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers,
-            "config0": golden_config0_full_width}
+            "config0": golden_config0_full_width, "optimizer_branches": golden_optimizer_branches}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

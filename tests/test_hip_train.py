@@ -1359,3 +1359,123 @@ def test_row_mlp_backward_big_kernels_match_small_tiles(NL):
             assert rel < 2e-5, (n, rel)
             checked += 1
     assert checked >= 7
+
+
+OPT_CASES = ("adam", "adam_frozen_head", "adamw", "sgd", "sgd_frozen_head")
+
+
+def _run_optimizer_case(g, case, monkeypatch):
+    import json
+
+    from protnote_amd.utils.configs import build_training
+
+    params = json.loads(str(g[case + "/params_json"]))
+    model, _ = make_protnote(g, DEV)
+    loss_fn, opt, trainer = build_training({"params": params}, model)
+    lab = torch.from_numpy(g["label_embeddings"]).to(DEV)
+    cnt = torch.from_numpy(g["label_token_counts"]).to(DEV)
+    n = int(g["n_batches"])
+    loader = [{"sequence_onehots": torch.from_numpy(g[f"batch{k}/x"]).to(DEV),
+               "sequence_lengths": torch.from_numpy(g[f"batch{k}/lens"]).to(DEV),
+               "label_multihots": torch.from_numpy(g[f"batch{k}/multihots"]).to(DEV),
+               "label_embeddings": lab, "label_token_counts": cnt} for k in range(n)]
+    queue = [torch.from_numpy(g[f"batch{k}/noise_u"]).to(DEV) for k in range(n)]
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: queue.pop(0))
+    seen = []
+    h = model.register_forward_hook(lambda m, a, out: seen.append(out[0].detach().clone()))
+    metrics = trainer.train_one_epoch(loader)
+    h.remove()
+    return params, model, opt, metrics, seen
+
+
+@pytest.mark.parametrize("case", OPT_CASES)
+def test_optimizer_branches_golden(golden_dir, case, monkeypatch):
+    """ProtNoteTrainer._set_optimizer's branches (ProtNoteTrainer.py:199-245) through build_training, against an epoch
+    that the REFERENCE'S OWN ProtNoteTrainer.train_one_epoch ran on CPU (tests/golden/make_golden.py::
+    golden_optimizer_branches): the set of parameters left trainable by TRAIN_PROJECTION_HEAD: False (output_layer.*
+    frozen; W_p / W_l keep training - the reference's startswith quirk), OPTIMIZER Adam / AdamW / SGD with WEIGHT_DECAY,
+    every batch's loss, the epoch metrics and the state dict after 10 optimisation steps."""
+    g = _g(golden_dir, "optimizer_branches.npz")
+    params, model, opt, metrics, seen = _run_optimizer_case(g, case, monkeypatch)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert names == [str(v) for v in g[case + "/trainable_names"]]
+    assert opt.n_param_ids == int(g[case + "/n_optimizer_params"]) == len(opt.params)
+    assert type(opt).__name__ == {"Adam": "FusedClipAdam", "AdamW": "FusedClipAdam", "SGD": "FusedClipSGD"}[params["OPTIMIZER"]]
+    assert str(g[case + "/optimizer_class"]) == params["OPTIMIZER"]
+    np.testing.assert_allclose(seen[0].cpu().numpy(), g[case + "/first_logits"], atol=5e-4, rtol=1e-4)
+    sgd = params["OPTIMIZER"] == "SGD"
+    np.testing.assert_allclose(metrics["loss"], float(g[case + "/metrics/train_loss"]), rtol=1e-4 if sgd else 3e-3)
+    if sgd:  # (Adam's sign-like update lets a handful of threshold decisions differ)
+        np.testing.assert_allclose(metrics["f1_macro"], float(g[case + "/metrics/train_f1_macro"]), rtol=1e-5)
+        np.testing.assert_allclose(metrics["f1_micro"], float(g[case + "/metrics/train_f1_micro"]), rtol=1e-5)
+    lr, n = float(params["LEARNING_RATE"]), int(g["n_batches"])
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    head = bool(params["TRAIN_PROJECTION_HEAD"])
+    for k in g.files:
+        if not k.startswith(case + "/sd_after/"):
+            continue
+        name = k[len(case + "/sd_after/"):]
+        if not head and name.startswith("output_layer") and not name.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert np.array_equal(got[name], g["sd/" + name]), name  # frozen: bit-for-bit the initial weights
+            assert dict(model.named_parameters())[name].grad is None, name
+        elif sgd or name.endswith(("running_mean", "running_var", "num_batches_tracked")) or name.startswith("sequence_encoder"):
+            np.testing.assert_allclose(got[name], g[k], atol=5e-5, rtol=5e-4, err_msg=name)
+        else:
+            _assert_adam_close(got[name], g[k], name, lr=lr, steps=n, frac=0.98)
+
+
+def test_frozen_output_layer_same_forward_and_remaining_gradients(golden_dir, monkeypatch):
+    """Freezing output_layer changes what the backward COMPUTES (no dW / dgamma / dbeta / dw_out / db_out for it: NULL
+    destinations in pn_pairhead_grads), never the numbers that remain: logits and the W_p / W_l gradients of a step with the
+    head frozen are bit-identical to the unfrozen step's."""
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    g = _g(golden_dir, "protnote_small_concatenation.npz")
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    y = torch.from_numpy(g["multihots"]).float().to(DEV)
+    res = []
+    for frozen in (False, True):
+        model, _ = make_protnote(g, DEV)
+        _freeze_encoder(model)
+        model.label_embedding_noising_alpha = 0.0
+        if frozen:
+            for n_, p_ in model.named_parameters():
+                if n_.startswith("output_layer"):
+                    p_.requires_grad = False
+        model.train()
+        logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        res.append((logits.detach().clone(), {n_: p_.grad for n_, p_ in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n_, gr in res[1][1].items():
+        if n_.startswith("output_layer") or n_.startswith("sequence_encoder"):
+            assert gr is None, n_
+        else:
+            assert torch.equal(gr, res[0][1][n_]), n_
+
+
+def test_sgd_state_interchange_with_torch_sgd(golden_dir):
+    """FusedClipSGD.state_dict() has torch.optim.SGD's layout (a reference checkpoint's optimizer_state_dict under
+    OPTIMIZER: SGD, utils/models.py:304-321) and one fused step equals torch's SGD step on the same gradients."""
+    from protnote_amd.utils.optim import FusedClipSGD
+
+    gen = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=gen).to(DEV)) for s in ((7, 5), (13,), (4, 4, 3))]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FusedClipSGD(ps, lr=0.05, weight_decay=0.01, max_norm=1.0)
+    tref = torch.optim.SGD(ref, lr=0.05, weight_decay=0.01)
+    for step in range(3):
+        for p, r in zip(ps, ref):
+            gr = torch.randn(p.shape, generator=gen)
+            p.grad.copy_(gr.to(DEV))
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        tref.step()
+        opt.step()
+        for p, r in zip(ps, ref):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), atol=1e-6, rtol=1e-6)
+    sd = opt.state_dict()
+    tref.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})  # torch accepts the layout
+    opt.load_state_dict(tref.state_dict())
+    assert opt.step_count == 1

@@ -307,3 +307,57 @@ def test_attention_pooling_eval_and_train(golden_dir):
         if k.startswith("train_BCE/sd_after/"):
             name = k[len("train_BCE/sd_after/"):]
             np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
+
+
+OPT_CASES = ("adam", "adam_frozen_head", "adamw", "sgd", "sgd_frozen_head")
+
+
+def _adam_close(got, ref, name, lr, steps, atol=3e-5, rtol=2e-4, frac=0.99):
+    """Adam's update is sign-like for gradients at f32-noise level: every element within 2 lr per step, `frac` of them
+    tight (same rule as tests/test_hip_train.py::_assert_adam_close)."""
+    diff = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    assert diff.max() <= 2 * lr * steps + atol, (name, diff.max())
+    assert (diff <= atol + rtol * np.abs(ref)).mean() >= frac, (name, (diff <= atol + rtol * np.abs(ref)).mean())
+
+
+@pytest.mark.parametrize("case", OPT_CASES)
+def test_optimizer_branches_vs_reference_trainer(golden_dir, case):
+    """_set_optimizer's branches (ProtNoteTrainer.py:199-245), pinned to an epoch the reference's own ProtNoteTrainer ran:
+    which parameters stay trainable under TRAIN_PROJECTION_HEAD: False (output_layer.* frozen, W_p / W_l not - the
+    reference's startswith quirk), and Adam / AdamW / SGD with WEIGHT_DECAY over 10 batches."""
+    import json
+
+    g = _load(golden_dir, "optimizer_branches.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    params = json.loads(str(g[case + "/params_json"]))
+    head = bool(params["TRAIN_PROJECTION_HEAD"])
+    assert O.trainable_names(sd, False, head) == [str(n) for n in g[case + "/trainable_names"]]
+    lab, cnt = torch.from_numpy(g["label_embeddings"]), torch.from_numpy(g["label_token_counts"])
+    lr, n = float(params["LEARNING_RATE"]), int(g["n_batches"])
+    st, losses = {}, []
+    for k in range(n):
+        x, lens = torch.from_numpy(g[f"batch{k}/x"]), torch.from_numpy(g[f"batch{k}/lens"])
+        logits, l, grads, _ = O.train_step(sd, x, lens, lab, torch.from_numpy(g[f"batch{k}/multihots"]), loss="BCE",
+                                           noise_alpha=20.0, noise_u=torch.from_numpy(g[f"batch{k}/noise_u"]),
+                                           label_token_counts=cnt, clip=float(params["CLIP_VALUE"]), lr=lr, adam_state=st,
+                                           train_projection_head=head, optimizer=params["OPTIMIZER"],
+                                           weight_decay=float(params["WEIGHT_DECAY"]))
+        losses.append(float(l))
+        if k == 0:
+            np.testing.assert_allclose(logits.numpy(), g[case + "/first_logits"], atol=1e-4, rtol=1e-5)
+            assert set(grads) == set(O.trainable_names(sd, False, head))
+    sgd = params["OPTIMIZER"] == "SGD"
+    np.testing.assert_allclose(losses, g[case + "/losses"], rtol=2e-5 if sgd else 2e-3)
+    for k in g.files:
+        if not k.startswith(case + "/sd_after/"):
+            continue
+        name = k[len(case + "/sd_after/"):]
+        ref, got = g[k], sd[name].detach().numpy()
+        if name.endswith("num_batches_tracked"):
+            continue  # the functional oracle does not count batches
+        if not head and name.startswith("output_layer") and not name.endswith(("running_mean", "running_var")):
+            assert np.array_equal(got, g["sd/" + name]) and np.array_equal(ref, g["sd/" + name]), name  # frozen: untouched
+        elif sgd or name.endswith(("running_mean", "running_var")) or name.startswith("sequence_encoder"):
+            np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-4, err_msg=name)
+        else:
+            _adam_close(got, ref, name, lr, n)
