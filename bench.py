@@ -44,10 +44,25 @@ KIND_NAMES = {
     12: "nt:bn_relu(z)->rowdot", 22: "nt:pairsum_relu->rowdot", 3: "nt:plain->scale", 2: "nt:plain->rowdot",
     104: "tn:plain x conv tap (encoder wgrad)", 100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
+    900: "similarity backward: dP^ / dL^ contractions + normalisation backward (pn_similarity_bwd)",
 }
 KIND_NAMES.update({1000 + k: v + " [bf16x3]" for k, v in list(KIND_NAMES.items())})
+# HBM-bound streaming stages (pn_prof kinds >= 2000; the library reports their ALGORITHMIC bytes, include/protnote_hip.h)
+STAGE_NAMES = {
+    2001: ("K2 conv1 from one-hots (k_ncl_to_nlc + 20-channel conv)", "4 B x (20 read + 1100 written) per residue"),
+    2002: ("K6 masked mean-pool (k_pool)", "4 B x 1100 read per residue"),
+    2003: ("K13/K14 loss + dlogits + TP/FN/FP (k_loss)", "4 B logit + 1 B target read, 4 B gradient written per pair "
+                                                         "(the ABI takes i64 / f32 targets: 8 / 4 B actually read)"),
+    2004: ("K16 clip + optimiser (k_sumsq + k_adam | k_sgd)", "Adam: 16 B read + 12 B written per parameter"),
+    2005: ("dz in place (k_dz_apply)", "top layer: z read, dz written (8 B x h per row); inner: z, G read, dz written (12 B x h)"),
+    2006: ("BatchNorm-backward statistics (k_bn_bwd_stats)", "top: z read (4 B x h per row); inner: z and G read (8 B x h)"),
+    2007: ("layer-1 masked reduction (k_pair_mask_reduce_fused)", "G read once (4 B x h per row)"),
+    2008: ("row-dot logits (k_rowdot_rows_reg)", "top pre-activation read (4 B x h per row), 4 B written"),
+    2009: ("conv operand staging (k_conv_stage_act)", "activation read + staged image written"),
+}
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: Peak BF16 MFMA, dense
+HBM_PEAK_TBPS = 8.0  # same guide: HBM3E spec (measured copy rate there: 6.29 TB/s)
 BUCKETS = (128, 256, 512, 1024, 2048)
 
 
@@ -179,9 +194,29 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def gemm_kinds(prof):
+    return {k: v for k, v in prof.items() if k < 2000}
+
+
+def stages_block(prof, steps):
+    """SURVEY 8d's HBM-bound stages, event-timed inside the timed region like the GEMM kinds: per stage the algorithmic
+    bytes of a launch, its mean duration, TB/s and the fraction of the 8 TB/s HBM roofline."""
+    out = {}
+    for kind, (cnt, ms, nbytes) in sorted(prof.items()):
+        if kind < 2000 or cnt == 0:
+            continue
+        name, what = STAGE_NAMES.get(kind, (str(kind), ""))
+        tbps = nbytes / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[name] = {"bound": "hbm", "launches_per_step": cnt / max(steps, 1), "algorithmic_bytes_per_launch": nbytes / cnt,
+                     "ms_per_launch": ms / cnt, "ms_per_step": ms / max(steps, 1), "achieved_TBps": round(tbps, 3),
+                     "peak_TBps": HBM_PEAK_TBPS, "frac": round(tbps / HBM_PEAK_TBPS, 4), "bytes": what}
+    return out
+
+
 def family(prof):
     """Dominant family: launches that contract over the full pair grid with a 3072x3072 weight
     -> (TFLOP/s, launches, total ms, total flop)."""
+    prof = gemm_kinds(prof)
     big = {k: v for k, v in prof.items() if v[0] > 0 and v[2] / v[0] > 1e12} or prof
     tot_ms = sum(v[1] for v in big.values())
     tot_fl = sum(v[2] for v in big.values())
@@ -191,7 +226,7 @@ def family(prof):
 
 def kernel_table(prof):
     out = {}
-    for kind, (cnt, ms, fl) in sorted(prof.items()):
+    for kind, (cnt, ms, fl) in sorted(gemm_kinds(prof).items()):
         out[KIND_NAMES.get(kind, str(kind))] = {
             "launches": cnt, "ms_total": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0}
     return out
@@ -207,6 +242,81 @@ def roofline_block(prof, math_mode, kernel_note):
         blk["note"] = ("algorithmic (f32-equivalent) flops over the dense bf16 peak; each costs three bf16 MFMA "
                        "flops, so the ceiling of frac is 1/3")
     return blk
+
+
+def similarity_bench(model, batch, dev, world, steps, sync, max_over_ranks):
+    """FEATURE_FUSION: similarity (ProtNote.py:281-284) at the headline shape: train step (focal loss, the
+    reference's default LOSS_FN) and eval forward of a model that shares the headline model's encoder.  The head itself is
+    one [B x d] x [N_L x d]^T contraction: 2*d FLOP + 4 B written per pair (SURVEY 8d) - reported with its own roofline;
+    the step around it is encoder- and W_l-bound."""
+    import torch
+
+    from protnote_amd import _lib
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    torch.manual_seed(4242)
+    sim = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024,
+                   sequence_encoder=model.sequence_encoder, projection_head_num_layers=4,
+                   projection_head_hidden_dim_scale_factor=3, label_embedding_noising_alpha=20.0,
+                   feature_fusion="similarity", temperature=0.07).to(dev).train()
+    loss_fn = get_loss({"params": {"LOSS_FN": "FocalLoss", "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1,
+                                   "LABEL_SMOOTHING": 0.0}}, bce_pos_weight=torch.tensor(1.0))
+    opt = FusedClipAdam(head_parameters(sim), lr=3e-4, max_norm=1.0)
+    B, NL = batch["label_multihots"].shape
+    d = 1024
+    for _ in range(2):
+        train_step(sim, loss_fn, opt, batch)
+    sync()
+    _lib.prof_begin()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = train_step(sim, loss_fn, opt, batch)
+    sync()
+    t_train = max_over_ranks(time.time() - t0)
+    tprof = _lib.prof_end()
+    sim.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            sim(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
+                label_embeddings=batch["label_embeddings"])
+        sync()
+        _lib.prof_begin()
+        t0 = time.time()
+        for _ in range(steps):
+            sim(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
+                label_embeddings=batch["label_embeddings"])
+        sync()
+        t_eval = max_over_ranks(time.time() - t0)
+        eprof = _lib.prof_end()
+
+    def head_roofline(prof, kinds, what):
+        cnt = sum(prof[k][0] for k in kinds if k in prof)
+        ms = sum(prof[k][1] for k in kinds if k in prof)
+        fl = sum(prof[k][2] for k in kinds if k in prof)  # 2*d FLOP per pair and contraction (SURVEY 8d)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # each contraction also moves 4 B per pair (logits written / dlogits read): the HBM-side bound of the same launches
+        return {"bound": "mfma", "kernel": what, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / F32_MFMA_PEAK_TFLOPS, "launches_per_step": cnt / steps, "ms_per_step": ms / steps,
+                "flop_per_pair": fl / steps / (B * NL), "bytes_per_pair": 4,
+                "hbm_side": {"achieved_TBps": 4.0 * B * NL * cnt / max(ms * 1e-3, 1e-12) / 1e12, "peak_TBps": HBM_PEAK_TBPS}}
+
+    out = {"workload": f"FEATURE_FUSION: similarity, per-GPU batch {B} x {NL} labels, d = {d}, focal loss; train step "
+                       "fwd+bwd+clip+Adam and eval forward; shares the headline model's frozen encoder",
+           "train": {"value": world * B * NL * steps / t_train, "unit": "pairs/s", "ms_per_step": t_train / steps * 1e3,
+                     "final_loss": float(loss),
+                     # forward cosine GEMM (nt:plain->scale) + the two backward contractions over the same grid
+                     "roofline": head_roofline(tprof, [3, 900], "cosine GEMM fwd (nt:plain->scale) + the backward's dP^ / dL^ "
+                                               "contractions (pn_similarity_bwd): 3 x 2*d FLOP per pair per step"),
+                     "kernels": kernel_table(tprof), "stages": stages_block(tprof, steps)},
+           "eval": {"value": world * B * NL * steps / t_eval, "unit": "pairs/s", "ms_per_forward": t_eval / steps * 1e3,
+                    "roofline": head_roofline(eprof, [3], "cosine GEMM (gemm_nt E_SCALE_RC: row norm x col norm / T in the epilogue)"),
+                    "kernels": kernel_table(eprof), "stages": stages_block(eprof, steps)}}
+    del opt, sim
+    return out
 
 
 def zero_shot_batches(seqs_per_rank, batch, rank, world, dev, seed=5):
@@ -326,7 +436,7 @@ def main():
     def spread(xs):
         return {"min": min(xs), "max": max(xs), "per_rank": [round(v, 4) for v in xs]}
 
-    def timed_train(steps, warmup):
+    def timed_train(steps, warmup, model=model, loss_fn=loss_fn, opt=opt, batch=batch):
         for _ in range(warmup):
             train_step(model, loss_fn, opt, batch, world_size=world, counts=counts)
         sync()
@@ -381,6 +491,46 @@ def main():
     # ------------------------------------------------------------------ sub-benchmarks (outside the headline region)
     extra = {}
     if not args.no_extra:
+        n_var = max(1, min(args.steps, 2))
+        # SURVEY 8d variant of the headline workload: sequence lengths ~ U[64, L] padded to L (the pads are masked inside
+        # the conv kernels; the head's pair grid is unchanged)
+        if not args.ragged_lengths:
+            rb = synthetic_batch(B, L, NL, dev, seed=1000 + rank, ragged=True)
+            r_el, r_prof, r_loss, _ = timed_train(n_var, 1, batch=rb)
+            extra["ragged_lengths"] = {
+                "workload": f"the headline train step with sequence lengths ~ U[64, {L}] padded to {L} (SURVEY 8d variant)",
+                "value": world * B * NL * n_var / r_el, "unit": "pairs/s", "ms_per_step": r_el / n_var * 1e3,
+                "steps": n_var, "valid_residue_fraction": float(rb["sequence_lengths"].float().mean().item()) / L,
+                "final_loss": r_loss, "roofline": roofline_block(r_prof, args.math, "pair-grid 3072x3072 GEMM family"),
+                "encoder_gemm_ms_per_step": sum(v[1] for k, v in gemm_kinds(r_prof).items() if k % 1000 == 31) / n_var}
+            del rb
+        # TRAIN_PROJECTION_HEAD: False (ProtNoteTrainer.py:216-222): output_layer.* frozen, W_p / W_l keep training.  The
+        # frozen stack's two 155 TFLOP weight-gradient GEMMs (and its dgamma / dbeta / dw_out reductions) are not run.
+        if not args.train_encoder:
+            from protnote_amd.utils.configs import build_training
+
+            cfg_f = {"params": {"LOSS_FN": "BCE", "BCE_POS_WEIGHT": 1, "OPTIMIZER": "Adam", "LEARNING_RATE": 3e-4,
+                                "CLIP_VALUE": 1, "TRAIN_SEQUENCE_ENCODER": False, "TRAIN_PROJECTION_HEAD": False}}
+            f_loss_fn, f_opt, _ = build_training(cfg_f, model)  # re-flattens the still-trainable parameters
+            if world > 1:
+                D.sync_initial_state(model, f_opt)
+            fz_el, fz_prof, fz_loss, _ = timed_train(n_var, 1, loss_fn=f_loss_fn, opt=f_opt)
+            fz_fam = family(fz_prof)
+            extra["frozen_output_layer"] = {
+                "workload": "the headline train step under TRAIN_PROJECTION_HEAD: False (output_layer.* frozen as the "
+                            "reference freezes it; W_p / W_l trained)",
+                "value": world * B * NL * n_var / fz_el, "unit": "pairs/s", "ms_per_step": fz_el / n_var * 1e3,
+                "steps": n_var, "final_loss": fz_loss, "trainable_parameters": int(f_opt.flat_w.numel()),
+                "family_tflop_per_step": fz_fam[3] / n_var / 1e12, "family_tflop_per_step_unfrozen": family(prof)[3] / args.steps / 1e12,
+                "roofline": roofline_block(fz_prof, args.math, "pair-grid 3072x3072 GEMM family"),
+                "kernels": kernel_table(fz_prof)}
+            for q in model.parameters():  # back to the headline configuration for what follows
+                if q.dtype.is_floating_point:
+                    q.requires_grad = True
+            for n_, q in model.named_parameters():
+                if n_.startswith("sequence_encoder"):
+                    q.requires_grad = False
+            del f_opt
         # the train-step activation store (2 x 101 GB) is not needed any more
         import protnote_amd
 
@@ -399,6 +549,7 @@ def main():
             _lib.set_math_mode(mode)
             e_el, e_prof, e_spread = timed_eval(fwd_only, max(1, min(args.steps, 3)), 1)
             n = max(1, min(args.steps, 3))
+            e_prof = gemm_kinds(e_prof)
             enc_ms = sum(v[1] for k, v in e_prof.items() if k % 1000 == 31)
             fo[mode] = {"value": world * B * NL * n / e_el, "unit": "pairs/s", "ms_per_forward": e_el / n * 1e3,
                         "encoder_share_of_gemm_time": enc_ms / max(sum(v[1] for v in e_prof.values()), 1e-9),
@@ -428,8 +579,11 @@ def main():
                 with torch.no_grad():
                     if zb:
                         model(sequence_onehots=zb[0][0], sequence_lengths=zb[0][1], label_embeddings=name)
+                # the same pass with W_l(L_f) recomputed per batch, as the reference does (ProtNote.py:270-271) - the
+                # figure comparable with the reference; the headline `value` of each table below runs with the label
+                # projection cached (computed once, in the untimed call above)
                 nocache = None
-                if name.startswith("EC"):  # the same pass with W_l(L_f) recomputed per batch, as the reference does
+                if mode == modes[0] or name.startswith("EC"):
                     model.label_projection_cache_size = 0
                     nocache, _, _ = timed_eval(run, 1, 0)
                     model.label_projection_cache_size = 4
@@ -437,6 +591,7 @@ def main():
                         if zb:
                             model(sequence_onehots=zb[0][0], sequence_lengths=zb[0][1], label_embeddings=name)
                 z_el, z_prof, z_spread = timed_eval(run, 1, 0)
+                z_prof = gemm_kinds(z_prof)
                 gemm_ms = max(sum(v[1] for v in z_prof.values()), 1e-9)
                 enc_ms = sum(v[1] for k, v in z_prof.items() if k % 1000 == 31)
                 res[name] = {"value": n_seq * table.shape[0] / z_el, "unit": "pairs/s (description rows scored)",
@@ -445,14 +600,19 @@ def main():
                              "roofline": roofline_block(z_prof, mode, "pair-grid 3072x3072 GEMM family (eval chunks)")}
                 if nocache is not None:
                     res[name]["seconds_without_label_projection_cache"] = nocache
+                    res[name]["value_without_label_projection_cache"] = n_seq * table.shape[0] / nocache
             zs[mode] = res
         extra["zero_shot"] = {"workload": f"BASELINE configs[4]: {n_seq} sequences ({args.zero_shot_seqs} per rank, "
                                           f"{residues} residues), lengths log-uniform 32..2048 padded to buckets "
                                           f"{list(BUCKETS)}, batch 128, two descriptions per label ensembled, GO table then "
-                                          "EC table swapped at run time; sequences dealt rank-strided within each bucket",
+                                          "EC table swapped at run time; sequences dealt rank-strided within each bucket; "
+                                          "`value` runs with L_e = W_l(table) cached per table (projected once, outside the "
+                                          "timed pass), `value_without_label_projection_cache` recomputes it per batch as "
+                                          "the reference does",
                               "sequences_per_rank": seqs_per_rank, "batches_per_rank": batches_per_rank, **zs}
         _lib.set_math_mode(args.math)
         model.inference_descriptions_per_label = 1
+        extra["similarity_head"] = similarity_bench(model, batch, dev, world, max(2, min(args.steps, 5)), sync, max_over_ranks)
 
     if rank == 0:
         pairs = world * B * NL * args.steps
@@ -498,6 +658,8 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": loss_val},
             "roofline": roof,
             "kernels": kernel_table(prof),
+            # SURVEY 8d's HBM-bound stages of the SAME timed steps (events inside the timed region)
+            "stages": stages_block(prof, args.steps),
         }
         if world > 1:
             replicas = (comm or {}).pop("_replicas", {})

@@ -13,7 +13,16 @@
  *  - all pointers are DEVICE pointers (HBM) unless the name ends in _host; f32 unless typed otherwise.
  *  - no hidden allocation, no ownership transfer: scratch comes from the caller (`ws`, size from the
  *    matching *_ws_bytes query); launches go to `stream` (a hipStream_t passed as void*), nothing
- *    synchronises the device.
+ *    synchronises the device.  The library never calls hipMalloc: even the arrival counters that pace
+ *    the big weight-gradient kernel live in the `ws` of the call that launches it.
+ *  - thread-safe per stream: calls that use DIFFERENT streams, workspaces and save buffers may run
+ *    concurrently from different host threads (tests/test_hip_train.py::
+ *    test_two_models_on_two_streams_concurrently_equal_serial).  The pn_set_* switches are process-wide.
+ *  - collectives are NOT part of this ABI, deliberately (SURVEY 2.3 / 8b lists pn_comm_init / allreduce /
+ *    broadcast as an option): data-parallel exchange is torch.distributed over RCCL in the Python host
+ *    layer (protnote_amd/utils/distributed.py - one flat gradient all-reduce, one BN-buffer broadcast,
+ *    one [3, N_L] count all-reduce), exactly where the reference has it (DDP, bin/main.py:452); the one
+ *    place the C side needs a cross-rank sum inside a call (SYNC_BN) takes it as a callback, pn_set_sync_bn.
  *  - internal activations are channels-last [B*L, ld4(C)] with ld4(C) = C rounded up to a multiple of 4
  *    and zero pad lanes; conv weights must be packed by pn_pack_conv_weight first.
  */
@@ -340,12 +349,11 @@ typedef int (*pn_sync_hook)(long n_doubles, void* user);
 int pn_set_sync_bn(pn_sync_hook hook, void* user, double* stage, long stage_doubles, int world);
 int pn_get_math_mode(void);
 
-/* Operand staging of the f32 pair-grid GEMMs: 1 (default; env PN_F32_DMA) = LDS-DMA (global_load_lds, gemm_dma.hpp),
+/* Operand staging of the f32 pair-grid GEMMs: 1 (default) = LDS-DMA (global_load_lds, gemm_dma.hpp),
  * 0 = the register-staged engine (gemm_engine.hpp).  Same arithmetic in the same order: results are bit-identical;
  * the switch exists for A/B timing and for the test that asserts exactly that. */
 int pn_set_f32_dma(int on);
-/* Same switch for the bf16x3 pair-grid GEMMs (weight operand pre-split into bf16 hi / lo planes and staged by LDS-DMA;
- * env PN_B3_DMA). */
+/* Same switch for the bf16x3 pair-grid GEMMs (weight operand pre-split into bf16 hi / lo planes and staged by LDS-DMA). */
 int pn_set_b3_dma(int on);
 
 /* The dropout keep-mask the kernels generate for (seed, stream, rows x cols): out[r][c] = 1.0 (kept) or 0.0, so a
@@ -357,7 +365,11 @@ int pn_dropout_mask(unsigned seed, int stream, float p, long rows, int cols, flo
  * by hipEvents on its own stream.  pn_prof_end aggregates per kernel kind
  * (kind = family*100 + operand_kind*10 + epilogue_kind; family 0 = NT engine, 1 = TN engine); the caller
  * must have synchronised the device first.  flops = 2*M*N*K of each launch (arithmetic actually issued).
- * Returns the number of kinds written. */
+ * Kinds >= 2000 are the HBM-bound streaming stages (bench.py `stages`); for them `total_flops` carries the
+ * ALGORITHMIC BYTES of the launches (what the pass must read + write once): 2001 conv1 from one-hots (K2),
+ * 2002 masked mean-pool (K6), 2003 loss + dlogits + TP/FN/FP (K13/K14), 2004 clip + Adam/SGD (K16),
+ * 2005 dz in place, 2006 BatchNorm-backward statistics, 2007 layer-1 masked reduction, 2008 row-dot logits,
+ * 2009 convolution operand staging.  Returns the number of kinds written. */
 int pn_prof_begin(void);
 int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops);
 

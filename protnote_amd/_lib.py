@@ -237,8 +237,11 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
-    """Grow-only per-device scratch buffer (uint8), reused across calls on the same stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Grow-only scratch buffer (uint8) per (device, stream, tag): calls queued on one stream reuse one buffer in stream
+    order; calls on ANOTHER stream (a second model training concurrently, a second host thread) get their own, so the
+    C ABI's "thread-safe per stream" holds for the workspaces this binding hands it (pacing counters included)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
@@ -257,7 +260,7 @@ def prof_begin():
 def prof_end():
     """-> {kind: (launches, total_ms, total_flops)} (synchronises the device first)."""
     torch.cuda.synchronize()
-    n = 64
+    n = 128
     kinds, counts = (C.c_int * n)(), (C.c_long * n)()
     ms, fl = (C.c_double * n)(), (C.c_double * n)()
     got = lib().pn_prof_end(n, kinds, counts, ms, fl)

@@ -1634,7 +1634,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
   return 0;
 }
 
-// PN_MLP_MAT=0 / pn_set_mlp_materialize(0): the row-MLP backward regenerates dY in the operand loaders for every row count
+// pn_set_mlp_materialize(0): the row-MLP backward regenerates dY in the operand loaders for every row count
 // (the path the small-size oracle tests pin) - an A/B switch for tests and measurements
 static int g_mlp_mat = 1;
 extern "C" int pn_set_mlp_materialize(int on) {
@@ -2392,7 +2392,8 @@ __global__ void k_normalize_bwd(const float* __restrict__ xhat, const float* __r
 }
 
 struct SimWs {
-  float *rs, *cs, *Ph, *Lh, *dPh, *dLh, *T1, *PhT;
+  float *rs, *cs, *Ph, *Lh, *dPh, *dLh, *T1, *PhT, *part;
+  size_t part_floats;
 };
 static bool sim_carve(int B, int NL, int d, Bump& bp, SimWs& w) {
   const int Bp = ld4(B);
@@ -2404,6 +2405,10 @@ static bool sim_carve(int B, int NL, int d, Bump& bp, SimWs& w) {
   w.dLh = bp.take<float>((size_t)NL * d);
   w.T1 = bp.take<float>((size_t)NL * Bp);   // dlogits^T, zero-padded columns
   w.PhT = bp.take<float>((size_t)d * Bp);   // P^^T, zero-padded columns
+  // split-K partial tiles of dP^ = dlogits P-side contraction over the NL label rows: its [Bp x d] output is only a
+  // handful of tiles, so the rows are split ~128 ways to fill the chip (one workgroup per tile ran at 4 TFLOP/s)
+  w.part_floats = (size_t)128 * Bp * d < TN_PART_FLOATS_MAX ? (size_t)128 * Bp * d : TN_PART_FLOATS_MAX;
+  w.part = bp.take<float>(w.part_floats);
   return bp.ok;
 }
 
@@ -2437,11 +2442,13 @@ extern "C" int pn_similarity_bwd(const float* P_e, const float* L_e, int B, int 
   PN_OK(transpose_into(dlogits, NL, B, NL, w.T1, Bp, st));  // T1[j][i] = dl[i][j]
   PN_OK(transpose_into(w.Ph, d, B, d, w.PhT, Bp, st));       // PhT[k][i] = P^[i][k]
   const float alpha = 1.f / temperature;
+  // both backward contractions of the cosine head under one timing kind (900: 2 x 2 B NL d FLOP)
+  ProfScope ps_sim(900, 4.0 * (double)B * (double)NL * (double)d, st);
   // dP^[i][k] = sum_j T1[j][i] L^[j][k]   (contraction over the NL rows)
   {
     TnParams tp = tn_zero();
     tp.R = NL; tp.M = Bp; tp.N = d; tp.A = w.T1; tp.lda = Bp; tp.B = w.Lh; tp.ldb = d;
-    PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, w.dPh, d, nullptr, 0, st)));
+    PN_OK((launch_tn<TA_PLAIN, TB_PLAIN>(tp, w.dPh, d, w.part, w.part_floats, st)));
   }
   // dL^[j][k] = sum_i T1[j][i] P^[i][k]
   {

@@ -1479,3 +1479,69 @@ def test_sgd_state_interchange_with_torch_sgd(golden_dir):
     tref.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})  # torch accepts the layout
     opt.load_state_dict(tref.state_dict())
     assert opt.step_count == 1
+
+
+def test_two_models_on_two_streams_concurrently_equal_serial():
+    """The C ABI promises "no hidden allocation, thread-safe per stream" (include/protnote_hip.h).  Two full-width models
+    take one train step each (forward, BCE, backward, clip + Adam) at the same time - two host threads, two streams of one
+    device, grids large enough for every big kernel incl. the paced weight-gradient kernel whose arrival counters used to
+    be one static buffer per device - and end with exactly the bits of the same two steps run one after the other."""
+    import threading
+
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    B, NL = 64, 2080  # 133 120 pair rows: 256-tile NT / specialised TN kernels, 2+ row splits
+    cases = []
+    for seed in (5, 6):
+        gen = torch.Generator().manual_seed(seed)
+        cases.append(dict(sd=random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3),
+                          P_f=torch.randn(B, 1100, generator=gen).to(DEV), lab=torch.randn(NL, 1024, generator=gen).to(DEV),
+                          y=(torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)))
+
+    def build(c):
+        m = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+        m.load_state_dict(c["sd"])
+        m = m.to(DEV).train()
+        return m, FusedClipAdam(head_parameters(m), lr=1e-3, max_norm=1.0)
+
+    def step(m, opt, c, stream, out, k, reps=3):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    logits, _ = m(sequence_embeddings=c["P_f"], label_embeddings=c["lab"])
+                    BCEWithLogitsLoss()(logits, c["y"]).backward()
+                    opt.step()
+                    opt.zero_grad()
+                out[k] = (logits.detach().clone(), opt.flat_w.clone(), opt.flat_m.clone(),
+                          [b.clone() for b in m.buffers()])
+            stream.synchronize()
+        except Exception as e:  # noqa: BLE001 - surfaced by the assert below
+            out[k] = e
+
+    serial, conc = {}, {}
+    for k, c in enumerate(cases):
+        m, opt = build(c)
+        step(m, opt, c, torch.cuda.current_stream(), serial, k)
+    torch.cuda.synchronize()
+    built = [build(c) for c in cases]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=step, args=(built[k][0], built[k][1], cases[k], streams[k], conc, k))
+               for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert not isinstance(conc[k], Exception), conc[k]
+        assert not isinstance(serial[k], Exception), serial[k]
+        a, b = serial[k], conc[k]
+        assert float(a[0].std()) > 0.05
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
+        for x, z in zip(a[3], b[3]):
+            assert torch.equal(x, z), k
