@@ -1,7 +1,7 @@
 """Config surface of the reference (protnote/utils/configs.py + configs/base_config.yaml): YAML load, the
-`--override KEY VALUE ...` rule (python-literal values, null/true/false spelled the YAML way), and the mapping
-from config keys to the model constructors that bin/main.py:383-446 performs.  Only what the hot path needs:
-no path prefixing, loggers or label-embedding cache-name mangling (I/O side, out of scope)."""
+`--override KEY VALUE ...` rule (python-literal values, null/true/false spelled the YAML way), the mapping
+from config keys to the model constructors that bin/main.py:383-446 performs, and the naming rule of the cached
+label-embedding files.  No path prefixing or loggers (I/O side, out of scope)."""
 from ast import literal_eval
 
 import yaml
@@ -48,6 +48,25 @@ def override_config(config: dict, overrides) -> dict:
         if not found:
             raise KeyError(f"Key '{key}' not found in the 'params' or 'paths' section of the config.")
     return config
+
+
+_LABEL_ENCODER_NICKNAMES = {"microsoft/biogpt": "BioGPT", "intfloat/e5-large-v2": "E5",
+                            "intfloat/multilingual-e5-large-instruct": "E5_multiling_inst"}
+
+
+def generate_label_embedding_path(params: dict, base_label_embedding_path: str) -> str:
+    """Name of the file that caches the label embeddings of one (label encoder, pooling method) pair - reference
+    utils/configs.py:74-107, used by get_setup (:249-251) and by the producer bin/generate_label_embeddings.py:85-92:
+    `dir/<first>_<rest>.<ext>` -> `dir/<first>_<Nick>_<rest>_<pool>.<ext>` where the file name is cut at its FIRST dot
+    and at underscores (`frozen_label_embeddings.pt` -> `frozen_BioGPT_label_embeddings_mean.pt`).  Unsupported
+    LABEL_ENCODER_CHECKPOINT values fail the same assertion."""
+    assert params["LABEL_ENCODER_CHECKPOINT"] in _LABEL_ENCODER_NICKNAMES, "Model not supported"
+    parts = base_label_embedding_path.split("/")
+    name = parts[-1].split(".")
+    words = name[0].split("_")
+    stem = "_".join([words[0], _LABEL_ENCODER_NICKNAMES[params["LABEL_ENCODER_CHECKPOINT"]]] + words[1:])
+    parts[-1] = stem + "_" + params["LABEL_EMBEDDING_POOLING_METHOD"] + "." + name[1]
+    return "/".join(parts)
 
 
 def build_models(config: dict, num_labels: int = None, label_encoder=None, feature_fusion: str = None):

@@ -36,6 +36,28 @@ def load_checkpoint_into(model, checkpoint_path: str, map_location="cpu", strict
     return {k: v for k, v in ckpt.items() if k != "model_state_dict"}
 
 
+def load_model(trainer, checkpoint_path: str, rank: int = 0, from_checkpoint: bool = False):
+    """Twin of the reference's load_model (utils/models.py:324-374; called by bin/main.py:521-527): the checkpoint's
+    model_state_dict ('module.' prefix of a DDP-wrapped writer stripped, :352-358) goes into the trainer's model; with
+    `from_checkpoint` the optimiser state (by parameter id: FusedClipAdam / FusedClipSGD take torch's layout), the epoch
+    (as `starting_epoch` and `epoch`) and `best_val_metric` are restored too.  Tensors saved on cuda:0 land on this
+    rank's device (:347)."""
+    map_location = {"cuda:0": f"cuda:{rank}"} if torch.cuda.is_available() else "cpu"
+    ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+    model = trainer._get_model() if hasattr(trainer, "_get_model") else getattr(trainer.model, "module", trainer.model)
+    model.load_state_dict(strip_ddp_prefix(ckpt["model_state_dict"]))
+    opt = getattr(trainer, "optimizer", None)
+    if opt is not None and hasattr(opt, "repack"):
+        opt.repack()  # load_state_dict copied INTO the flat views; make sure nothing was re-assigned
+    if "optimizer_state_dict" in ckpt and from_checkpoint:
+        opt.load_state_dict(ckpt["optimizer_state_dict"])
+    if "epoch" in ckpt and from_checkpoint:
+        trainer.starting_epoch = ckpt["epoch"]
+        trainer.epoch = trainer.starting_epoch
+    if "best_val_metric" in ckpt and from_checkpoint:
+        trainer.best_val_metric = ckpt["best_val_metric"]
+
+
 def index_path_for(embedding_path: str) -> str:
     """`a/b/emb.pt` -> `a/b/emb_index.pt` - same split-on-first-dot rule as the reference (datasets.py:115-118;
     any other '.' in the path breaks it there too), but done on the file name only."""

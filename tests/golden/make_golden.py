@@ -859,6 +859,165 @@ def golden_optimizer_branches():
     print("optimizer_branches.npz", os.path.getsize(os.path.join(OUT, "optimizer_branches.npz")) // 1024, "KiB")
 
 
+def golden_disk_formats():
+    """On-disk formats either side of the hot path, produced / consumed by the reference's own code:
+      * utils/configs.py:74-107 generate_label_embedding_path - the cache-file naming rule, as a table of
+        (params, base path) -> path;
+      * utils/models.py:304-321 save_checkpoint called on a DistributedDataParallel-wrapped ProtNote (keys carry the
+        'module.' prefix, bin/main.py:452) with the Adam the trainer builds, after one optimisation step
+        -> tests/golden/disk_formats/ref_checkpoint_ddp.pt, and what utils/models.py:324-374 load_model restores from it;
+      * a cached label-embedding pair in the layout bin/generate_label_embeddings.py:93-97,123-164 writes (tensor file +
+        `<stem>_index.<ext>` pandas DataFrame with id / description_type / description / token_count), named by
+        generate_label_embedding_path, and what the reference's consumer (ProteinDataset, datasets.py:115-127,269-343)
+        makes of it: sorted embedding rows and token counts for a vocabulary.  (The producer script itself needs the
+        BioGPT download and cannot run here; the pair is written with its last three statements' calls.)"""
+    import json
+    import logging
+    import tempfile
+
+    import pandas as pd
+    import torch.distributed as dist
+    import Bio.SeqIO as SeqIO
+
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.configs import generate_label_embedding_path
+    from protnote.utils.models import load_model, save_checkpoint
+
+    out_dir = os.path.join(OUT, "disk_formats")
+    os.makedirs(out_dir, exist_ok=True)
+    # ---- naming rule ----
+    table = []
+    for ckpt in ("microsoft/biogpt", "intfloat/e5-large-v2", "intfloat/multilingual-e5-large-instruct"):
+        for pool in ("mean", "last_token", "all"):
+            for base in ("embeddings/frozen_label_embeddings.pt", "data/embeddings/frozen_label_embeddings_2024.pt",
+                         "frozen_ec_embeddings.pt", "a/b/c/go_jul_2024_extra_tag.pkl"):
+                params = {"LABEL_ENCODER_CHECKPOINT": ckpt, "LABEL_EMBEDDING_POOLING_METHOD": pool}
+                table.append({"params": params, "base": base, "path": generate_label_embedding_path(params, base)})
+    bad = None
+    try:
+        generate_label_embedding_path({"LABEL_ENCODER_CHECKPOINT": "bert-base", "LABEL_EMBEDDING_POOLING_METHOD": "mean"}, "x.pt")
+    except AssertionError as e:
+        bad = str(e)
+    doc = {"naming": table, "unsupported_checkpoint_assertion": bad}
+
+    # ---- checkpoint written by save_checkpoint from a DDP-wrapped model ----
+    tmp = tempfile.mkdtemp()
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(tmp, "pg"), rank=0, world_size=1)
+    enc_cfg = dict(num_labels=5, input_channels=20, output_channels=8, kernel_size=9, dilation_base=3,
+                   num_resnet_blocks=1, bottleneck_factor=0.5)
+    head_cfg = dict(protein_embedding_dim=8, label_embedding_dim=8, latent_dim=4, output_mlp_hidden_dim_scale_factor=2,
+                    output_mlp_num_layers=2, projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=2)
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+
+    def build():
+        return ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg), label_encoder=None,
+                        feature_fusion="concatenation", **head_cfg)
+
+    model = build()
+    randomize_(model, g)
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    opt = torch.optim.Adam([p for p in ddp.parameters() if p.requires_grad], lr=1e-3)
+    x, _ = onehots(g, [12, 7, 12], 12)
+    lens = torch.tensor([12, 7, 12])
+    lab = torch.randn(6, 8, generator=g)
+    ddp.train()
+    logits, _ = ddp(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+    logits.square().mean().backward()
+    opt.step()
+    ck = os.path.join(out_dir, "ref_checkpoint_ddp.pt")
+    save_checkpoint(model=ddp, optimizer=opt, epoch=7, best_val_metric=0.4375, model_path=ck)
+    # what the reference's load_model restores from it (into a fresh, unwrapped model + fresh Adam)
+    m2 = build()
+    for n, p in m2.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+    tr = types.SimpleNamespace(model=m2, optimizer=torch.optim.Adam([p for p in m2.parameters() if p.requires_grad], lr=1.0),
+                               starting_epoch=1, epoch=1, best_val_metric=0.0)
+    tr._get_model = lambda: m2
+    load_model(tr, ck, rank=0, from_checkpoint=True)
+    exp = {"ckpt/sd/" + k: v.numpy().copy() for k, v in m2.state_dict().items()}
+    osd = tr.optimizer.state_dict()
+    for i, st in osd["state"].items():
+        exp[f"ckpt/opt/{i}/exp_avg"] = st["exp_avg"].numpy().copy()
+        exp[f"ckpt/opt/{i}/exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+        exp[f"ckpt/opt/{i}/step"] = np.array(float(st["step"]))
+    doc["checkpoint"] = {"file": "ref_checkpoint_ddp.pt", "epoch": tr.epoch, "starting_epoch": tr.starting_epoch,
+                         "best_val_metric": tr.best_val_metric, "optimizer_lr": osd["param_groups"][0]["lr"],
+                         "optimizer_param_ids": list(osd["param_groups"][0]["params"]),
+                         "enc_cfg": enc_cfg, "head_cfg": head_cfg,
+                         "first_key_in_file": list(torch.load(ck, weights_only=False)["model_state_dict"])[0]}
+
+    # ---- cached label-embedding pair, named by the rule, read back by the reference's dataset ----
+    params = {"LABEL_ENCODER_CHECKPOINT": "microsoft/biogpt", "LABEL_EMBEDDING_POOLING_METHOD": "mean"}
+    rel = generate_label_embedding_path(params, "frozen_label_embeddings.pt")
+    out_path = os.path.join(out_dir, rel)
+    idx_parts = out_path.split(".")  # generate_label_embeddings.py:93-97 (same rule in datasets.py:115-118)
+    idx_path = "_".join([idx_parts[0], "index"]) + "." + idx_parts[1]
+    rows = []
+    for gid in ["GO:0004", "GO:0001", "GO:0007", "GO:0002", "GO:0003"]:
+        for dt, n_d in (("name", 1), ("label", 1), ("synonym_exact", 2)):
+            for _ in range(n_d):
+                rows.append({"id": gid, "description_type": dt, "description": f"{gid} {dt} {len(rows)}",
+                             "token_count": 3 + (5 * len(rows)) % 11})
+    embeddings_idx = {k: [r[k] for r in rows] for k in ("id", "description_type", "description", "token_count")}
+    embeddings = torch.randn(len(rows), 8, generator=g)
+    embeddings_idx = pd.DataFrame(embeddings_idx)
+    torch.save(embeddings, out_path)
+    torch.save(embeddings_idx, idx_path)
+
+    class _Rec:
+        def __init__(self, desc, seq):
+            self.description, self.seq = desc, seq
+
+    def _parse(path, fmt):
+        desc, seq = None, []
+        for line in open(path):
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if desc is not None:
+                    yield _Rec(desc, "".join(seq))
+                desc, seq = line[1:], []
+            elif line:
+                seq.append(line)
+        if desc is not None:
+            yield _Rec(desc, "".join(seq))
+
+    SeqIO.parse = _parse
+    from protnote.data.datasets import ProteinDataset
+
+    fasta = [("P1", "ACDEFGHIK", ["GO:0002", "GO:0004"]), ("P2", "MKTAYIAK", ["GO:0001"]), ("P3", "GGSGG", ["GO:0003", "GO:0001"])]
+    fp = os.path.join(tmp, "toy.fasta")
+    with open(fp, "w") as f:
+        for sid, seq, labs in fasta:
+            f.write(">" + " ".join([sid] + labs) + "\n" + seq + "\n")
+    real_load = torch.load
+    torch.load = lambda *a, **k: real_load(*a, **{**k, "weights_only": False})
+    try:
+        cfg = {"params": {"AUGMENT_RESIDUE_PROBABILITY": 0.0, "LABEL_AUGMENTATION_DESCRIPTIONS": "name+label",
+                          "TRAIN_SUBSET_FRACTION": 1, "TEST_SUBSET_FRACTION": 1, "VALIDATION_SUBSET_FRACTION": 1,
+                          "INFERENCE_GO_DESCRIPTIONS": "name+label", "EXTRACT_VOCABULARIES_FROM": None,
+                          "DEDUPLICATE": True, "MAX_SEQUENCE_LENGTH": 100},
+               "paths": {}, "LABEL_EMBEDDING_PATH": out_path}
+        ds = ProteinDataset({"data_path": fp, "dataset_type": "test"}, cfg, logger=logging.getLogger("g"))
+    finally:
+        torch.load = real_load
+    exp["pair/label_vocabulary"] = np.array(ds.label_vocabulary)
+    exp["pair/sorted_label_embeddings"] = ds.sorted_label_embeddings.numpy().copy()
+    exp["pair/sorted_label_token_counts"] = np.asarray(ds.sorted_label_token_counts)
+    doc["pair"] = {"params": params, "base": "frozen_label_embeddings.pt", "embedding_file": rel,
+                   "index_file": os.path.relpath(idx_path, out_dir), "descriptions": ["name", "label"]}
+    with open(os.path.join(out_dir, "disk_formats.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+    np.savez_compressed(os.path.join(out_dir, "expected.npz"), **exp)
+    print("disk_formats/", sorted(os.listdir(out_dir)), doc["checkpoint"]["first_key_in_file"], rel)
+
+
 def golden_grid_samplers():
     """Index streams of protnote/data/samplers.py::GridBatchSampler (Python `random`, seeded) and
     ::GeneralDistributedSampler (rank shards of an arbitrary sampler's stream)."""
@@ -902,7 +1061,8 @@ if __name__ == "__main__":
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers,
-            "config0": golden_config0_full_width, "optimizer_branches": golden_optimizer_branches}
+            "config0": golden_config0_full_width, "optimizer_branches": golden_optimizer_branches,
+            "disk_formats": golden_disk_formats}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

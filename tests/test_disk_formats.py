@@ -63,3 +63,81 @@ def test_tf_weight_transfer_matches_reference(golden_dir):
     for k in keys:
         assert np.array_equal(sd[k].numpy(), g["sd/" + k]), k
     assert int(sd["resnet_blocks.1.bn_activation_2.0.num_batches_tracked"]) == 12345
+
+
+# ---- fixtures written / read by the reference's own code (tests/golden/make_golden.py::golden_disk_formats) ----
+def _disk(golden_dir):
+    import json
+
+    d = os.path.join(golden_dir, "disk_formats")
+    return d, json.load(open(os.path.join(d, "disk_formats.json"))), np.load(os.path.join(d, "expected.npz"))
+
+
+def test_generate_label_embedding_path_matches_reference_table(golden_dir):
+    """utils/configs.py:74-107: 36 (label encoder, pooling method, base path) cases produced by the reference function."""
+    import pytest
+
+    from protnote_amd.utils.configs import generate_label_embedding_path
+
+    _, doc, _ = _disk(golden_dir)
+    assert len(doc["naming"]) == 36
+    for row in doc["naming"]:
+        assert generate_label_embedding_path(row["params"], row["base"]) == row["path"], row
+    with pytest.raises(AssertionError, match=doc["unsupported_checkpoint_assertion"]):
+        generate_label_embedding_path({"LABEL_ENCODER_CHECKPOINT": "bert-base", "LABEL_EMBEDDING_POOLING_METHOD": "mean"}, "x.pt")
+
+
+def test_reference_checkpoint_from_ddp_model_loads_bit_exactly(golden_dir):
+    """A checkpoint written by the reference's save_checkpoint (utils/models.py:304-321) from a DistributedDataParallel-
+    wrapped ProtNote ('module.' keys) after one Adam step: load_checkpoint_into / load_model put exactly the tensors into the
+    twin that the reference's own load_model (:324-374) restored, and hand back its optimiser state, epoch and metric."""
+    import types
+
+    d, doc, exp = _disk(golden_dir)
+    c = doc["checkpoint"]
+    assert c["first_key_in_file"].startswith("module.")
+    enc = ProteInfer(activation=torch.nn.ReLU, **c["enc_cfg"])
+    model = ProtNote(sequence_encoder=enc, label_encoder=None, feature_fusion="concatenation", **c["head_cfg"])
+    rest = M.load_checkpoint_into(model, os.path.join(d, c["file"]))
+    sd = model.state_dict()
+    keys = [k[len("ckpt/sd/"):] for k in exp.files if k.startswith("ckpt/sd/")]
+    assert sorted(keys) == sorted(sd)
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), exp["ckpt/sd/" + k]), k
+    assert rest["epoch"] == c["epoch"] == 7 and rest["best_val_metric"] == c["best_val_metric"]
+    osd = rest["optimizer_state_dict"]
+    assert osd["param_groups"][0]["params"] == c["optimizer_param_ids"] and osd["param_groups"][0]["lr"] == c["optimizer_lr"]
+    for i, st in osd["state"].items():
+        assert np.array_equal(st["exp_avg"].numpy(), exp[f"ckpt/opt/{i}/exp_avg"])
+        assert np.array_equal(st["exp_avg_sq"].numpy(), exp[f"ckpt/opt/{i}/exp_avg_sq"])
+        assert float(st["step"]) == float(exp[f"ckpt/opt/{i}/step"])
+    # the load_model twin on a trainer-shaped object (torch Adam here: no GPU in this test)
+    model2 = ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **c["enc_cfg"]), label_encoder=None,
+                      feature_fusion="concatenation", **c["head_cfg"])
+    for n, p in model2.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+    tr = types.SimpleNamespace(model=model2, optimizer=torch.optim.Adam([p for p in model2.parameters() if p.requires_grad], lr=1.0),
+                               starting_epoch=1, epoch=1, best_val_metric=0.0)
+    M.load_model(tr, os.path.join(d, c["file"]), rank=0, from_checkpoint=True)
+    assert (tr.epoch, tr.starting_epoch, tr.best_val_metric) == (c["epoch"], c["starting_epoch"], c["best_val_metric"])
+    assert tr.optimizer.state_dict()["param_groups"][0]["lr"] == c["optimizer_lr"]
+    assert all(np.array_equal(model2.state_dict()[k].numpy(), exp["ckpt/sd/" + k]) for k in keys)
+    M.load_model(tr2 := types.SimpleNamespace(model=model2, optimizer=None, epoch=1), os.path.join(d, c["file"]))
+    assert tr2.epoch == 1  # without from_checkpoint only the weights move
+
+
+def test_label_embedding_pair_in_producer_layout_reads_like_the_reference_dataset(golden_dir):
+    """The cached pair as bin/generate_label_embeddings.py:93-97,159-164 lays it out (tensor + `<stem>_index.<ext>` DataFrame),
+    named by generate_label_embedding_path; load_label_embedding_cache returns exactly the sorted embedding rows and token
+    counts the reference's ProteinDataset (datasets.py:115-127,269-343) derived from the same two files."""
+    from protnote_amd.utils.configs import generate_label_embedding_path
+
+    d, doc, exp = _disk(golden_dir)
+    pr = doc["pair"]
+    rel = generate_label_embedding_path(pr["params"], pr["base"])
+    assert rel == pr["embedding_file"] and M.index_path_for(rel) == pr["index_file"]
+    vocab = [str(v) for v in exp["pair/label_vocabulary"]]
+    emb, counts, per = M.load_label_embedding_cache(os.path.join(d, rel), vocab, tuple(pr["descriptions"]))
+    assert np.array_equal(emb.numpy(), exp["pair/sorted_label_embeddings"])
+    assert np.array_equal(counts.numpy(), exp["pair/sorted_label_token_counts"]) and per == 2

@@ -1545,3 +1545,43 @@ def test_two_models_on_two_streams_concurrently_equal_serial():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
         for x, z in zip(a[3], b[3]):
             assert torch.equal(x, z), k
+
+
+def test_reference_ddp_checkpoint_resumes_on_the_fused_optimizer(golden_dir):
+    """--from-checkpoint on the HIP path (bin/main.py:521-527 -> utils/models.py:324-374): a checkpoint the reference's
+    save_checkpoint wrote from a DDP-wrapped model and its torch Adam is restored by the load_model twin into the twin
+    model + FusedClipAdam built by build_training - weights, Adam moments by parameter id, step count, epoch, metric -
+    and training continues from it."""
+    import json
+
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.protein_encoders import ProteInfer
+    from protnote_amd.utils import models as M
+    from protnote_amd.utils.configs import build_training
+
+    d = os.path.join(golden_dir, "disk_formats")
+    c = json.load(open(os.path.join(d, "disk_formats.json")))["checkpoint"]
+    exp = np.load(os.path.join(d, "expected.npz"))
+    enc = ProteInfer(activation=torch.nn.ReLU, **c["enc_cfg"])
+    model = ProtNote(sequence_encoder=enc, label_encoder=None, feature_fusion="concatenation", **c["head_cfg"]).to(DEV)
+    cfg = {"params": {"LOSS_FN": "BCE", "BCE_POS_WEIGHT": 1, "OPTIMIZER": "Adam", "LEARNING_RATE": 1.0, "CLIP_VALUE": 1,
+                      "TRAIN_SEQUENCE_ENCODER": False}}
+    loss_fn, opt, trainer = build_training(cfg, model)
+    M.load_model(trainer, os.path.join(d, c["file"]), rank=0, from_checkpoint=True)
+    assert (trainer.epoch, trainer.starting_epoch, trainer.best_val_metric) == (7, 7, c["best_val_metric"])
+    assert opt.step_count == 1 and opt.lr == c["optimizer_lr"]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    for k, v in model.state_dict().items():
+        assert np.array_equal(v.cpu().numpy(), exp["ckpt/sd/" + k]), k
+    off = dict((id(p), o) for p, o in opt._offsets())
+    for i, (n, p) in enumerate(named):  # the reference's ids = position in the requires_grad-filtered list
+        o = off[id(p)]
+        assert np.array_equal(opt.flat_m[o:o + p.numel()].view_as(p).cpu().numpy(), exp[f"ckpt/opt/{i}/exp_avg"]), n
+        assert p.data_ptr() == opt.flat_w.data_ptr() + 4 * o  # still views of the flat block after the load
+    gen = torch.Generator().manual_seed(1)
+    x = torch.nn.functional.one_hot(torch.randint(0, 20, (3, 12), generator=gen), 20).permute(0, 2, 1).float().to(DEV)
+    batch = {"sequence_onehots": x, "sequence_lengths": torch.tensor([12, 7, 12]).to(DEV),
+             "label_embeddings": torch.randn(6, 8, generator=gen).to(DEV),
+             "label_multihots": (torch.rand(3, 6, generator=gen) < 0.4).float().to(DEV)}
+    out = trainer.train_one_epoch([batch])
+    assert np.isfinite(out["loss"]) and opt.step_count == 2
