@@ -65,6 +65,9 @@ typedef struct pn_encoder {
   const float* conv1_w; /* packed [C][ksize][ld4(Cin)] */
   const float* conv1_b; /* [C] */
   pn_res_block blk[PN_MAX_BLOCKS];
+  /* pn_encoder_fwd_train / pn_encoder_bwd only: != 0 = BatchNorm in EVAL mode inside a differentiable forward (see
+   * pn_mlp.bn_use_running); pn_encoder_fwd takes its mode from the `training` argument */
+  int bn_use_running;
 } pn_encoder;
 
 /* torch Conv1d weight [Cout][Cin][k] -> packed [Cout][k][ld4(Cin)] (zero pad lanes). */
@@ -93,6 +96,11 @@ typedef struct pn_mlp {
   float dropout_p;
   unsigned dropout_seed;
   int dropout_stream; /* base of this stack's mask streams: 100 for W_p, 200 for W_l (pn_dropout_mask) */
+  /* *_fwd_train / *_bwd only.  0 (default): train-mode BatchNorm - batch statistics, running statistics updated.
+   * != 0: the module is in eval() but autograd is on (reference ProtNote.forward puts no mode restriction on either,
+   * ProtNote.py:243-309): normalise with the RUNNING statistics, update nothing; the backward treats them as
+   * constants (dz = relu' * g * gamma/sigma; dgamma / dbeta as usual). */
+  int bn_use_running;
 } pn_mlp;
 
 size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows);
@@ -119,6 +127,7 @@ typedef struct pn_pairhead {
    * generated inside the operand loaders of the next GEMM and regenerated in the backward from the same seed */
   float dropout_p;
   unsigned dropout_seed;
+  int bn_use_running; /* as in pn_mlp: eval-mode BatchNorm inside pn_pairhead_fwd_train / pn_pairhead_bwd */
 } pn_pairhead;
 
 size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);
@@ -153,6 +162,11 @@ int pn_additive_attention_bwd(const float* hidden, const int64_t* attention_mask
  * protein_major = 0: input is the label-major pair grid x[j*B + i]; 1: input is x[i*NL + j]. */
 int pn_ensemble_logit(const float* logits_pairs, int B, int NL, int ndesc, int protein_major, float* out,
                       void* stream);
+
+/* Backward of the ensembling for a differentiated eval-mode forward (autograd through ProtNote.py:313-322):
+ * logits [B][NL] protein-major description-row logits, dout [B][NL/ndesc] -> dlogits [B][NL]. */
+int pn_ensemble_logit_bwd(const float* logits, const float* dout, int B, int NL, int ndesc, float* dlogits,
+                          void* stream);
 
 /* ProtNote.py:219-240: out = L_f + (2u - 1) * scale, scale = alpha / sqrt(d); u ~ U[0,1) from the caller. */
 int pn_label_noise(const float* L_f, const float* u, float scale, float* out, long n, void* stream);

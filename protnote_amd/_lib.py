@@ -29,21 +29,23 @@ class pn_res_block(C.Structure):
 class pn_encoder(C.Structure):
     _fields_ = [("Cin", C.c_int), ("C", C.c_int), ("Cb", C.c_int), ("ksize", C.c_int), ("nblocks", C.c_int),
                 ("dil_base", C.c_int), ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p),
-                ("blk", pn_res_block * PN_MAX_BLOCKS)]
+                ("blk", pn_res_block * PN_MAX_BLOCKS), ("bn_use_running", C.c_int)]
 
 
 class pn_mlp(C.Structure):
     _fields_ = [("nlayers", C.c_int), ("dims", C.c_int * (PN_MAX_LAYERS + 1)),
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint), ("dropout_stream", C.c_int)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint), ("dropout_stream", C.c_int),
+                ("bn_use_running", C.c_int)]
 
 
 class pn_pairhead(C.Structure):
     _fields_ = [("d", C.c_int), ("in_dim", C.c_int), ("fusion", C.c_int), ("nlayers", C.c_int), ("h", C.c_int),
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
-                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint)]
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint),
+                ("bn_use_running", C.c_int)]
 
 
 class pn_res_block_grads(C.Structure):
@@ -89,6 +91,7 @@ _SIGS = {
     "pn_additive_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_ensemble_logit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pn_ensemble_logit_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_label_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pn_similarity_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,

@@ -646,8 +646,43 @@ __global__ void k_bn_fold_train(pn_bn bn, const double* sum, const double* sumsq
 }
 
 // fold of a train-mode BatchNorm from this rank's column sums; with SYNC_BN the sums of all ranks (see pn_set_sync_bn)
+// BatchNorm in EVAL mode inside a differentiable forward (model.eval() with autograd on: reference ProtNote.forward has
+// no mode restriction, ProtNote.py:243-309): the fold comes from the running statistics, nothing is updated, and the
+// saved mean / invstd are the running ones, so the backward's xhat, dgamma, dbeta follow - only the batch-statistics
+// terms (p, q of the dz generator) vanish.  Selected per call by the descriptor's bn_use_running field; the exported
+// functions run in one host thread each, so a thread-local carries it to the fold / finalise helpers.
+static thread_local bool tl_bn_running = false;
+struct BnMode {
+  bool prev;
+  explicit BnMode(bool on) : prev(tl_bn_running) { tl_bn_running = on; }
+  ~BnMode() { tl_bn_running = prev; }
+};
+
+__global__ void k_bn_fold_running(pn_bn bn, float eps, int C, int ld, float* s, float* t, float* mean_out,
+                                  float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+  if (c < C) {
+    mu = bn.running_mean[c];
+    is = 1.f / sqrtf(bn.running_var[c] + eps);
+    sc = bn.weight[c] * is;
+    sh = bn.bias[c] - mu * sc;
+  }
+  s[c] = sc;
+  t[c] = sh;
+  if (mean_out) mean_out[c] = mu;
+  if (invstd_out) invstd_out[c] = is;
+}
+
 static int fold_train(hipStream_t st, pn_bn bn, const double* sum, const double* sumsq, double count, float eps,
                       float momentum, int C, int ld, float* s, float* t, float* mean_out, float* invstd_out) {
+  if (tl_bn_running) {
+    hipLaunchKernelGGL(k_bn_fold_running, dim3(nblk(ld, 256)), dim3(256), 0, st, bn, eps, C, ld, s, t, mean_out,
+                       invstd_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   const double* gcount = nullptr;
   PN_OK(sync_sum2(const_cast<double*>(sum), const_cast<double*>(sumsq), C, count, &gcount, st));
   hipLaunchKernelGGL(k_bn_fold_train, dim3(nblk(ld, 256)), dim3(256), 0, st, bn, sum, sumsq, count, gcount, eps,
@@ -729,6 +764,32 @@ __global__ void k_ensemble(const float* __restrict__ pairs, int B, int NL, int n
     v = logf(pm / (1.f - pm));
   }
   out[(long)i * nout + jo] = v;
+}
+
+// backward of the ensembling (autograd of ProtNote.py:313-322 when an eval-mode forward is differentiated): x [B][NL]
+// protein-major logits of the description rows, dout [B][NL / ndesc] -> dx [B][NL];
+// d logit(clamp(pm)) / dx_k = [eps <= pm <= 1 - eps] / (pm (1 - pm)) * sigma'(x_k) / ndesc
+__global__ void k_ensemble_bwd(const float* __restrict__ x, const float* __restrict__ dout, int B, int NL, int ndesc,
+                               float* __restrict__ dx) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nout = NL / ndesc;
+  if (idx >= (long)B * nout) return;
+  const int i = (int)(idx / nout), jo = (int)(idx % nout);
+  const float* xr = x + (long)i * NL + (long)jo * ndesc;
+  float* dr = dx + (long)i * NL + (long)jo * ndesc;
+  const float g = dout[(long)i * nout + jo];
+  if (ndesc == 1) {
+    dr[0] = g;
+    return;
+  }
+  float acc = 0.f;
+  for (int d = 0; d < ndesc; ++d) acc += 1.f / (1.f + expf(-xr[d]));
+  const float pm = acc / (float)ndesc, eps = 1e-7f;
+  const float outer = (pm < eps || pm > 1.f - eps) ? 0.f : g / (pm * (1.f - pm)) / (float)ndesc;
+  for (int d = 0; d < ndesc; ++d) {
+    const float sg = 1.f / (1.f + expf(-xr[d]));
+    dr[d] = outer * sg * (1.f - sg);
+  }
 }
 
 // 1 / max(||x_r||_2, 1e-12)  (F.normalize, ProtNote.py:282-283); one wave per row
@@ -963,6 +1024,7 @@ extern "C" int pn_encoder_fwd_train(const pn_encoder* e, const float* onehots, c
   EncSave sv;
   if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
   if (!enc_save_carve(e, B, L, bs, sv)) return fail("encoder: save buffer too small (%zu given)", save_bytes);
+  BnMode bn_mode(e->bn_use_running != 0);
   return encoder_forward(e, onehots, lens, B, L, emb, ld_emb, 1, w, &sv, (hipStream_t)stream);
 }
 
@@ -1200,6 +1262,15 @@ extern "C" int pn_ensemble_logit(const float* logits_pairs, int B, int NL, int n
   const long n = (long)B * (NL / ndesc);
   hipLaunchKernelGGL(k_ensemble, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, logits_pairs, B, NL, ndesc,
                      protein_major, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_ensemble_logit_bwd(const float* logits, const float* dout, int B, int NL, int ndesc, float* dlogits,
+                                     void* stream) {
+  if (ndesc < 1 || NL % ndesc != 0) return fail("ensemble bwd: NL=%d not divisible by ndesc=%d", NL, ndesc);
+  hipLaunchKernelGGL(k_ensemble_bwd, dim3(nblk((long)B * (NL / ndesc), 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                     dout, B, NL, ndesc, dlogits);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1484,14 +1555,15 @@ static int bwd_finalize(hipStream_t st, const double* S1, const double* S2, cons
                         const float* gamma, const float* s, const float* mean, const float* invstd, const float* w,
                         float* cs, float* pv, float* qv, float* dgamma, float* dbeta, float* dw_out) {
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, dwacc, count,
-                     (const double*)nullptr, C, gamma, s, mean, invstd, w, cs, pv, qv, dgamma, dbeta, dw_out);
+                     (const double*)nullptr, C, gamma, s, mean, invstd, w, cs, pv, qv, dgamma, dbeta, dw_out,
+                     tl_bn_running ? 1 : 0);
   HIP_OK(hipGetLastError());
-  if (sync_bn_on() && gamma != nullptr) {
+  if (sync_bn_on() && gamma != nullptr && !tl_bn_running) {
     const double* gcount = nullptr;
     PN_OK(sync_sum2(const_cast<double*>(S1), const_cast<double*>(S2), C, count, &gcount, st));
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(C, 256)), dim3(256), 0, st, S1, S2, (const double*)nullptr,
                        count, gcount, C, gamma, s, mean, invstd, w, cs, pv, qv, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, 0);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -1587,6 +1659,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
                                      size_t save_bytes, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(mlp_check(m, ldx));
+  BnMode bn_mode(m->bn_use_running != 0);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
   MlpSave sv;
   MlpTrainWs w;
@@ -1647,6 +1720,7 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
                                size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(mlp_check(m, ldx));
+  BnMode bn_mode(m->bn_use_running != 0);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
   MlpSave sv;
   MlpTrainWs w;
@@ -1870,6 +1944,7 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
                                      size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
+  BnMode bn_mode(hd->bn_use_running != 0);
   const int h = hd->h, d = hd->d, n = hd->nlayers;
   const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
@@ -1903,7 +1978,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
   }
   if (!prod) {
     if (hd->bn[0].weight == nullptr) fold_nobn(0);
-    else if (sync_bn_on()) {
+    else if (sync_bn_on() || tl_bn_running) {
+      // (eval-mode BatchNorm in a differentiable forward: fold_train takes the running statistics and ignores the sums)
       // SYNC_BN: this rank's grid sums (sum = NL sumA + B sumB, sumsq = NL sqA + 2 sumA sumB + B sqB), added over the
       // ranks, folded like any other BatchNorm over world * B * NL rows (the ranks' tables differ, so the global grid
       // is not a product grid and the var_i(A) + var_j(Bm) shortcut does not apply)
@@ -1984,6 +2060,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
                                void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
+  BnMode bn_mode(hd->bn_use_running != 0);
   if (NL > 65535 || B > 65535)  // the layer-1 reductions put one label / protein per gridDim.y entry
     return fail("pairhead bwd: at most 65535 labels and 65535 proteins per step (got %d x %d)", B, NL);
   const int h = hd->h, d = hd->d, n = hd->nlayers;
@@ -2129,15 +2206,16 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     hipLaunchKernelGGL(k_pair_bn0_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)w.statscr.red, nchunk,
                        (const float*)sv.A1, (long)h, (const float*)w.dA1, (long)h, B, NL, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], w.cs, w.p, w.q,
-                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2, sync_bn_on() ? w.s12 : (double*)nullptr);
-    if (sync_bn_on() && hd->bn[0].weight != nullptr) {  // global S1 / S2 -> cs, p, q (dgamma / dbeta stay local)
+                       gr->dgamma[0], gr->dbeta[0], w.S1, w.S2, sync_bn_on() ? w.s12 : (double*)nullptr,
+                       tl_bn_running ? 1 : 0);
+    if (sync_bn_on() && hd->bn[0].weight != nullptr && !tl_bn_running) {  // global S1 / S2 -> cs, p, q (dgamma / dbeta stay local)
       double* s12 = w.s12;  // workspace, not the staging buffer: sync_sum2 stages through that itself
       const double* gcount = nullptr;
       PN_OK(sync_sum2(s12, s12 + h, h, (double)B * (double)NL, &gcount, st));
       hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(nblk(h, 256)), dim3(256), 0, st, (const double*)s12, (const double*)(s12 + h),
                          (const double*)nullptr, (double)B * (double)NL, gcount, h, hd->bn[0].weight,
                          (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0], (const float*)nullptr,
-                         w.cs, w.p, w.q, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                         w.cs, w.p, w.q, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
       HIP_OK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_pair_apply, dim3(nblk((long)NL * h, 256)), dim3(256), 0, st, w.dB1, (long)h,
@@ -2725,6 +2803,7 @@ extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* de
                               void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder bwd: too many blocks");
+  BnMode bn_mode(e->bn_use_running != 0);
   Bump bs(save, save_bytes), bw(ws, ws_bytes);
   EncSave sv;
   EncBwdWs w;

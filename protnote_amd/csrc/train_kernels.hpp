@@ -300,7 +300,7 @@ __global__ void k_unpack_conv_grad(const float* __restrict__ packed, int Cout, i
 __global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const double* dwacc, double count,
                                   const double* count_dev, int C, const float* gamma, const float* s, const float* mean,
                                   const float* invstd, const float* w, float* cs, float* pv, float* qv, float* dgamma,
-                                  float* dbeta, float* dw_out) {
+                                  float* dbeta, float* dw_out, int fixed_stats) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   if (count_dev != nullptr) count = *count_dev;  // SYNC_BN: the rows of all ranks (see sync_sum2)
@@ -308,10 +308,11 @@ __global__ void k_bn_bwd_finalize(const double* S1, const double* S2, const doub
   if (gamma != nullptr) {
     const float sc = s[c];
     const double c1 = S1[c] / count, c2 = S2[c] / count;
-    const float q = (float)(-(double)sc * (double)invstd[c] * c2);
+    // fixed_stats: eval-mode BatchNorm (running statistics are constants) - no batch-statistics terms in dz
+    const float q = fixed_stats ? 0.f : (float)(-(double)sc * (double)invstd[c] * c2);
     cs[c] = sc * wc;
     qv[c] = q;
-    pv[c] = (float)(-(double)sc * c1 - (double)q * (double)mean[c]);
+    pv[c] = fixed_stats ? 0.f : (float)(-(double)sc * c1 - (double)q * (double)mean[c]);
     if (dgamma) dgamma[c] = (float)S2[c];
     if (dbeta) dbeta[c] = (float)S1[c];
   } else {
@@ -554,7 +555,7 @@ __global__ void k_pair_bn0_finalize(const double* __restrict__ chunks, int nchun
                                     const float* __restrict__ M1, long ldm1, int B, int NL, int C,
                                     const float* gamma, const float* s, const float* mean, const float* invstd,
                                     float* cs, float* pv, float* qv, float* dgamma, float* dbeta, double* sumA,
-                                    double* sumB, double* s12_out) {
+                                    double* sumB, double* s12_out, int fixed_stats) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double S1 = 0, T = 0, sb = 0;
@@ -579,10 +580,10 @@ __global__ void k_pair_bn0_finalize(const double* __restrict__ chunks, int nchun
       s12_out[C + c] = S2;
     }
     const float sc = s[c];
-    const float q = (float)(-(double)sc * (double)invstd[c] * (S2 / count));
+    const float q = fixed_stats ? 0.f : (float)(-(double)sc * (double)invstd[c] * (S2 / count));
     cs[c] = sc;
     qv[c] = q;
-    pv[c] = (float)(-(double)sc * (S1 / count) - (double)q * (double)mean[c]);
+    pv[c] = fixed_stats ? 0.f : (float)(-(double)sc * (S1 / count) - (double)q * (double)mean[c]);
     if (dgamma) dgamma[c] = (float)S2;
     if (dbeta) dbeta[c] = (float)S1;
   } else {  // no BatchNorm: dz1 = du, the slot carries the Linear-bias gradient

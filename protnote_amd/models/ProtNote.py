@@ -272,6 +272,15 @@ class ProtNote(nn.Module):
         except KeyError:
             raise KeyError(f"no label table named {name!r}; call set_label_table first") from None
 
+    def _needs_graph(self, sequence_embeddings, label_embeddings) -> bool:
+        """Would autograd record anything for this forward?  (A trainable head / scorer parameter, or an input that
+        requires grad; the encoder only contributes in training mode, ProtNote.py:248-264.)"""
+        from .train_path import trainable_parameters
+
+        if any(p.requires_grad for p in trainable_parameters(self)):
+            return True
+        return any(t is not None and torch.is_tensor(t) and t.requires_grad for t in (sequence_embeddings, label_embeddings))
+
     def _train_chunk(self, B, NL):
         """Labels per chunk of the backward ring (rows = chunk * B); ~256k pair rows by default (each chunk is one
         GEMM launch of ~49k workgroups, so launch tails are <1 %; costs one chunk of slack per stored layer)."""
@@ -374,24 +383,35 @@ class ProtNote(nn.Module):
         L.require_hip(L_f)
         pool_all = self.label_embedding_pooling_method == "all"
         attn_mask = None
+        if save_embeddings and (self.training or not self.feature_fusion.startswith("concatenation")):
+            raise NotImplementedError("save_embeddings=True is implemented for inference with the concatenation heads")
+        # Which kernels run.  The reference puts no restriction on (mode, autograd) combinations (ProtNote.py:168-334):
+        #   train mode, autograd on / off -> the activation-storing path (train-mode BatchNorm: batch statistics, buffers
+        #                                    advance - also under torch.no_grad());
+        #   eval mode, autograd on and something to differentiate -> the same path with BatchNorm on its running
+        #                                    statistics (pn_*.bn_use_running): logits are differentiable;
+        #   eval mode otherwise           -> the fused inference kernels (nothing stored).
+        stored = self.training or (torch.is_grad_enabled() and not save_embeddings
+                                   and self._needs_graph(sequence_embeddings, label_embeddings))
         if pool_all:
-            # token embeddings [N, T, d] + tokenized_labels["attention_mask"] (ProtNote.py:266-267).  In a training
-            # forward the pooling happens inside forward_train (after the label noise, as in the reference, and inside
-            # the autograd graph so raw_attn_scorer is trained).
+            # token embeddings [N, T, d] + tokenized_labels["attention_mask"] (ProtNote.py:266-267).  On the stored path
+            # the pooling happens inside forward_train (after the label noise, as in the reference, and inside the
+            # autograd graph so raw_attn_scorer is trained).
             if tokenized_labels is None or "attention_mask" not in tokenized_labels:
                 raise ValueError("LABEL_EMBEDDING_POOLING_METHOD='all' needs tokenized_labels['attention_mask']")
             attn_mask = tokenized_labels["attention_mask"]
-            if not (self.training and torch.is_grad_enabled()):
+            if not stored:
                 L_f = self.additive_attention(L_f, attn_mask)
-        if save_embeddings and (self.training or not self.feature_fusion.startswith("concatenation")):
-            raise NotImplementedError("save_embeddings=True is implemented for inference with the concatenation heads")
 
         with torch.autocast(device_type="cuda", enabled=False):  # kernels are f32; ignore AMP (ProtNoteTrainer.py:728)
-            if self.training and torch.is_grad_enabled():
-                from .train_path import forward_train
+            if stored:
+                from .train_path import ensemble_logits, forward_train
 
                 logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
                                        label_token_counts, attn_mask)
+                ndesc = 1 if self.training else int(self.inference_descriptions_per_label)
+                if ndesc != 1:  # ProtNote.py:308-322, differentiable
+                    logits = ensemble_logits(logits, ndesc)
                 return logits, {"output_layer_embeddings": [], "joint_embeddings": []}
 
             with torch.no_grad():
@@ -407,8 +427,6 @@ class ProtNote(nn.Module):
                     P_f = self.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
                 else:
                     raise ValueError("Incompatible sequence parameters passed to forward method.")
-                if self.training:
-                    raise NotImplementedError("train-mode forward under no_grad is not implemented")
                 P_e = self._project_eval(self.W_p, P_f)
                 L_e = self._label_projection_eval(table) if table is not None else self._project_eval(self.W_l, L_f)
                 B, NL = P_e.shape[0], L_e.shape[0]

@@ -121,8 +121,8 @@ class ProteInfer(torch.nn.Module):
         With gradients enabled and trainable parameters (TRAIN_SEQUENCE_ENCODER: True) the call is differentiable:
         pn_encoder_fwd_train keeps the activations, pn_encoder_bwd returns every parameter gradient."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.trunk_parameters()):
-            if not self.training:
-                raise NotImplementedError("differentiating the encoder in eval mode is not implemented")
+            # (eval mode: BatchNorm normalises with its running statistics, which the backward treats as constants -
+            #  pn_encoder.bn_use_running)
             return _EncoderTrainFn.apply(self, x, sequence_lengths, *self.trunk_parameters())
         L.require_hip(x, sequence_lengths)
         if x.dim() != 3 or x.shape[1] != self._dims["Cin"]:
@@ -184,13 +184,15 @@ class _EncoderTrainFn(torch.autograd.Function):
         lens = lens.detach().to(device=x.device, dtype=torch.int64).contiguous()
         B, _, Lmax = x.shape
         enc, keep = enc_mod._descriptor()
+        ctx.bn_running = enc.bn_use_running = 0 if enc_mod.training else 1
         lib = L.lib()
         save = torch.empty(lib.pn_encoder_train_save_bytes(C.byref(enc), B, Lmax), dtype=torch.uint8, device=x.device)
         ws = L.workspace(lib.pn_encoder_ws_bytes(C.byref(enc), B, Lmax), x.device, "enc")
         emb = torch.empty(B, enc_mod._dims["C"], dtype=torch.float32, device=x.device)
         L.check(lib.pn_encoder_fwd_train(C.byref(enc), L.ptr(x), L.ptr(lens), B, Lmax, L.ptr(emb), emb.shape[1],
                                          L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), L.stream_ptr()))
-        enc_mod._bump_batches_tracked()
+        if enc_mod.training:
+            enc_mod._bump_batches_tracked()
         ctx.enc_mod, ctx.save, ctx.shape, ctx.params = enc_mod, save, (B, Lmax), params
         del keep
         return emb
@@ -199,6 +201,7 @@ class _EncoderTrainFn(torch.autograd.Function):
     def backward(ctx, demb):
         enc_mod, (B, Lmax) = ctx.enc_mod, ctx.shape
         enc, keep = enc_mod._descriptor()
+        enc.bn_use_running = ctx.bn_running
         lib = L.lib()
         demb = demb.contiguous().float()
         grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in ctx.params]

@@ -6,6 +6,7 @@ output_layer): forward and backward are sequences of C-ABI calls (pn_mlp_rows_fw
 pn_pairhead_fwd_train, pn_pairhead_bwd, pn_mlp_rows_bwd); torch only routes the returned gradient tensors.
 The frozen encoder runs under no_grad with train-mode BatchNorm exactly like the reference."""
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -39,7 +40,16 @@ def _stack_params(layers):
     return ps
 
 
-def _save_buf(model, tag, nbytes, device):
+def _backward_pending(model) -> bool:
+    """True while the graph of the model's last differentiable train-path forward is still alive (its backward has not
+    run and its context has not been collected): the one activation store is then spoken for."""
+    ref = model.__dict__.get("_pn_train_pending")
+    return ref is not None and ref() is not None
+
+
+def _save_buf(model, tag, nbytes, device, temporary=False):
+    if temporary:  # a no_grad forward while another forward's backward is pending: do not touch the shared store
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     cache = model.__dict__.setdefault("_pn_train_save", {})
     buf = cache.get(tag)
     if buf is None or buf.numel() < nbytes or buf.device != device:
@@ -60,21 +70,38 @@ class _HeadsTrainFn(torch.autograd.Function):
         st = L.stream_ptr()
         ctx.model = model
         ctx.param_list = params
+        # autograd runs this under no_grad; whether a graph is being built was noted by forward_train
+        want_graph = bool(model.__dict__.pop("_pn_want_graph", True))
+        # model.eval() + autograd (reference ProtNote.forward has no mode restriction): BatchNorm normalises with its
+        # running statistics and updates nothing (pn_mlp.bn_use_running)
+        bn_running = ctx.bn_running = 0 if model.training else 1
         # The saved activations live in ONE buffer per model (2 x 101 GB at the bench config: a second copy cannot
-        # exist), so a forward invalidates the previous forward's backward.  Stamp it; backward checks the stamp.
-        ctx.generation = model.__dict__["_pn_train_generation"] = model.__dict__.get("_pn_train_generation", 0) + 1
+        # exist), so a differentiable forward invalidates the previous forward's backward.  Stamp it; backward checks
+        # the stamp.  A forward under torch.no_grad() (train-mode BatchNorm still advances its buffers)
+        # has no backward: it reuses the store when it is free and takes a temporary one while a backward is pending.
+        temporary = False
+        if want_graph:
+            ctx.generation = model.__dict__["_pn_train_generation"] = model.__dict__.get("_pn_train_generation", 0) + 1
+            try:
+                model.__dict__["_pn_train_pending"] = weakref.ref(ctx)
+            except TypeError:  # context objects without weak-reference support: assume pending until a backward runs
+                model.__dict__["_pn_train_pending"] = lambda: True
+        else:
+            ctx.generation = None
+            temporary = _backward_pending(model)
         B, NL = P_f.shape[0], L_f.shape[0]
         # OUTPUT_MLP_DROPOUT: one fresh seed per forward (host RNG: follows torch.manual_seed, no device sync); the
-        # backward regenerates the same masks from it
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model.mlp_dropout > 0 else None
+        # backward regenerates the same masks from it.  Dropout layers are the identity in eval mode.
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (model.mlp_dropout > 0 and model.training) else None
         ctx.drop_seed = seed
         mp, lp = model._mlp_desc(model.W_p, seed, 100)
         ml, ll = model._mlp_desc(model.W_l, seed, 200)
+        mp.bn_use_running = ml.bn_use_running = bn_running
         ctx.P_f, ctx.L_f = P_f, L_f
 
         def mlp_fwd(m, x, tag):
             rows = x.shape[0]
-            save = _save_buf(model, tag, lib.pn_mlp_rows_train_save_bytes(C.byref(m), rows), dev)
+            save = _save_buf(model, tag, lib.pn_mlp_rows_train_save_bytes(C.byref(m), rows), dev, temporary)
             ws = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
             y = torch.empty(rows, m.dims[m.nlayers], dtype=torch.float32, device=dev)
             L.check(lib.pn_mlp_rows_fwd_train(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(y), L.ptr(save),
@@ -85,21 +112,23 @@ class _HeadsTrainFn(torch.autograd.Function):
         L_e = mlp_fwd(ml, L_f, "W_l")
         ctx.P_e, ctx.L_e = P_e, L_e
         # BatchNorm bookkeeping of all three stacks in ONE multi-tensor add (was one tiny launch per BatchNorm)
-        tracked = [bn.num_batches_tracked for _, bn in lp + ll if bn is not None]
+        tracked = [bn.num_batches_tracked for _, bn in lp + ll if bn is not None] if model.training else []
 
         if model.feature_fusion == "similarity":
             if tracked:  # PROJECTION_HEAD_NUM_LAYERS: 1 -> no BatchNorm in W_p / W_l
                 torch._foreach_add_(tracked, 1)
             return model._similarity(P_e, L_e)
         hd, hl = model._pair_desc(seed)
+        hd.bn_use_running = bn_running
         chunk = model._train_chunk(B, NL)
         ctx.chunk = chunk
-        save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev)
+        save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev, temporary)
         ws = L.workspace(lib.pn_pairhead_train_ws_bytes(C.byref(hd), B, NL), dev, "train")
         pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
         L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
                                           L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), st))
-        tracked += [bn.num_batches_tracked for _, bn in hl[:-1] if bn is not None]
+        if model.training:
+            tracked += [bn.num_batches_tracked for _, bn in hl[:-1] if bn is not None]
         if tracked:
             torch._foreach_add_(tracked, 1)
         logits = torch.empty(B, NL, dtype=torch.float32, device=dev)
@@ -113,10 +142,11 @@ class _HeadsTrainFn(torch.autograd.Function):
             raise RuntimeError("protnote_amd: backward called twice on one train-mode forward (the saved activations "
                                "are consumed in place; retain_graph is not supported)")
         if model.__dict__.get("_pn_train_generation") != ctx.generation:
-            raise RuntimeError("protnote_amd: another train-mode forward ran on this model before this backward; the "
+            raise RuntimeError("protnote_amd: another differentiable forward ran on this model before this backward; the "
                                "saved activations (one buffer per model) were overwritten.  Call backward() after "
-                               "each forward (gradient accumulation does exactly that), or run extra forwards under "
-                               "torch.no_grad() / model.eval()")
+                               "each forward (gradient accumulation does exactly that), or run the extra forwards under "
+                               "torch.no_grad()")
+        model.__dict__["_pn_train_pending"] = None
         lib = L.lib()
         st = L.stream_ptr()
         P_f, L_f, P_e, L_e = ctx.P_f, ctx.L_f, ctx.P_e, ctx.L_e
@@ -150,6 +180,7 @@ class _HeadsTrainFn(torch.autograd.Function):
 
         # ---- pair head ----
         hd, hl = model._pair_desc(ctx.drop_seed)
+        hd.bn_use_running = ctx.bn_running
         hidden, out = hl[:-1], hl[-1][0]
         gr = L.pn_pairhead_grads()
         for i, (lin, bn) in enumerate(hidden):
@@ -176,6 +207,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         # ---- projection heads ----
         def mlp_bwd(seq, x, dy, tag, dx=None):
             m, layers = model._mlp_desc(seq, ctx.drop_seed, 100 if tag == "W_p" else 200)
+            m.bn_use_running = ctx.bn_running
             g = L.pn_mlp_grads()
             for i, (lin, bn) in enumerate(layers):
                 g.dw[i] = gbuf(lin.weight)
@@ -244,23 +276,67 @@ class _AttnPoolFn(torch.autograd.Function):
         return None, None, None, dw, db
 
 
+class _PassGradFn(torch.autograd.Function):
+    """value = `value`, gradient -> `source` unchanged (value = source + something that does not depend on it)."""
+
+    @staticmethod
+    def forward(ctx, source, value):
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _EnsembleFn(torch.autograd.Function):
+    """Inference-time description ensembling (ProtNote.py:308-322) inside a differentiated eval-mode forward."""
+
+    @staticmethod
+    def forward(ctx, logits, ndesc):
+        from .ProtNote import ProtNote
+
+        logits = logits.contiguous()
+        ctx.save_for_backward(logits)
+        ctx.ndesc = ndesc
+        return ProtNote._ensemble(logits, logits.shape[0], logits.shape[1], ndesc, protein_major=True)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (logits,) = ctx.saved_tensors
+        B, NL = logits.shape
+        dx = torch.empty_like(logits)
+        L.check(L.lib().pn_ensemble_logit_bwd(L.ptr(logits), L.ptr(dout.contiguous().float()), B, NL, ctx.ndesc, L.ptr(dx),
+                                              L.stream_ptr()))
+        return dx, None
+
+
+def ensemble_logits(logits, ndesc):
+    return _EnsembleFn.apply(logits, int(ndesc))
+
+
 def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths, L_f, label_token_counts,
                   attention_mask=None):
-    """Reference ProtNote.forward in training mode (ProtNote.py:219-309)."""
+    """Reference ProtNote.forward (ProtNote.py:219-309) on the activation-storing kernels: training mode (with or without
+    autograd: under torch.no_grad() BatchNorm still takes batch statistics and advances its buffers) and eval mode with
+    autograd on (BatchNorm on its running statistics, no noise, no dropout; the result is differentiable)."""
+    L_src = L_f
     with torch.no_grad():
         L_f = L_f.detach().float().contiguous()
-        if label_token_counts is not None and model.label_embedding_noising_alpha > 0:
+        if model.training and label_token_counts is not None and model.label_embedding_noising_alpha > 0:
             # (for [N, T, d] token embeddings the reference's scale is alpha / sqrt(L_f.shape[1]) = alpha / sqrt(T),
             #  ProtNote.py:227-230 - _noised reads shape[1] the same way)
             L_f = model._noised(L_f, torch.rand_like(L_f))
+    if L_src.requires_grad and torch.is_grad_enabled():
+        # the reference uses the caller's tensor as is (ProtNote.py:192-196; the noise is additive): gradients reach it
+        L_f = _PassGradFn.apply(L_src, L_f)
     if attention_mask is not None:  # LABEL_EMBEDDING_POOLING_METHOD: all - pooling after the noise (:266-267)
         sc = model.raw_attn_scorer
         L_f = _AttnPoolFn.apply(model, L_f, attention_mask, sc.weight, sc.bias)
     P_f = None
-    if sequence_embeddings is not None and not model.train_sequence_encoder:
-        P_f = sequence_embeddings.detach().float().contiguous()
+    if sequence_embeddings is not None and (not model.train_sequence_encoder or not model.training):
+        P_f = sequence_embeddings.float().contiguous()  # not detached, as in the reference (:243-247)
     elif sequence_onehots is not None and sequence_lengths is not None:
-        if model.train_sequence_encoder:
+        if model.train_sequence_encoder and model.training:
             # reference ProtNote.py:248-256: encoder inside the autograd graph (differentiable when its
             # parameters require grad: _EncoderTrainFn)
             P_f = model.sequence_encoder.get_embeddings(sequence_onehots, sequence_lengths)
@@ -276,8 +352,9 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
     from .ProtNote import input_dropout_p
 
     p_seq, p_lab = input_dropout_p(model.W_p), input_dropout_p(model.W_l)
-    if p_seq > 0:
+    if p_seq > 0 and model.training:
         P_f = torch.nn.functional.dropout(P_f, p_seq, training=True)
-    if p_lab > 0:
+    if p_lab > 0 and model.training:
         L_f = torch.nn.functional.dropout(L_f, p_lab, training=True)
+    model.__dict__["_pn_want_graph"] = torch.is_grad_enabled()
     return _HeadsTrainFn.apply(model, P_f, L_f, *head_parameters(model))

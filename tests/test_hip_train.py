@@ -920,7 +920,7 @@ def test_second_forward_invalidates_pending_backward(golden_dir):
               label_embeddings=b["label_embeddings"])
     l1 = loss_fn(m(**kw)[0], b["label_multihots"])
     l2 = loss_fn(m(**kw)[0], b["label_multihots"])
-    with pytest.raises(RuntimeError, match="another train-mode forward"):
+    with pytest.raises(RuntimeError, match="another differentiable forward"):
         l1.backward()
     l2.backward()  # the latest forward is intact
     m.eval()  # a forward that keeps nothing does not invalidate anything
