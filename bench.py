@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 KIND_NAMES = {
-    0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
+    0: "nt:plain", 10: "nt:bn_relu(z)", 20: "nt:pairsum_relu", 31: "nt:conv", 32: "nt:conv, f64 accumulation (trainable encoder)", 40: "nt:dz(elem)", 50: "nt:dz(rowg)",
     12: "nt:bn_relu(z)->rowdot", 22: "nt:pairsum_relu->rowdot", 3: "nt:plain->scale", 2: "nt:plain->rowdot",
     104: "tn:plain x conv tap (encoder wgrad)", 100: "tn:plain x plain", 101: "tn:plain x bn_relu", 102: "tn:plain x pairsum", 110: "tn:dz(elem) x plain", 111: "tn:dz(elem) x bn_relu",
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",

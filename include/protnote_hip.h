@@ -370,6 +370,12 @@ int pn_set_f32_dma(int on);
 /* Same switch for the bf16x3 pair-grid GEMMs (weight operand pre-split into bf16 hi / lo planes and staged by LDS-DMA). */
 int pn_set_b3_dma(int on);
 
+/* pn_encoder_fwd_train (the forward of a TRAINABLE encoder): 1 (default) = its two wide convolutions per block accumulate
+ * in float64 on the matrix cores (v_mfma_f64_16x16x4_f64) and round to f32 once, so that the stored pre-activations and
+ * the ReLU masks of the backward are the correctly rounded ones (gradient error class of the reference's f32 CPU run
+ * instead of that of a K = 9900 f32 chain); 0 = the f32-MFMA kernels of pn_encoder_fwd (A/B measurements). */
+int pn_set_encoder_f64(int on);
+
 /* The dropout keep-mask the kernels generate for (seed, stream, rows x cols): out[r][c] = 1.0 (kept) or 0.0, so a
  * test can hand the oracle the very same masks.  stream: row MLP hidden layer l -> base + l, its output -> base + 99
  * (base 100 for W_p, 200 for W_l); pair-head hidden layer l -> 300 + l.  A pair-grid row is r = j * B + i. */

@@ -33,8 +33,8 @@ SD = Dict[str, Tensor]
 def set_padding_to_sentinel(x: Tensor, lens: Tensor, sentinel: float) -> Tensor:
     """datasets.py:535-569 - x[b, :, t] = sentinel for t >= lens[b]; x is [B, C, L]."""
     b, _, l = x.shape
-    pad = torch.arange(l).expand(b, l) >= lens.unsqueeze(1)
-    return torch.where(pad.unsqueeze(1).expand_as(x), torch.tensor(sentinel, dtype=x.dtype), x)
+    pad = torch.arange(l, device=x.device).expand(b, l) >= lens.to(x.device).unsqueeze(1)
+    return torch.where(pad.unsqueeze(1).expand_as(x), torch.tensor(sentinel, dtype=x.dtype, device=x.device), x)
 
 
 def masked_conv1d(x: Tensor, lens: Tensor, w: Tensor, b: Tensor, dilation: int) -> Tensor:
@@ -422,7 +422,8 @@ def train_grads_chunked(sd: SD, P_f: Tensor, L_f: Tensor, multihots: Tensor, *, 
 # ------------------------------------------------------------------------------------------------
 def bce_loss(logits: Tensor, target: Tensor, pos_weight: float = 1.0) -> Tensor:
     """losses.py:275-276."""
-    return F.binary_cross_entropy_with_logits(logits, target, pos_weight=torch.tensor(pos_weight))
+    return F.binary_cross_entropy_with_logits(logits, target,
+                                              pos_weight=torch.tensor(pos_weight, dtype=logits.dtype, device=logits.device))
 
 
 def focal_loss(logits: Tensor, target: Tensor, gamma: float = 2.0, alpha: float = -1.0,

@@ -158,6 +158,7 @@ _SIGS = {
     "pn_set_sync_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
+    "pn_set_encoder_f64": (C.c_int, [C.c_int]),
     "pn_set_b3_dma": (C.c_int, [C.c_int]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),

@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "_obj")
 API = os.path.join(os.path.dirname(HERE), "include", "protnote_hip.h")
 # translation unit -> headers it depends on
 UNITS = {
-    "protnote_hip.hip": ["gemm_engine.hpp", "gemm_bf16x3.hpp", "gemm_dma.hpp", "gemm_conv_dma.hpp", "gemm_tn_fast.hpp", "gemm_tn.hpp", "train_kernels.hpp", "common.hpp"],
+    "protnote_hip.hip": ["gemm_engine.hpp", "gemm_bf16x3.hpp", "gemm_dma.hpp", "gemm_conv_dma.hpp", "gemm_conv_f64.hpp", "gemm_tn_fast.hpp", "gemm_tn.hpp", "train_kernels.hpp", "common.hpp"],
     "metrics.hip": ["common.hpp"],
 }
 SRC = [os.path.join(CSRC, u) for u in UNITS]

@@ -11,6 +11,7 @@
 #include "gemm_bf16x3.hpp"
 #include "gemm_dma.hpp"
 #include "gemm_conv_dma.hpp"
+#include "gemm_conv_f64.hpp"
 #include "gemm_tn_fast.hpp"
 #include "train_kernels.hpp"
 
@@ -407,6 +408,14 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
 
 // f32 pair-grid GEMMs with LDS-DMA operand staging (gemm_dma.hpp); pn_set_f32_dma(0) selects the register-staged engine
 // (the bit-identity tests compare the two)
+// float64 accumulation in the forward convolutions of a trainable encoder (gemm_conv_f64.hpp): on by default; the switch
+// exists for the A/B measurement (tools/encoder_grad_error.py) and the test that shows what it buys
+static int g_enc_f64 = 1;
+extern "C" int pn_set_encoder_f64(int on) {
+  g_enc_f64 = on ? 1 : 0;
+  return 0;
+}
+
 static int g_f32_dma = 1;
 static bool use_f32_dma() { return g_f32_dma == 1; }
 
@@ -824,7 +833,9 @@ struct EncWs {
   double *sum_x, *sq_x, *sum_z, *sq_z;
   ColScr cs;  // per-tile partials of the train-mode BatchNorm statistics
   float *H, *Wr;  // LDS-DMA convolution path (gemm_conv_dma.hpp): staged activation with guard rows, re-laid weights
+  StatScr st64;   // f64-accumulating convolutions (gemm_conv_f64.hpp): column statistics of their output
 };
+static const long ENC_COLSTAT_ROWS = 512;
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // the all-DMA convolution kernel serves the wide layers of a big enough batch (conv1 with its 20 input channels and
@@ -849,7 +860,8 @@ static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
   w.sq_z = w.sum_z ? w.sum_z + ldb : nullptr;
   colscr_carve(bp, P, ldc, w.cs);
   w.H = w.Wr = nullptr;
-  if (conv_dma_shape(ldb, ldc, P) || conv_dma_shape(ldc, ldb, P)) {
+  statscr_carve(bp, P, ENC_COLSTAT_ROWS, ldc, w.st64);
+  {  // (staged operands: the all-DMA f32 kernels at the big shapes, the f64-accumulating kernels at every shape)
     long dil = 1;
     for (int i = 1; i < e->nblocks; ++i) dil *= e->dil_base;
     const long G = (long)(e->ksize / 2) * dil;  // widest guard band
@@ -922,6 +934,33 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.bias = bias; p.resid = resid; p.ldr = ld_out;
     p.col_sum = csum; p.col_sumsq = csq;
     if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
+    if (sv != nullptr && s != nullptr && g_math_mode == 0 && g_enc_f64 && w.H != nullptr) {
+      // trainable encoder (pn_encoder_fwd_train): the two wide convolutions of a block accumulate in float64 so that
+      // the stored pre-activations - and with them the ReLU masks the backward multiplies by - are the correctly
+      // rounded ones (gemm_conv_f64.hpp).  conv1 (K = 9 x 20) keeps the f32 kernel.
+      const int Kpad = round_up(ld_in, 32), G = (ntap / 2) * dil, Lp = L + G, Cpad = round_up(Cout, 64);
+      hipLaunchKernelGGL(k_conv_relay_weight, dim3(nblk((long)Cpad * ntap * Kpad, 256)), dim3(256), 0, st, wpk, Cout, ntap,
+                         ld_in, w.Wr, Cpad, Kpad);
+      hipLaunchKernelGGL(k_conv_stage_act, dim3(nblk(((long)G + (long)B * Lp) * (Kpad / 4), 256)), dim3(256), 0, st, in,
+                         (long)ld_in, s, t, (const int*)lens32, w.H, Kpad, B, L, Lp, G, ld_in);
+      HIP_OK(hipGetLastError());
+      ConvF64Params cp;
+      cp.H = w.H + (long)G * Kpad; cp.ldh = Kpad; cp.Lp = Lp; cp.W = w.Wr; cp.ldw = (long)ntap * Kpad;
+      cp.M = (int)P; cp.N = Cout; cp.Nstore = ld_out; cp.ntap = ntap; cp.Kpad = Kpad; cp.dil = dil; cp.L = L;
+      cp.lens = lens32; cp.bias = bias; cp.resid = resid; cp.ldr = ld_out; cp.C = out; cp.ldc = ld_out;
+      {
+        ProfScope ps(32, 2.0 * (double)P * (double)Cout * (double)ntap * (double)ld_in, st);
+        hipLaunchKernelGGL(gemm_conv_f64_kernel, dim3(nblk(P, 128) * nblk(ld_out, 64)), dim3(256), 0, st, cp);
+      }
+      HIP_OK(hipGetLastError());
+      if (csum) {
+        const unsigned nrb = nblk(P, ENC_COLSTAT_ROWS);
+        hipLaunchKernelGGL(k_col_stats, dim3(nblk(Cout, 256), nrb), dim3(256), 0, st, (const float*)out, (long)ld_out, P,
+                           Cout, ENC_COLSTAT_ROWS, w.st64.part);
+        PN_OK(reduce_parts<double>(w.st64.part, nrb, 2 * Cout, Cout, csum, csq, nullptr, w.st64.red, st));
+      }
+      return 0;
+    }
     const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
     if (g_math_mode == 0 && use_f32_dma() && s != nullptr && w.H != nullptr && conv_dma_shape(ld_in, ld_out, P)) {
       // f32 default: stage relu(bn(in)) once (masked, K padded to 32, guard rows between sequences), re-lay the weights,
