@@ -376,6 +376,11 @@ int pn_set_b3_dma(int on);
  * instead of that of a K = 9900 f32 chain); 0 = the f32-MFMA kernels of pn_encoder_fwd (A/B measurements). */
 int pn_set_encoder_f64(int on);
 
+/* conv1 of the encoder (MaskedConv1D(20 -> C, k), protein_encoders.py:84-91): 1 (default) = when the input is one-hot
+ * (checked on the device per call) a gather-sum kernel bound by the activation write, bit-identical to the general
+ * convolution, which only runs for inputs that are not one-hot; 0 = always the general convolution (A/B, tests). */
+int pn_set_conv1_gather(int on);
+
 /* The dropout keep-mask the kernels generate for (seed, stream, rows x cols): out[r][c] = 1.0 (kept) or 0.0, so a
  * test can hand the oracle the very same masks.  stream: row MLP hidden layer l -> base + l, its output -> base + 99
  * (base 100 for W_p, 200 for W_l); pair-head hidden layer l -> 300 + l.  A pair-grid row is r = j * B + i. */

@@ -159,6 +159,7 @@ _SIGS = {
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
     "pn_set_encoder_f64": (C.c_int, [C.c_int]),
+    "pn_set_conv1_gather": (C.c_int, [C.c_int]),
     "pn_set_b3_dma": (C.c_int, [C.c_int]),
     "pn_prof_begin": (C.c_int, []),
     "pn_prof_end": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double),

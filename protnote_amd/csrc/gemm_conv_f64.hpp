@@ -162,4 +162,155 @@ __global__ void k_col_stats(const float* __restrict__ X, long ldx, long R, int C
   part[((long)blockIdx.y * 2 + 1) * C + c] = s2;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv1 on ONE-HOT input (MaskedConv1D(20 -> 1100, k = 9), protein_encoders.py:84-91,110): with exactly one 1.0
+// per residue the convolution is a gather-sum, y[p][c] = b[c] + sum_tap W[c][aa[p + tap - k/2]][tap] - 9 adds per output
+// instead of 180 multiply-adds, bound by writing the [B*L, 1100] activation (4 400 B per residue).  The f32-MFMA chain
+// adds the same terms in the same (tap) order and every other product is an exact 0, so the result is BIT-IDENTICAL to
+// the general convolution.  k_onehot_ids recognises one-hot input (and raises *flag otherwise: soft / augmented inputs
+// take the general kernel, which is launched behind this one with GemmParams::run_if = flag).
+// ------------------------------------------------------------------------------------------------------------------
+// ids[p] = index of the 1.0 of residue p, -1 for an all-zero column or a pad position; *flag |= 1 when a live residue is
+// anything else.  onehots [B][Cin][L].
+__global__ void k_onehot_ids(const float* __restrict__ x, const int* __restrict__ lens, signed char* __restrict__ ids,
+                             int* __restrict__ flag, int B, int Cin, int L) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)B * L) return;
+  const int b = (int)(p / L), t = (int)(p - (long)b * L);
+  int id = -1;
+  if (t < lens[b]) {
+    const float* src = x + (long)b * Cin * L + t;
+    int ones = 0;
+    bool bad = false;
+    for (int c = 0; c < Cin; ++c) {
+      const float v = src[(long)c * L];
+      if (v == 1.f) {
+        id = c;
+        ++ones;
+      } else if (v != 0.f) {
+        bad = true;
+      }
+    }
+    if (bad || ones > 1) atomicOr(flag, 1);
+  }
+  ids[p] = (signed char)id;
+}
+
+// packed conv weight [C][ntap][ldi] -> Wt [ntap][Cin][ldc] (output channel fastest), zero pad lanes
+__global__ void k_conv1_relay(const float* __restrict__ w, int C, int ntap, int Cin, int ldi, float* __restrict__ out,
+                              int ldc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)ntap * Cin * ldc) return;
+  const int c = (int)(i % ldc);
+  const int a = (int)((i / ldc) % Cin);
+  const int tap = (int)(i / ((long)ldc * Cin));
+  out[i] = c < C ? w[((long)c * ntap + tap) * ldi + a] : 0.f;
+}
+
+// One workgroup (512 threads): `tiles` row tiles of BM residues x one 64-channel slice whose weights sit in LDS as
+// [tap][1 + Cin][64] - row 0 of every tap is all zeros, so "no residue here" (outside the sequence, an all-zero column)
+// is just another row and the inner loop has no select: it adds +0.  Thread (rl = tid / 16, cl = tid % 16): residues rl,
+// rl + 32, ... of a tile, channels 4 cl .. 4 cl + 3 of the slice.  Per tile, each row's NTAP weight-row indices (one byte
+// each) and its live flag are staged in LDS once (16 bytes per row: one ds_read_b128), so a tap costs a byte extract, an
+// address add, a 16-byte LDS read and four adds.  col_part (train-mode BatchNorm statistics of the output, optional):
+// [row tile][2][C] f32 partials, the layout and tile height of the general convolution's epilogue, so the same
+// fixed-order reduction finishes them.
+template <int NTAP>
+__global__ __launch_bounds__(512) void k_conv1_gather(const signed char* __restrict__ ids, const int* __restrict__ lens,
+                                                      const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int P, int L, int C, int ldc, int Cin,
+                                                      const int* __restrict__ flag, float* __restrict__ col_part,
+                                                      int BM, int tiles) {
+  static_assert(NTAP <= 12, "row indices of one residue are packed into 12 bytes");
+  if (*flag != 0) return;
+  constexpr int CS = 64, RL = 32, NT = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int R1 = Cin + 1;
+  float* Ws = smem;                               // [NTAP * (1 + Cin)][CS]
+  float* red = Ws + (size_t)NTAP * R1 * CS;       // [RL][2][CS]
+  unsigned* ridx = (unsigned*)(red + RL * 2 * CS);  // [BM][4]: bytes 0 .. NTAP-1 = weight row of each tap, byte 15 = live
+  const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+  // (blockIdx.x = channel slice: the slices of one row tile run at the same time, so a 4.4 KB activation row is written
+  //  by its 18 workgroups together instead of in 18 visits far apart)
+  const int c0 = blockIdx.x * CS, col = c0 + 4 * cl;
+  const bool cin_range = col < ldc;
+  for (int i = tid; i < NTAP * R1 * (CS / 4); i += NT) {
+    const int row = i / (CS / 4), q = i - row * (CS / 4);
+    const int tap = row / R1, a1 = row - tap * R1;  // a1 = 0: the zero row
+    const int cc = c0 + 4 * q;
+    const float4 v = (a1 > 0 && cc < ldc) ? ld4(Wt + ((long)tap * Cin + (a1 - 1)) * ldc + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(Ws + row * CS + 4 * q) = v;
+  }
+  float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cin_range && bias != nullptr) {
+    bj.x = col + 0 < C ? bias[col + 0] : 0.f;
+    bj.y = col + 1 < C ? bias[col + 1] : 0.f;
+    bj.z = col + 2 < C ? bias[col + 2] : 0.f;
+    bj.w = col + 3 < C ? bias[col + 3] : 0.f;
+  }
+  const bool c0ok = col + 0 < C, c1ok = col + 1 < C, c2ok = col + 2 < C, c3ok = col + 3 < C;
+  constexpr int half = NTAP / 2;
+  const int ntile = (P + BM - 1) / BM;
+  const unsigned ws_lane = lds_addr(Ws) + 16u * cl;
+  for (int tl = 0; tl < tiles; ++tl) {
+    const int tile = blockIdx.y * tiles + tl;
+    if (tile >= ntile) break;
+    const int row0 = tile * BM;
+    __syncthreads();
+    for (int k = tid; k < BM; k += NT) {
+      const int p = row0 + k;
+      unsigned w4[4] = {0u, 0u, 0u, 0u};
+      if (p < P) {
+        const int b = p / L, t = p - b * L;
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+          const int tt = t + tap - half;
+          const int id = ((unsigned)tt < (unsigned)L) ? (int)ids[p + tap - half] : -1;  // (pads carry -1)
+          w4[tap >> 2] |= (unsigned)(tap * R1 + id + 1) << (8 * (tap & 3));
+        }
+        if (t < lens[b]) w4[3] |= 0x80000000u;
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) w4[tap >> 2] |= (unsigned)(tap * R1) << (8 * (tap & 3));
+      }
+      *reinterpret_cast<uint4*>(ridx + 4 * k) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    __syncthreads();
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int r = rl; r < BM; r += RL) {
+      if (row0 + r >= P) break;
+      const uint4 rx = *reinterpret_cast<const uint4*>(ridx + 4 * r);
+      const unsigned w4[4] = {rx.x, rx.y, rx.z, rx.w};
+      const bool live = (rx.w >> 31) != 0;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const unsigned row = (w4[tap >> 2] >> (8 * (tap & 3))) & (tap == 15 ? 0x7fu : 0xffu);
+        const float4 wv = lds_read4(ws_lane + row * (CS * 4u));
+        // the terms of the k-ordered fmaf chain in its order (acc = fma(1, w, acc)); the zero row adds +0
+        acc.x += wv.x; acc.y += wv.y; acc.z += wv.z; acc.w += wv.w;
+      }
+      float4 v;  // (acc + bias) on live rows, 0 elsewhere and in the pad lanes (E_CONV)
+      v.x = (live && c0ok) ? acc.x + bj.x : 0.f;
+      v.y = (live && c1ok) ? acc.y + bj.y : 0.f;
+      v.z = (live && c2ok) ? acc.z + bj.z : 0.f;
+      v.w = (live && c3ok) ? acc.w + bj.w : 0.f;
+      if (cin_range) *reinterpret_cast<float4*>(out + (long)(row0 + r) * ldc + col) = v;
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+    if (col_part != nullptr) {
+      *reinterpret_cast<float4*>(red + (rl * 2 + 0) * CS + 4 * cl) = s1;
+      *reinterpret_cast<float4*>(red + (rl * 2 + 1) * CS + 4 * cl) = s2;
+      __syncthreads();
+      if (tid < 2 * CS) {
+        const int which = tid / CS, c = tid - which * CS;
+        float a = 0.f;
+        for (int w = 0; w < RL; ++w) a += red[(w * 2 + which) * CS + c];
+        if (c0 + c < C) col_part[((long)tile * 2 + which) * C + c0 + c] = a;
+      }
+    }
+  }
+}
+
 }  // namespace pn

@@ -94,6 +94,8 @@ struct GemmParams {
   const uint16_t* w_hi;  // stages them by LDS-DMA (set by the launcher from wsplit)
   const uint16_t* w_lo;
   int xcd_br, xcd_bc;  // > 0: XCD-aware order in br x bc tile blocks (set by the launcher when the grid suits it)
+  const int* run_if;   // optional device flag: the whole launch is a no-op while *run_if == 0 (the general convolution
+                       // behind the one-hot gather kernel of conv1 runs only when the input turned out not to be one-hot)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -138,6 +140,7 @@ __device__ __forceinline__ void pin4(float4& v) {
 // workgroups through that L2, and a row-panel is needed by ntn/bc XCDs instead of all 8.
 template <int BM, int BN>
 __device__ __forceinline__ bool tile_coords(const GemmParams& p, int& tile_m, int& tile_n) {
+  if (p.run_if != nullptr && *p.run_if == 0) return false;
   const int bid = blockIdx.x;
   const int ntn = (p.Nstore + BN - 1) / BN;
   if (PN_XCD && p.xcd_bc > 0) {

@@ -49,6 +49,7 @@ struct TnParams {
   // ---- output ----
   float* Cpart;  // [nsplit][M][ldc]
   long ldc;
+  long row_base;       // generic kernel: first row of split 0 (a tail launch over rows [row_base, R) of a bigger contraction)
   int* task_sync;  // optional [tasks][4] arrival counters (zeroed by the launcher): keeps a task's workgroups in step
   int task_ns;   // > 0: 1-D grid of 32-workgroup region tasks over a 12 x 12 tile grid with task_ns row splits (see kernel)
 };
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_tn_kernel(const TnPar
     tile_m = blockIdx.x / ntn;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const long r_begin = (long)split * p.rows_per_split;
+  const long r_begin = p.row_base + (long)split * p.rows_per_split;
   long r_end = r_begin + p.rows_per_split;
   if (r_end > p.R) r_end = p.R;
 

@@ -416,6 +416,13 @@ extern "C" int pn_set_encoder_f64(int on) {
   return 0;
 }
 
+// conv1 on one-hot input as a gather-sum (k_conv1_gather); 0 = always the general convolution (A/B, bit-identity test)
+static int g_conv1_gather = 1;
+extern "C" int pn_set_conv1_gather(int on) {
+  g_conv1_gather = on ? 1 : 0;
+  return 0;
+}
+
 static int g_f32_dma = 1;
 static bool use_f32_dma() { return g_f32_dma == 1; }
 
@@ -586,7 +593,8 @@ __global__ void k_lens32(const int64_t* lens, int* out, int B) {
 // [B][Cin][L] f32 -> channels-last [B*L][ld], padding (t >= len) and pad lanes zeroed
 // (first half of MaskedConv1D.forward, protein_encoders.py:14)
 __global__ void k_ncl_to_nlc(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ out,
-                             int B, int Cin, int L, int ld) {
+                             int B, int Cin, int L, int ld, const int* __restrict__ run_if) {
+  if (run_if != nullptr && *run_if == 0) return;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (long)B * L) return;
   const int b = (int)(p / L), t = (int)(p - (long)b * L);
@@ -834,7 +842,17 @@ struct EncWs {
   ColScr cs;  // per-tile partials of the train-mode BatchNorm statistics
   float *H, *Wr;  // LDS-DMA convolution path (gemm_conv_dma.hpp): staged activation with guard rows, re-laid weights
   StatScr st64;   // f64-accumulating convolutions (gemm_conv_f64.hpp): column statistics of their output
+  signed char* ids;  // conv1 as a gather-sum over one-hot input: residue ids, the "not one-hot" flag, re-laid weights
+  int* oh_flag;
+  float* W1t;
 };
+static const int CONV1_GATHER_CS = 64;
+static bool conv1_gather_shape(const pn_encoder* e) {  // the weight slice [ksize * Cin][64] must fit the LDS next to the scratch
+  return e->ksize == 9 && e->ksize * (e->Cin + 1) <= 255;  // (weight-row indices are bytes; the kernel is built for k = 9)
+}
+static size_t conv1_gather_lds(const pn_encoder* e, int BM) {
+  return ((size_t)e->ksize * (e->Cin + 1) * CONV1_GATHER_CS + 32 * 2 * CONV1_GATHER_CS) * sizeof(float) + 16 * (size_t)BM + 16;
+}
 static const long ENC_COLSTAT_ROWS = 512;
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -861,6 +879,9 @@ static bool enc_carve(const pn_encoder* e, int B, int L, Bump& bp, EncWs& w) {
   colscr_carve(bp, P, ldc, w.cs);
   w.H = w.Wr = nullptr;
   statscr_carve(bp, P, ENC_COLSTAT_ROWS, ldc, w.st64);
+  w.ids = (signed char*)bp.take<char>((size_t)P);
+  w.oh_flag = bp.take<int>(64);
+  w.W1t = bp.take<float>((size_t)e->ksize * e->Cin * ldc);
   {  // (staged operands: the all-DMA f32 kernels at the big shapes, the f64-accumulating kernels at every shape)
     long dil = 1;
     for (int i = 1; i < e->nblocks; ++i) dil *= e->dil_base;
@@ -925,6 +946,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, lens32, B);
   HIP_OK(hipGetLastError());
 
+  const int* conv_run_if = nullptr;  // set around conv1: the general kernel is a no-op while the flag is 0
   auto conv = [&](const float* in, int ld_in, const float* wpk, const float* bias, int Cout, int ld_out, float* out,
                   int ntap, int dil, const float* s, const float* t, const float* resid, double* csum,
                   double* csq) -> int {
@@ -934,6 +956,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.bias = bias; p.resid = resid; p.ldr = ld_out;
     p.col_sum = csum; p.col_sumsq = csq;
     if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
+    p.run_if = conv_run_if;
     if (sv != nullptr && s != nullptr && g_math_mode == 0 && g_enc_f64 && w.H != nullptr) {
       // trainable encoder (pn_encoder_fwd_train): the two wide convolutions of a block accumulate in float64 so that
       // the stored pre-activations - and with them the ReLU masks the backward multiplies by - are the correctly
@@ -986,11 +1009,40 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   float* xn = w.xb;
   {  // K2: 4 B x Cin read + 4 B x C written per residue
     ProfScope ps(ST_CONV1, (double)P * 4.0 * (e->Cin + e->C), st);
+    // One-hot input (what the reference's collator produces): a gather-sum, bit-identical to the general convolution
+    // (gemm_conv_f64.hpp, k_conv1_gather); the general kernel is queued behind it and runs only if k_onehot_ids found a
+    // residue that is not one-hot (the flag lives on the device: no host round trip).
+    const bool gather = g_conv1_gather && w.ids != nullptr && conv1_gather_shape(e);
+    if (gather) {
+      const bool big = PN_BIG && ldc >= 512 && P >= 4096;
+      const int BM = big ? 256 : 128;  // row-tile height of the general kernel's statistics partials
+      const int tiles = P >= 65536 ? 4 : 1;
+      const size_t lds = conv1_gather_lds(e, BM);
+      static bool attr_done[64] = {false};
+      int dev = 0;
+      HIP_OK(hipGetDevice(&dev));
+      if (dev < 64 && !attr_done[dev]) {
+        HIP_OK(hipFuncSetAttribute((const void*)k_conv1_gather<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done[dev] = true;
+      }
+      HIP_OK(hipMemsetAsync(w.oh_flag, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_onehot_ids, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, w.ids, w.oh_flag, B,
+                         e->Cin, L);
+      hipLaunchKernelGGL(k_conv1_relay, dim3(nblk((long)e->ksize * e->Cin * ldc, 256)), dim3(256), 0, st, e->conv1_w, e->C,
+                         e->ksize, e->Cin, ldi, w.W1t, ldc);
+      hipLaunchKernelGGL(k_conv1_gather<9>, dim3(nblk(ldc, CONV1_GATHER_CS), nblk(nblk(P, BM), tiles)), dim3(512), lds, st,
+                         (const signed char*)w.ids, (const int*)lens32, (const float*)w.W1t, e->conv1_b, x, (int)P, L, e->C, ldc,
+                         e->Cin, (const int*)w.oh_flag, training ? w.cs.part : (float*)nullptr, BM, tiles);
+      HIP_OK(hipGetLastError());
+      conv_run_if = w.oh_flag;
+    }
+    // channels-last copy of the input: operand of the general kernel, and of the conv1 weight gradient (sv)
     hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
-                       L, ldi);
+                       L, ldi, (gather && sv == nullptr) ? (const int*)w.oh_flag : (const int*)nullptr);
     HIP_OK(hipGetLastError());
     PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
                training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+    conv_run_if = nullptr;
   }
 
   int dil = 1;
@@ -1445,6 +1497,12 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
 // the specialised f32 kernel of the big weight gradients (gemm_tn_fast.hpp); preconditions checked by launch_tn
 static const int TN_SYNC_INTS = 4096;  // arrival counters of the paced TN kernel: [splits][4 regions][4 rotating]
 
+// A contraction whose row count is not a multiple of 32 (a ragged last batch: B = 100 x 32 102 labels ...) runs its first
+// R - R % 32 rows here and the last R % 32 rows as one more split-K partial on the small generic kernel (row_base), summed
+// by the same fixed-order reduce.
+// (Tried in round 4 and removed: the pair-sum operand for batch sizes that are not multiples of 32 with a scalar per-row
+//  pair decode - 4 more B' row registers per thread push the slab loop into scratch spills, 129 instead of the generic
+//  kernel's 133 TFLOP/s at B = 100 / 250; profiles/r04_shape_sweep.json.)
 template <int TB>
 static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   // pacing only for the kind whose second operand streams from HBM too (the pair-sum kind's tables are L2-resident: 0.22 TB)
@@ -1457,8 +1515,14 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TN_FAST_LDS_BYTES));
     attr_done[dev] = true;
   }
+  const long R_all = p.R, tail = p.R % 32;
+  if (tail != 0) {
+    if (part == nullptr || part_cap_floats < 2 * (size_t)p.M * p.N) return fail("gemm_tn: no partial buffer for the row tail");
+    p.R = R_all - tail;
+    part_cap_floats -= (size_t)p.M * p.N;  // the tail's slot
+  }
   int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats, 256, 1);
-  if (ns == 1) {
+  if (ns == 1 && tail == 0) {
     p.Cpart = dst;
     p.ldc = ldd;
     p.rows_per_split = (p.R + 31) / 32 * 32;
@@ -1486,13 +1550,25 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
     }
   }
   {
-    ProfScope ps(100 + TA_PLAIN * 10 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
+    ProfScope ps(100 + TA_PLAIN * 10 + TB, 2.0 * (double)R_all * (double)p.M * (double)p.N, st);
     hipLaunchKernelGGL(kern, grid, dim3(512), TN_FAST_LDS_BYTES, st, p);
+    if (tail != 0) {  // rows [R - tail, R): one more partial, from the 128-tile generic kernel
+      auto tk = gemm_tn_kernel<TA_PLAIN, TB, false>;
+      static bool tattr[64] = {false};
+      if (dev < 64 && !tattr[dev]) {
+        HIP_OK(hipFuncSetAttribute((const void*)tk, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+        tattr[dev] = true;
+      }
+      TnParams t = p;
+      t.R = R_all; t.row_base = R_all - tail; t.rows_per_split = 32;
+      t.Cpart = part + (size_t)ns * p.M * p.N; t.ldc = p.N; t.task_ns = 0; t.task_sync = nullptr;
+      hipLaunchKernelGGL(tk, dim3((unsigned)((p.M / 128) * (p.N / 128)), 1), dim3(256), TN_LDS_BYTES, st, t);
+    }
   }
   HIP_OK(hipGetLastError());
-  if (ns > 1) {
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(nblk((long)p.M * p.N, 256)), dim3(256), 0, st, (const float*)part, ns,
-                       p.M, p.N, (long)p.N, dst, ldd);
+  if (ns > 1 || tail != 0) {
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nblk((long)p.M * p.N, 256)), dim3(256), 0, st, (const float*)part,
+                       ns + (tail != 0 ? 1 : 0), p.M, p.N, (long)p.N, dst, ldd);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -1563,14 +1639,16 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
   // 256x256 tiles for the big weight gradients (M, N multiples of 256 and a long contraction); a plain A operand (the
   // materialised dz) is staged by LDS-DMA when every split is a whole number of 32-row slabs
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
-    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 16384 && p.R % 32 == 0 && p.lda % 4 == 0) {
+    if (PN_BIG && use_f32_dma() && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 16384 && p.lda % 4 == 0) {
       if constexpr (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU) {
-        // the low-VALU kernel: 32-bit per-lane offsets, and for the pair sum a slab inside one label
+        // the low-VALU kernel: 32-bit per-lane offsets, and for the pair sum a slab inside one label (B % 32 == 0); a row
+        // count that is not a multiple of 32 leaves its tail to one extra partial
         const bool fits = (long)8 * p.ldb * 4 < (1L << 31) && p.ldb % 4 == 0 && (TB != TB_AFFINE_RELU || p.b_s != nullptr);
+        const bool tail_ok = p.R % 32 == 0 || (part != nullptr && part_cap_floats >= 3 * (size_t)p.M * p.N);
         const bool pair_ok = TB != TB_PAIRSUM_RELU || (p.pairB % 32 == 0 && p.ldb2 % 4 == 0);
-        if (fits && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
+        if (fits && tail_ok && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
       }
-      return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
+      if (p.R % 32 == 0) return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
     }
   }
   if (PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 16384)

@@ -824,10 +824,24 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
   double lsum = 0;
   float tp = 0.f, fn = 0.f, fp = 0.f;
   if (j < p.N) {
-    for (int i = i0; i < i1; ++i) {
+    // (the pass is latency-bound - 8 row blocks of 32 dependent iterations: the loads of 8 rows go out back to back)
+    constexpr int U = 8;
+    for (int ib = i0; ib < i1; ib += U) {
+      float xs[U], ys[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int iu = ib + u < i1 ? ib + u : i1 - 1;
+        const long idx = (long)iu * p.N + j;
+        xs[u] = p.logits[idx];
+        ys[u] = p.tf ? p.tf[idx] : (float)p.ti[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+      const int i = ib + u;
+      if (i >= i1) break;
       const long idx = (long)i * p.N + j;
-      const float x = p.logits[idx];
-      const float y = p.tf ? p.tf[idx] : (float)p.ti[idx];
+      const float x = xs[u];
+      const float y = ys[u];
       float l, g;
       const float sp_pos = softplusf(x);   // -log(1-sigmoid)
       const float sp_neg = softplusf(-x);  // -log(sigmoid)
@@ -873,6 +887,7 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
         tp += pred * y;
         fn += (1.f - pred) * y;
         fp += pred * (1.f - y);
+      }
       }
     }
     if (p.tp) {

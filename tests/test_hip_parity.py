@@ -608,3 +608,55 @@ def test_encoder_conv_dma_bit_identical(B, Lmax, lens, train_bn):
     if not train_bn:
         ref = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, x, lens_t)
         assert (got.cpu() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("C,B,Lmax,lens", [(1100, 10, 450, [450, 1, 333, 450, 77, 449, 40, 5, 256, 129]),
+                                           (52, 6, 200, [200, 1, 37, 150, 199, 9])])
+def test_conv1_onehot_gather_bit_identical_and_soft_input_falls_back(C, B, Lmax, lens):
+    """conv1 on one-hot input runs as a gather-sum (k_conv1_gather: 9 adds per output instead of 180 multiply-adds, bound by
+    the activation write).  It adds the terms the f32-MFMA chain adds, in the same order, and every other product is an
+    exact zero: eval-mode embeddings are BIT-IDENTICAL to the general convolution (pn_set_conv1_gather(0)), garbage in the
+    padding and an all-zero residue column included; with train-mode BatchNorm the statistics partials are summed in
+    another order (running buffers within f32 rounding).  An input that is NOT one-hot (soft / mixed residues) is detected on
+    the device and takes the general kernel: bit-identical to the switch being off, and equal to the oracle."""
+    from protnote_amd import _lib as L
+
+    cfg = dict(num_labels=11, input_channels=20, output_channels=C, kernel_size=9, dilation_base=3,
+               num_resnet_blocks=2, bottleneck_factor=0.5)
+    gen = torch.Generator().manual_seed(15)
+    sd = random_encoder_sd(cfg, gen)
+    ids = torch.randint(0, 20, (B, Lmax), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    x[0, :, lens[0]:] = 7.0   # garbage in the padding must not leak (and must not count as "not one-hot")
+    x[1 % B, :, 0] = 0.0      # an all-zero column (unknown residue): contributes nothing
+    soft = x.clone()
+    soft[3 % B, :, 2] = torch.softmax(torch.randn(20, generator=gen), 0)  # one soft residue in a live position
+    lens_t = torch.tensor(lens)
+
+    def run(inp, gather, train_bn):
+        L.check(L.lib().pn_set_conv1_gather(gather))
+        enc = make_encoder({k: v.clone() for k, v in sd.items()}, "", cfg, DEV)
+        enc.train(train_bn)
+        for p in enc.parameters():
+            p.requires_grad = False
+        emb = enc.get_embeddings(inp.to(DEV), lens_t.to(DEV))
+        torch.cuda.synchronize()
+        return emb, {k: v.clone() for k, v in enc.state_dict().items()}
+
+    try:
+        g_eval, _ = run(x, 1, False)
+        c_eval, _ = run(x, 0, False)
+        g_soft, _ = run(soft, 1, False)
+        c_soft, _ = run(soft, 0, False)
+        g_tr, sd_g = run(x, 1, True)
+        c_tr, sd_c = run(x, 0, True)
+    finally:
+        L.lib().pn_set_conv1_gather(1)
+    assert torch.equal(g_eval, c_eval)
+    assert torch.equal(g_soft, c_soft) and not torch.equal(g_soft, g_eval)
+    ref = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, x, lens_t)
+    ref_soft = O.proteinfer_get_embeddings({k: v.clone() for k, v in sd.items()}, soft, lens_t)
+    assert (g_eval.cpu() - ref).abs().max().item() < 2e-4 and (g_soft.cpu() - ref_soft).abs().max().item() < 2e-4
+    np.testing.assert_allclose(g_tr.cpu().numpy(), c_tr.cpu().numpy(), atol=2e-6, rtol=2e-6)
+    for k in sd_c:
+        np.testing.assert_allclose(sd_g[k].cpu().numpy(), sd_c[k].cpu().numpy(), atol=1e-6, rtol=1e-5, err_msg=k)
