@@ -46,7 +46,10 @@ KIND_NAMES = {
     112: "tn:dz(elem) x pairsum", 121: "tn:dz(rowg) x bn_relu", 122: "tn:dz(rowg) x pairsum",
     900: "similarity backward: dP^ / dL^ contractions + normalisation backward (pn_similarity_bwd)",
 }
-KIND_NAMES.update({1000 + k: v + " [bf16x3]" for k, v in list(KIND_NAMES.items())})
+_F32_KINDS = dict(KIND_NAMES)
+KIND_NAMES.update({1000 + k: v + " [bf16x3]" for k, v in _F32_KINDS.items()})
+# pn_set_backward_math(1): the hidden layers' backward pair-grid GEMMs on ONE bf16 product (f32 accumulation)
+KIND_NAMES.update({1500 + k: v + " [bf16, one product]" for k, v in _F32_KINDS.items() if k < 500})
 # HBM-bound streaming stages (pn_prof kinds >= 2000; the library reports their ALGORITHMIC bytes, include/protnote_hip.h)
 STAGE_NAMES = {
     2001: ("K2 conv1 from one-hots (k_ncl_to_nlc + 20-channel conv)", "4 B x (20 read + 1100 written) per residue"),
@@ -488,6 +491,39 @@ def main():
                 "roofline": roofline_block(f_prof, "bf16x3", "pair-grid 3072x3072 bf16x3 GEMM family"),
                 "kernels": kernel_table(f_prof)}
 
+    # the same step with the reference's AMP-class backward: forward as in `fast_mode` (bf16x3, logits bit-identical to
+    # it), the four backward pair-grid GEMMs of the hidden layers on ONE bf16 product with f32 accumulation
+    # (pn_set_backward_math(1); the reference trains under fp16 autocast, ProtNoteTrainer.py:728-738)
+    amp = None
+    if args.math == "f32" and not args.no_fast_mode:
+        n_amp, w_amp = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        amp = {}
+        for fwd_mode in ("bf16x3", "f32"):
+            _lib.set_math_mode(fwd_mode)
+            _lib.set_backward_math("bf16")
+            try:
+                a_elapsed, a_prof, a_loss, _ = timed_train(n_amp if fwd_mode == "bf16x3" else max(1, min(n_amp, 3)), w_amp)
+            finally:
+                _lib.set_backward_math("same")
+                _lib.set_math_mode("f32")
+            n_run = n_amp if fwd_mode == "bf16x3" else max(1, min(n_amp, 3))
+            one = {k: v for k, v in gemm_kinds(a_prof).items() if 1500 <= k < 2000 and v[0] > 0}
+            one_ms, one_fl = sum(v[1] for v in one.values()), sum(v[2] for v in one.values())
+            one_n = sum(v[0] for v in one.values())
+            ach = one_fl / (one_ms * 1e-3) / 1e12 if one_ms > 0 else 0.0
+            amp["forward_" + fwd_mode] = {
+                "math": f"forward {fwd_mode} (logits bit-identical to that mode); backward dW_l / dh_l GEMMs of the hidden "
+                        "layers: operands rounded to bf16, one MFMA product, f32 accumulation",
+                "dtype": f"forward {fwd_mode}, backward GEMMs bf16 x bf16 -> f32",
+                "value": world * B * NL * n_run / a_elapsed, "unit": "pairs/s", "ms_per_step": a_elapsed / n_run * 1e3,
+                "steps": n_run, "final_loss": a_loss,
+                "roofline": {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / BF16_MFMA_PEAK_TFLOPS, "launches": one_n,
+                             "avg_ms_per_launch": one_ms / max(one_n, 1), "flops_per_launch": one_fl / max(one_n, 1),
+                             "kernel": "backward pair-grid GEMMs on one bf16 product (gemm_nt_bf16x3_kernel<.., NP = 1> / "
+                                       "gemm_tn_bf16x3_kernel<.., NP = 1>): f32 operands converted while staging"},
+                "kernels": kernel_table(a_prof)}
+
     # ------------------------------------------------------------------ sub-benchmarks (outside the headline region)
     extra = {}
     if not args.no_extra:
@@ -617,7 +653,7 @@ def main():
     if rank == 0:
         pairs = world * B * NL * args.steps
         traffic, traffic_src, traffic_stale = None, None, None
-        for cand in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if args.math == "f32" and os.path.exists(tpath):
                 try:
@@ -671,6 +707,8 @@ def main():
                            "share_of_step": sum(v["ms_per_step"] for v in per_step.values()) / (elapsed / args.steps * 1e3)}
         if fast is not None:
             out["fast_mode"] = fast
+        if amp is not None:
+            out["amp_backward"] = amp
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

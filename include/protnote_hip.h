@@ -363,6 +363,19 @@ typedef int (*pn_sync_hook)(long n_doubles, void* user);
 int pn_set_sync_bn(pn_sync_hook hook, void* user, double* stage, long stage_doubles, int world);
 int pn_get_math_mode(void);
 
+/* Arithmetic of the BACKWARD pair-grid GEMMs of the output MLP's hidden layers (dW_l = dz_l^T h_{l-1}, dh_{l-1} = dz_l W_l):
+ * 0 (default) = whatever pn_set_math_mode selected for the forward; 1 = one product of the bf16-rounded operands with
+ * f32 accumulation (v_mfma_f32_32x32x16_bf16) - the arithmetic class of the reference's own training run, whose Linear
+ * gradient GEMMs execute in half precision under torch.autocast (ProtNoteTrainer.py:728-738).  The forward (logits are
+ * bit-identical to mode 0), the BatchNorm backward, every reduction, the layer-1 factorisation and the row MLPs are not
+ * affected; layers with OUTPUT_MLP_DROPOUT > 0 keep the f32 kernels. */
+int pn_set_backward_math(int mode);
+int pn_get_backward_math(void);
+/* Kernels of mode 1: 1 (default) = the deep-pipelined single-product kernels (gemm_bf16.hpp: every operand fetched two
+ * slabs ahead), 0 = the single-product instantiations of the bf16x3 kernels.  Same products in the same order: results are
+ * bit-identical; the switch exists for A/B timing and for the test that asserts exactly that. */
+int pn_set_bwd_deep(int on);
+
 /* Operand staging of the f32 pair-grid GEMMs: 1 (default) = LDS-DMA (global_load_lds, gemm_dma.hpp),
  * 0 = the register-staged engine (gemm_engine.hpp).  Same arithmetic in the same order: results are bit-identical;
  * the switch exists for A/B timing and for the test that asserts exactly that. */

@@ -27,3 +27,16 @@ def get_math_mode() -> str:
     from . import _lib
 
     return _lib.get_math_mode()
+
+
+def set_backward_math(mode) -> None:
+    """"same" (default) or "bf16" for the backward pair-grid GEMMs; see include/protnote_hip.h pn_set_backward_math."""
+    from . import _lib
+
+    _lib.set_backward_math(mode)
+
+
+def get_backward_math() -> str:
+    from . import _lib
+
+    return _lib.get_backward_math()

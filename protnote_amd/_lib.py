@@ -157,6 +157,9 @@ _SIGS = {
     "pn_set_mlp_materialize": (C.c_int, [C.c_int]),
     "pn_set_sync_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
     "pn_get_math_mode": (C.c_int, []),
+    "pn_set_backward_math": (C.c_int, [C.c_int]),
+    "pn_get_backward_math": (C.c_int, []),
+    "pn_set_bwd_deep": (C.c_int, [C.c_int]),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
     "pn_set_encoder_f64": (C.c_int, [C.c_int]),
     "pn_set_conv1_gather": (C.c_int, [C.c_int]),
@@ -198,6 +201,9 @@ def lib():
         mode = os.environ.get("PN_MATH_MODE")
         if mode:
             set_math_mode(mode)
+        mode = os.environ.get("PN_BACKWARD_MATH")
+        if mode:
+            set_backward_math(mode)
     return _lib
 
 
@@ -215,6 +221,23 @@ def set_math_mode(mode) -> None:
 
 def get_math_mode() -> str:
     return "bf16x3" if lib().pn_get_math_mode() == 1 else "f32"
+
+
+_BWD_MODES = {"same": 0, "0": 0, "bf16": 1, "1": 1}
+
+
+def set_backward_math(mode) -> None:
+    """Arithmetic of the backward pair-grid GEMMs of the output MLP's hidden layers: "same" (default: the forward's mode)
+    or "bf16" (one bf16 product, f32 accumulation - the class of the reference's autocast backward).  The forward and
+    the logits are not affected.  Also settable with PN_BACKWARD_MATH."""
+    key = str(mode).lower()
+    if key not in _BWD_MODES:
+        raise ValueError(f"backward math must be 'same' or 'bf16', got {mode!r}")
+    check(lib().pn_set_backward_math(_BWD_MODES[key]))
+
+
+def get_backward_math() -> str:
+    return "bf16" if lib().pn_get_backward_math() == 1 else "same"
 
 
 def check(rc: int):

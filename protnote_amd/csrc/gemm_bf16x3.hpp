@@ -56,6 +56,13 @@ __device__ __forceinline__ HiLo split4(float4 v) {
   return r;
 }
 
+// eight f32 -> eight bf16 (round to nearest even): 4 x v_cvt_pk_bf16_f32
+__device__ __forceinline__ bf16x8 round8(float4 v0, float4 v1) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8 x = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  return __builtin_convertvector(x, bf16x8);
+}
+
 // GEN = false: the pair-grid fast path (one K segment, K % 32 == 0, N % BN == 0: no masks anywhere).
 // GEN = true : segmented K with a ragged tail, ragged N, the dilated-conv tap gather (A_CONV) - the encoder's convs
 //              and the row MLPs; invalid operand quads are zeroed by selects, loads stay unconditional.
@@ -67,9 +74,14 @@ __device__ __forceinline__ HiLo split4(float4 v) {
 //              16-lane groups of ds_read_b128.  W is L2-resident (3 MB per column tile), so one region of lead time is
 //              enough: B(s+1) is issued at the top of slab s and waited for (vmcnt(0), the only VMEM in flight at that
 //              point) between the A commit and the A prefetch; the barrier at the end of the slab publishes it.
-template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, bool GEN = false, bool BDMA = false>
+// NP = 3: the three split products above.  NP = 1 ("bf16 backward", pn_set_backward_math(1)): ONE product of the bf16-rounded
+//              operands, f32 accumulation - the arithmetic class of the reference's autocast backward (ProtNoteTrainer.py:728-738:
+//              the Linear layers' gradient GEMMs run in half precision).  Same LDS image (the lo slots stay unwritten and
+//              unread), a third of the MFMAs, half of the fragment reads and LDS writes, only the hi plane is DMA-staged.
+template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, bool GEN = false, bool BDMA = false, int NP = 3>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) void gemm_nt_bf16x3_kernel(const GemmParams p) {
   static_assert(!BDMA || (!GEN && WAVES_M * WAVES_N == 8 && WAVES_N * WN * 32 == 256), "BDMA: 256-column pair-grid tiles");
+  static_assert(NP == 3 || (NP == 1 && BDMA), "the single-product variant is built for the DMA-staged pair-grid kernel");
   constexpr int BK = 32;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32;
@@ -101,13 +113,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 
   // ---- BDMA: wave w issues chunks c = 4 w + q (q < 4) of a stage: plane c / 16, tile rows 16 (c % 16) .. + 15;
   //      lane l: row + l / 4, LDS granule position l % 4 <- source granule (l % 4) ^ ((row >> 2) & 3)
+  //      (NP = 1: the 16 chunks of the hi plane only, c = 2 w + q, q < 2)
+  constexpr int NDQ = NP == 3 ? 4 : 2;
   const uint16_t* bsrc[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned bdst[4] = {0, 0, 0, 0};
   if constexpr (BDMA) {
     const int w = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * w + q;
+    for (int q = 0; q < NDQ; ++q) {
+      const int c = NDQ * w + q;
       const int r = 16 * (c & 15) + (lane >> 2);
       const int g = (lane & 3) ^ ((r >> 2) & 3);
       bsrc[q] = ((c >> 4) ? p.w_lo : p.w_hi) + (long)(col0 + r) * p.Kseg + 8 * g;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   const unsigned lds0_b = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)smem;
   auto issue_b_dma = [&](int s_, int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NDQ; ++q)
       tn_glds16(reinterpret_cast<const float*>(bsrc[q] + s_ * BK),
                 __builtin_amdgcn_readfirstlane(lds0_b + (unsigned)(buf * STAGE) * 4u + bdst[q]));
   };
@@ -265,6 +279,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   };
 
   auto store8 = [](float* dst, float4 v0, float4 v1) {
+    if constexpr (NP == 1) {
+      *reinterpret_cast<bf16x8*>(dst) = round8(v0, v1);
+      return;
+    }
     const HiLo a = split4(v0), b = split4(v1);
     bf16x8 hi, lo;
 #pragma unroll
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK);
-      al[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK + 4);
+      if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK + 4);
     }
     if constexpr (BDMA) {
       // row r of plane P: P + 16 r floats; k-group g at granule position g ^ ((r >> 2) & 3), (r >> 2) & 3 is the
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 16);
-        bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 16 + BPLANE);
+        if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 16 + BPLANE);
       }
     } else {
       const float* Bs = smem + buf * STAGE + BM * LDK + (wn * WN * 32 + frag_row) * LDK + (2 * KS + frag_g) * 8;
@@ -360,8 +378,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
   };
@@ -376,6 +396,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
   using std::integral_constant;
   auto weave = [&](auto nvalu_c) {
     constexpr int NV = decltype(nvalu_c)::value;
+    if constexpr (NP == 1) {  // 8 MFMAs per k-step; the region stages 2 x 8 elements per thread: ~3 VALU per MFMA, 2 LDS writes
+      __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+#pragma unroll
+      for (int i = 0; i < WM * WN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      return;
+    }
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);  // all fragment reads of the k-step first
 #pragma unroll
     for (int i = 0; i < WM * WN * 3; ++i) {
@@ -463,7 +493,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N) / 4) voi
 // the MFMA block are identical.  256x256 output tile, 8 waves (4 x 2, each 64 x 128), split-K partial tiles summed
 // in order by k_splitk_reduce.  Restrictions: M % 256 == 0, N % 256 == 0, TA_PLAIN, pairB % 8 == 0 for PAIRSUM.
 // ---------------------------------------------------------------------------------------------------------------
-template <int TB>
+// NP = 1: one product of the bf16-rounded operands (see the NT kernel).
+template <int TB, int NP = 3>
 __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnParams p) {
   constexpr int BM = 256, BN = 256, BK = 32, LDK = BK + 4;
   constexpr int WM = 2, WN = 4;
@@ -585,6 +616,10 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   };
 
   auto store8 = [](float* dst, const float (&v)[8]) {
+    if constexpr (NP == 1) {
+      *reinterpret_cast<bf16x8*>(dst) = round8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+      return;
+    }
     const HiLo a = split4(make_float4(v[0], v[1], v[2], v[3])), b = split4(make_float4(v[4], v[5], v[6], v[7]));
     bf16x8 hi, lo;
 #pragma unroll
@@ -647,19 +682,21 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK);
-      al[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK + 4);
+      if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * LDK + 4);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       bh[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK);
-      bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK + 4);
+      if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * LDK + 4);
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
   };
@@ -669,6 +706,16 @@ __global__ __launch_bounds__(512, PN_MINW) void gemm_tn_bf16x3_kernel(const TnPa
   using std::true_type;
   auto weave = [&](auto nvalu_c) {
     constexpr int NV = decltype(nvalu_c)::value;
+    if constexpr (NP == 1) {  // 8 MFMAs per k-step against the staging of 16 elements: 3 x the vector work per MFMA, 2 LDS writes
+      __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+#pragma unroll
+      for (int i = 0; i < WM * WN; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3 * NV, 0);
+        if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      return;
+    }
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WM + WN), 0);
 #pragma unroll
     for (int i = 0; i < WM * WN * 3; ++i) {

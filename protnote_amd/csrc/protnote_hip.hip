@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "gemm_engine.hpp"
 #include "gemm_bf16x3.hpp"
+#include "gemm_bf16.hpp"
 #include "gemm_dma.hpp"
 #include "gemm_conv_dma.hpp"
 #include "gemm_conv_f64.hpp"
@@ -350,6 +351,25 @@ extern "C" int pn_set_math_mode(int mode) {
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
 
+// Arithmetic of the BACKWARD pair-grid GEMMs of the hidden layers (dW_l = dz_l^T h_{l-1} and dh_{l-1} = dz_l W_l, l >= 1):
+// 0 = the forward's mode (default), 1 = ONE product of the bf16-rounded operands with f32 accumulation (the NP = 1 kernels
+// of gemm_bf16x3.hpp) - the arithmetic class of the reference's autocast backward (ProtNoteTrainer.py:728-738).  The
+// forward, every reduction, the BatchNorm backward and the row MLPs keep the forward's mode: logits are bit-identical.
+static int g_bwd_math = 0;
+extern "C" int pn_set_backward_math(int mode) {
+  if (mode != 0 && mode != 1) return fail("pn_set_backward_math: 0 (as the forward) or 1 (bf16, one product)");
+  g_bwd_math = mode;
+  return 0;
+}
+extern "C" int pn_get_backward_math(void) { return g_bwd_math; }
+// set by pn_pairhead_bwd around the GEMMs it applies to; read by launch_gemm / launch_tn
+static thread_local bool tl_bwd_bf16 = false;
+struct BwdBf16Scope {
+  bool prev;
+  explicit BwdBf16Scope(bool on) : prev(tl_bwd_bf16) { tl_bwd_bf16 = on; }
+  ~BwdBf16Scope() { tl_bwd_bf16 = prev; }
+};
+
 // bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; pn_set_b3_dma(0) keeps the register
 // path (the bit-identity test compares the two)
 static int g_b3_dma = 1;
@@ -359,14 +379,14 @@ extern "C" int pn_set_b3_dma(int on) {
   return 0;
 }
 
-template <int AK, int EK, int WAVES_N, int WN, bool GEN, bool BDMA = false>
+template <int AK, int EK, int WAVES_N, int WN, bool GEN, bool BDMA = false, int NP = 3>
 static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   using Cfg = GemmCfg<4, WAVES_N, 2, WN, 32>;
   if constexpr (!GEN && !BDMA && WAVES_N * WN * 32 == 256) {
     if (p.wsplit != nullptr && use_b3_dma() && p.Nstore == p.N)
       return launch_gemm_bf16x3<AK, EK, WAVES_N, WN, GEN, true>(p, st);
   }
-  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA>;
+  auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA, NP>;
   constexpr int LDS_BYTES = BDMA ? 2 * (256 * 36 + 2 * 256 * 16) * (int)sizeof(float) : Cfg::LDS_BYTES;
   static bool attr_done[64] = {false};
   int dev = 0;
@@ -399,11 +419,51 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
                        p.wsplit, p.wsplit + (size_t)p.N * p.Kseg);
   }
   {
-    ProfScope ps(1000 + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
+    ProfScope ps((NP == 3 ? 1000 : 1500) + AK * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.nseg * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
   return finish_col_stats(p, tm, st);
+}
+
+// dh = dz W of the bf16 backward on the deep-pipelined single-product kernel (gemm_bf16.hpp); preconditions checked by
+// launch_gemm.  pn_set_bwd_deep(0) keeps the NP = 1 instantiation of the bf16x3 kernel (same products in the same order:
+// the bit-identity test compares the two)
+static int g_bwd_deep = 1;
+extern "C" int pn_set_bwd_deep(int on) {
+  g_bwd_deep = on ? 1 : 0;
+  return 0;
+}
+static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
+  auto kern = gemm_nt_bf16_kernel<E_STORE>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  const long tm = (p.M + 255) / 256, tn = p.N / 256;
+  GemmParams pp = p;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
+  long grid = tm * tn;
+  if (pp.xcd_bc) {
+    const long nblk_ = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk_ + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  pp.w_hi = p.wsplit;  // W rounded to one bf16 plane [N][K], once per launch (k_split_planes' hi plane; its lo plane is unused)
+  pp.w_lo = p.wsplit + (size_t)p.N * p.Kseg;
+  hipLaunchKernelGGL(k_split_planes, dim3(nblk((long)p.N * p.Kseg / 4, 256)), dim3(256), 0, st, p.W, p.ldw, p.N, p.Kseg,
+                     p.wsplit, p.wsplit + (size_t)p.N * p.Kseg);
+  {
+    ProfScope ps(1500 + A_PLAIN * 10 + E_STORE, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16_LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // f32 pair-grid GEMMs with LDS-DMA operand staging (gemm_dma.hpp); pn_set_f32_dma(0) selects the register-staged engine
@@ -527,6 +587,16 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
       return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK, true>(p, st);
     } else {
       return fail("gemm: dropout is not defined for operand kind %d / epilogue %d", AK, EK);
+    }
+  }
+  if (tl_bwd_bf16 && PN_BIG) {  // pn_set_backward_math(1): dh = dz W on one bf16 product (weight plane by LDS-DMA)
+    if constexpr (AK == A_PLAIN && EK == E_STORE) {
+      if (variant == 0 && p.M >= 4096 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N &&
+          p.wsplit != nullptr && p.bias == nullptr && p.e_scale == nullptr && p.col_part == nullptr) {
+        if (g_bwd_deep && p.Kseg >= 96 && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0)
+          return launch_gemm_bf16_single(p, st);
+        return launch_gemm_bf16x3<AK, EK, 2, 4, false, true, 1>(p, st);
+      }
     }
   }
   if (g_math_mode == 1 && PN_BIG) {  // opt-in bf16x3 arithmetic (gemm_bf16x3.hpp)
@@ -1574,9 +1644,9 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   return 0;
 }
 
-template <int TB>
+template <int TB, int NP = 3>
 static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_bf16x3_kernel<TB>;
+  auto kern = gemm_tn_bf16x3_kernel<TB, NP>;
   constexpr int LDS = 2 * 512 * 36 * (int)sizeof(float);
   static bool attr_done[64] = {false};
   int dev = 0;
@@ -1606,7 +1676,7 @@ static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_
     grid = dim3(tn_task_grid(ns), 1);
   }
   {
-    ProfScope ps(1100 + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
+    ProfScope ps((NP == 3 ? 1100 : 1600) + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
     hipLaunchKernelGGL(kern, grid, dim3(512), LDS, st, p);
   }
   HIP_OK(hipGetLastError());
@@ -1629,6 +1699,12 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
       return launch_tn_cfg<TA, TB, false, false, true>(p, dst, ldd, part, part_cap_floats, st);
     } else {
       return fail("gemm_tn: dropout is not defined for operand kinds %d x %d", TA, TB);
+    }
+  }
+  if constexpr (TA == TA_PLAIN && (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {  // pn_set_backward_math(1)
+    if (tl_bwd_bf16 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
+        (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0)) {
+      return launch_tn_bf16x3<TB, 1>(p, dst, ldd, part, part_cap_floats, st);
     }
   }
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
@@ -2201,6 +2277,9 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
 
   const float* G = nullptr;  // gradient wrt relu(bn(z_l)) for the layer being processed (rows [0,R) of a zbuf)
   const long stats_rows = PAIR_STATS_ROWS;
+  // pn_set_backward_math(1): the two pair-grid GEMMs of every hidden layer below run on one bf16 product (the dropped
+  // layers keep the f32 kernels that carry the mask code)
+  BwdBf16Scope bwd_scope(g_bwd_math == 1 && hd->dropout_p == 0.f);
   for (int l = n - 1; l >= 1; --l) {
     const bool top = (l == n - 1);
     float* z = sv.zbuf[l] + (size_t)S * h;
@@ -2291,6 +2370,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   }
 
   // ---- layer 0: upstream gradient G = dh_0 over the pair grid ----
+  tl_bwd_bf16 = false;  // (the scope object restores the caller's value on return)
   const bool prod = hd->fusion == 2;
   float* dQ = nullptr;  // concatenation_prod: gradient wrt the P (.) L block, [R][d]
   if (!prod) {

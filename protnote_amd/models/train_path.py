@@ -47,7 +47,12 @@ def _backward_pending(model) -> bool:
     return ref is not None and ref() is not None
 
 
-def _save_buf(model, tag, nbytes, device, temporary=False):
+def _save_buf(model, tag, nbytes, device, temporary=False, private=None):
+    if private is not None:  # a store owned by ONE forward's autograd context (see _HeadsTrainFn.forward)
+        buf = private.get(tag)
+        if buf is None:
+            buf = private[tag] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return buf
     if temporary:  # a no_grad forward while another forward's backward is pending: do not touch the shared store
         return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     cache = model.__dict__.setdefault("_pn_train_save", {})
@@ -60,6 +65,24 @@ def _save_buf(model, tag, nbytes, device, temporary=False):
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         cache[tag] = buf
     return buf
+
+
+def _try_private_store(model, P_f, L_f):
+    """Room for a second set of saved activations?  Returns an (empty) private store when the three save buffers of this
+    forward fit in what the device has free (the driver's free memory plus torch's cached-but-unused blocks) with 10 %
+    to spare, else None."""
+    lib = L.lib()
+    dev = P_f.device
+    B, NL = P_f.shape[0], L_f.shape[0]
+    mp, _ = model._mlp_desc(model.W_p, None, 100)
+    ml, _ = model._mlp_desc(model.W_l, None, 200)
+    need = lib.pn_mlp_rows_train_save_bytes(C.byref(mp), B) + lib.pn_mlp_rows_train_save_bytes(C.byref(ml), NL)
+    if model.feature_fusion != "similarity":
+        hd, _ = model._pair_desc(None)
+        need += lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, model._train_chunk(B, NL))
+    free, _total = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return {} if need * 1.1 < free + cached else None
 
 
 class _HeadsTrainFn(torch.autograd.Function):
@@ -75,12 +98,21 @@ class _HeadsTrainFn(torch.autograd.Function):
         # model.eval() + autograd (reference ProtNote.forward has no mode restriction): BatchNorm normalises with its
         # running statistics and updates nothing (pn_mlp.bn_use_running)
         bn_running = ctx.bn_running = 0 if model.training else 1
-        # The saved activations live in ONE buffer per model (2 x 101 GB at the bench config: a second copy cannot
-        # exist), so a differentiable forward invalidates the previous forward's backward.  Stamp it; backward checks
-        # the stamp.  A forward under torch.no_grad() (train-mode BatchNorm still advances its buffers)
-        # has no backward: it reuses the store when it is free and takes a temporary one while a backward is pending.
+        # The saved activations of the usual one-forward-one-backward loop live in ONE grow-only buffer per model (2 x 101
+        # GB at the bench config).  A differentiable forward that starts while an earlier forward's backward is still
+        # pending gets a store of its OWN, held by its autograd context and released with it (torch semantics: both
+        # backwards work, in any order) - if the device has the memory; if it has not (two bench-size stores cannot
+        # exist), the new forward takes the shared store and the earlier backward raises.  The stamp below is what
+        # that backward checks.  A forward under torch.no_grad() (train-mode BatchNorm still advances its buffers,
+        # SURVEY 3.4-1) has no backward: it reuses the shared store when it is free and takes a temporary one otherwise.
         temporary = False
-        if want_graph:
+        ctx.own_save = None
+        B, NL = P_f.shape[0], L_f.shape[0]
+        if want_graph and _backward_pending(model):
+            ctx.own_save = _try_private_store(model, P_f, L_f)
+        if ctx.own_save is not None:
+            ctx.generation = None
+        elif want_graph:
             ctx.generation = model.__dict__["_pn_train_generation"] = model.__dict__.get("_pn_train_generation", 0) + 1
             try:
                 model.__dict__["_pn_train_pending"] = weakref.ref(ctx)
@@ -89,7 +121,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         else:
             ctx.generation = None
             temporary = _backward_pending(model)
-        B, NL = P_f.shape[0], L_f.shape[0]
+        own = ctx.own_save
         # OUTPUT_MLP_DROPOUT: one fresh seed per forward (host RNG: follows torch.manual_seed, no device sync); the
         # backward regenerates the same masks from it.  Dropout layers are the identity in eval mode.
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (model.mlp_dropout > 0 and model.training) else None
@@ -101,7 +133,7 @@ class _HeadsTrainFn(torch.autograd.Function):
 
         def mlp_fwd(m, x, tag):
             rows = x.shape[0]
-            save = _save_buf(model, tag, lib.pn_mlp_rows_train_save_bytes(C.byref(m), rows), dev, temporary)
+            save = _save_buf(model, tag, lib.pn_mlp_rows_train_save_bytes(C.byref(m), rows), dev, temporary, own)
             ws = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
             y = torch.empty(rows, m.dims[m.nlayers], dtype=torch.float32, device=dev)
             L.check(lib.pn_mlp_rows_fwd_train(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(y), L.ptr(save),
@@ -122,7 +154,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         hd.bn_use_running = bn_running
         chunk = model._train_chunk(B, NL)
         ctx.chunk = chunk
-        save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev, temporary)
+        save = _save_buf(model, "pair", lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, chunk), dev, temporary, own)
         ws = L.workspace(lib.pn_pairhead_train_ws_bytes(C.byref(hd), B, NL), dev, "train")
         pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
         L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
@@ -141,12 +173,13 @@ class _HeadsTrainFn(torch.autograd.Function):
         if model is None:
             raise RuntimeError("protnote_amd: backward called twice on one train-mode forward (the saved activations "
                                "are consumed in place; retain_graph is not supported)")
-        if model.__dict__.get("_pn_train_generation") != ctx.generation:
-            raise RuntimeError("protnote_amd: another differentiable forward ran on this model before this backward; the "
-                               "saved activations (one buffer per model) were overwritten.  Call backward() after "
-                               "each forward (gradient accumulation does exactly that), or run the extra forwards under "
-                               "torch.no_grad()")
-        model.__dict__["_pn_train_pending"] = None
+        if ctx.own_save is None:
+            if model.__dict__.get("_pn_train_generation") != ctx.generation:
+                raise RuntimeError("protnote_amd: another differentiable forward ran on this model before this backward and "
+                                   "the device had no room for a second activation store, so the saved activations were "
+                                   "overwritten.  Call backward() after each forward (gradient accumulation does exactly "
+                                   "that), or run the extra forwards under torch.no_grad()")
+            model.__dict__["_pn_train_pending"] = None
         lib = L.lib()
         st = L.stream_ptr()
         P_f, L_f, P_e, L_e = ctx.P_f, ctx.L_f, ctx.P_e, ctx.L_e
@@ -194,7 +227,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         gr.db_out = gbuf(out.bias)
         dP_e = torch.empty_like(P_e)
         dL_e = torch.empty_like(L_e)
-        save = _save_buf(model, "pair", 0, dev)
+        save = _save_buf(model, "pair", 0, dev, private=ctx.own_save)
         ws = L.workspace(lib.pn_pairhead_train_ws_bytes(C.byref(hd), B, NL), dev, "train")
         L.check(lib.pn_pairhead_bwd(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(dl_pairs), C.byref(gr),
                                     L.ptr(dP_e), L.ptr(dL_e), ctx.chunk, L.ptr(save), save.numel(), L.ptr(ws),
@@ -215,7 +248,7 @@ class _HeadsTrainFn(torch.autograd.Function):
                     g.dgamma[i] = gbuf(bn.weight)
                     g.dbeta[i] = gbuf(bn.bias)
             rows = x.shape[0]
-            sv = _save_buf(model, tag, 0, dev)
+            sv = _save_buf(model, tag, 0, dev, private=ctx.own_save)
             w = L.workspace(lib.pn_mlp_rows_train_ws_bytes(C.byref(m), rows), dev, "train")
             L.check(lib.pn_mlp_rows_bwd(C.byref(m), L.ptr(x), x.shape[1], rows, L.ptr(dy), C.byref(g), L.ptr(dx),
                                         L.ptr(sv), sv.numel(), L.ptr(w), w.numel(), st))
@@ -229,6 +262,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]):
             outs.append(grads.get(id(p)) if need else None)
         ctx.model = None
+        ctx.own_save = None  # a private store goes back to the allocator with its backward
         return (None, dP_f, dL_f, *outs)
 
 

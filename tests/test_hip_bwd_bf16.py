@@ -1,0 +1,207 @@
+"""pn_set_backward_math(1): the hidden layers' backward pair-grid GEMMs (dW_l = dz_l^T h_{l-1}, dh_{l-1} = dz_l W_l) on ONE
+bf16 product with f32 accumulation - the arithmetic class of the reference's own training run, whose Linear gradient
+GEMMs execute in half precision under torch.autocast (ProtNoteTrainer.py:728-738).  The forward is untouched."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def bwd_bf16():
+    import protnote_amd
+
+    protnote_amd.set_backward_math("bf16")
+    yield
+    protnote_amd.set_backward_math("same")
+
+
+def _full_width_model(sd):
+    from protnote_amd.models.ProtNote import ProtNote
+
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    return model.to(DEV).train()
+
+
+def _oracle_grads(sd, P_f, lab, y, dtype, autocast=False):
+    """Loss, logits and gradients of the oracle's naive formulation (stock torch ops + autograd) on the device."""
+    ref_sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()).to(DEV) for k, v in sd.items()}
+    names = O.trainable_names(ref_sd)
+    leaves = {k: ref_sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(ref_sd)
+    work.update(leaves)
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if autocast else torch.autocast("cuda", enabled=False)
+    with ctx:
+        lg = O.protnote_forward(work, None, None, lab.to(dtype).to(DEV), training=True,
+                                sequence_embeddings=P_f.to(dtype).to(DEV))
+    ls = O.bce_loss(lg.to(dtype), y.to(dtype).to(DEV))
+    grads = dict(zip(names, (g_.double().cpu() for g_ in torch.autograd.grad(ls, [leaves[k] for k in names]))))
+    return lg.detach().double().cpu(), float(ls.item()), grads
+
+
+@pytest.mark.parametrize("math_mode", ["f32", "bf16x3"])
+def test_backward_bf16_step_vs_f64_with_autocast_yardstick(math_mode):
+    """Full-width head, 256 x 300 pairs (76 800 rows: both the TN and the NT single-product kernels take their shapes).
+    (i) logits and loss are BIT-identical to the same forward mode with the default backward; (ii) every gradient is
+    within 2 x the error that the oracle's own formulation shows when torch runs it under autocast(bfloat16) on the
+    device - the acceptance bar for an AMP-class backward - measured against the float64 oracle; (iii) the gradients
+    differ from the default backward's (the single-product kernels really ran)."""
+    import protnote_amd
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(33)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 256, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64)
+    torch.cuda.empty_cache()
+    _, ls_amp, g_amp = _oracle_grads(sd, P_f, lab, y, torch.float32, autocast=True)
+    torch.cuda.empty_cache()
+
+    model = _full_width_model(sd)
+
+    def run(bwd):
+        protnote_amd.set_math_mode(math_mode)
+        protnote_amd.set_backward_math(bwd)
+        try:
+            for p in model.parameters():
+                p.grad = None
+            logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+            loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+            loss.backward()
+            return logits.detach().clone(), loss.item(), {n: p.grad.detach().double().cpu() for n, p in model.named_parameters()}
+        finally:
+            protnote_amd.set_backward_math("same")
+            protnote_amd.set_math_mode("f32")
+
+    lg0, l0, g0 = run("same")
+    lg1, l1, g1 = run("bf16")
+    assert torch.equal(lg0, lg1) and l0 == l1                      # (i) the forward is not touched
+    assert (lg1.double().cpu() - lg64).abs().max().item() < 1e-3   # and stays inside the north-star bound
+    np.testing.assert_allclose(l1, ls64, rtol=1e-4)
+
+    def rel(a, ref):
+        return (a - ref).norm().item() / max(ref.norm().item(), 1e-30)
+
+    report, changed = [], 0
+    for name, ref in g64.items():
+        e_same, e_bf16, e_amp = rel(g0[name], ref), rel(g1[name], ref), rel(g_amp[name], ref)
+        report.append((name, e_same, e_bf16, e_amp))
+        assert e_bf16 <= 2.0 * e_amp + 1e-6, (name, e_bf16, e_amp)   # (ii) AMP class, measured
+        assert e_bf16 < 2e-2, (name, e_bf16)
+        changed += int(rel(g1[name], g0[name]) > 1e-6)
+    # (iii) everything downstream of a single-product GEMM moved; dw_out / db_out and the top BatchNorm's dgamma / dbeta come
+    # from reductions in front of the first GEMM of the backward
+    assert changed >= len(g64) - 4, changed
+    worst = max(report, key=lambda r: r[2])
+    print(f"[{math_mode}] backward bf16: worst gradient error vs f64 {worst[2]:.2e} ({worst[0]}; default backward "
+          f"{worst[1]:.2e}, torch autocast(bf16) {worst[3]:.2e}); median ratio bf16-backward / autocast = "
+          f"{float(np.median([r[2] / max(r[3], 1e-30) for r in report])):.3f}")
+
+
+def test_backward_bf16_gemm_error_class(bwd_bf16):
+    """The mode reaches only the pair head's hidden-layer backward: the public GEMM entry points keep their arithmetic."""
+    from protnote_amd import _lib as L
+
+    g = torch.Generator().manual_seed(2)
+    R, M, N = 65536, 256, 256
+    A = torch.randn(R, M, generator=g).to(DEV)
+    Bm = torch.randn(R, N, generator=g).to(DEV)
+    C = torch.empty(M, N, device=DEV)
+    ws = torch.empty(16 * M * N * 4 + 1024, dtype=torch.uint8, device=DEV)
+    L.check(L.lib().pn_gemm_tn(L.ptr(A), M, L.ptr(Bm), N, L.ptr(C), N, R, M, N, L.ptr(ws), ws.numel(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = A.double().T @ Bm.double()
+    scale = A.double().abs().T @ Bm.double().abs()
+    assert ((C.double() - ref).abs() / scale).max().item() < 1e-6   # f32 class
+
+
+def test_backward_bf16_training_tracks_f32():
+    """200 optimisation steps (fwd + bwd + clip + Adam) of the full-width head on a 64 x 1100 pair grid from the same
+    initial state, once with the default backward and once with the bf16 backward: both learn, and the loss
+    trajectories stay together."""
+    import protnote_amd
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    gen = torch.Generator().manual_seed(6)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1100
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    # learnable targets: a fixed random bilinear rule of the inputs
+    U = torch.randn(1100, 1024, generator=gen).to(DEV) / 1100 ** 0.5
+    y = ((P_f @ U @ lab.T) > 32.0).float()  # (the bilinear form has standard deviation sqrt(1024) = 32: ~16 % positives)
+    assert 0.02 < y.mean().item() < 0.4
+
+    def run(bwd):
+        protnote_amd.set_backward_math(bwd)
+        try:
+            model = _full_width_model(sd)
+            opt = FusedClipAdam(head_parameters(model), lr=1e-4, max_norm=1.0)
+            losses = []
+            for _ in range(200):
+                logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+                l = BCEWithLogitsLoss()(logits, y)
+                l.backward()
+                opt.step()
+                opt.zero_grad()
+                losses.append(l.item())
+            return np.array(losses)
+        finally:
+            protnote_amd.set_backward_math("same")
+
+    l32, lbf = run("same"), run("bf16")
+    assert l32[-1] < 0.5 * l32[0] and lbf[-1] < 0.5 * lbf[0], (l32[[0, -1]], lbf[[0, -1]])
+    dev = np.abs(lbf - l32) / np.maximum(l32, 1e-3)
+    print(f"200 steps: loss {l32[0]:.4f} -> {l32[-1]:.4f} (default backward), {lbf[0]:.4f} -> {lbf[-1]:.4f} (bf16 backward); "
+          f"max relative gap {dev.max():.3f}, at step 50 {dev[50]:.4f}")
+    assert lbf[0] == l32[0]
+    assert dev[:50].max() < 0.05 and dev.max() < 0.25, (dev[:50].max(), dev.max())
+
+
+def test_backward_bf16_deep_pipeline_bit_identical():
+    """dh = dz W of the bf16 backward on the deep-pipelined kernel (gemm_bf16.hpp: two register sets for dz, three LDS
+    buffers for the weight plane, every wait a counted vmcnt) against the single-product instantiation of the bf16x3
+    kernel (pn_set_bwd_deep(0)): the same bf16 values meet the same products in the same order - every gradient
+    bit-identical - on a grid with a ragged last row tile, several backward chunks and an odd slab count per chunk."""
+    import protnote_amd
+    from protnote_amd import _lib as L
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(41)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 72, 930          # 66 960 pair rows: not a multiple of 256; chunks of 300 labels = 21 600 rows (84.4 row tiles)
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.1).float().to(DEV)
+    model = _full_width_model(sd)
+    model.pair_label_chunk = 300
+
+    def run(deep):
+        L.check(L.lib().pn_set_bwd_deep(deep))
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    protnote_amd.set_backward_math("bf16")
+    try:
+        a, b, c = run(1), run(0), run(1)
+    finally:
+        L.lib().pn_set_bwd_deep(1)
+        protnote_amd.set_backward_math("same")
+    assert all(float(g.abs().max()) > 0 for g in a)
+    for x, z, w in zip(a, b, c):
+        assert torch.equal(x, z) and torch.equal(x, w)
