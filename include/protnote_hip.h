@@ -371,10 +371,13 @@ int pn_get_math_mode(void);
  * affected; layers with OUTPUT_MLP_DROPOUT > 0 keep the f32 kernels. */
 int pn_set_backward_math(int mode);
 int pn_get_backward_math(void);
-/* Kernels of mode 1: 1 (default) = the deep-pipelined single-product kernels (gemm_bf16.hpp: every operand fetched two
- * slabs ahead), 0 = the single-product instantiations of the bf16x3 kernels.  Same products in the same order: results are
- * bit-identical; the switch exists for A/B timing and for the test that asserts exactly that. */
-int pn_set_bwd_deep(int on);
+/* Kernels of mode 1, a bit mask (default 3).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
+ * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel - same products
+ * in the same order, bit-identical.  Bit 1: dW = dz^T h on the transpose-read kernel (16-byte row loads, K-major LDS image,
+ * ds_read_b64_tr_b16) instead of the single-product instantiation of the bf16x3 TN
+ * kernel - again the same products in the same order, bit-identical.  The switch exists for A/B timing and for the test
+ * that asserts exactly that. */
+int pn_set_bwd_deep(int mask);
 
 /* Operand staging of the f32 pair-grid GEMMs: 1 (default) = LDS-DMA (global_load_lds, gemm_dma.hpp),
  * 0 = the register-staged engine (gemm_engine.hpp).  Same arithmetic in the same order: results are bit-identical;

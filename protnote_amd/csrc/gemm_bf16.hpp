@@ -1,22 +1,20 @@
-// Single-product bf16 NT GEMM of the "bf16 backward" (pn_set_backward_math(1)): dh = dz W of the hidden layers' backward,
-// operands rounded to bf16 (round to nearest even), ONE v_mfma_f32_32x32x16_bf16 per product, f32 accumulation - the
-// arithmetic class of the reference's autocast backward (ProtNoteTrainer.py:728-738).
+// Single-product bf16 GEMMs of the "bf16 backward" (pn_set_backward_math(1)): the pair-grid GEMMs of the hidden layers'
+// backward, operands rounded to bf16 (round to nearest even), ONE v_mfma_f32_32x32x16_bf16 per product, f32 accumulation -
+// the arithmetic class of the reference's autocast backward (ProtNoteTrainer.py:728-738).  Two kernels, each with the
+// NP = 1 instantiation of its bf16x3 counterpart (gemm_bf16x3.hpp) as general fallback and bit-identical to it:
 //
-// Same tile (256 x 256, 8 waves of 64 x 128), LDS images, fragment reads, XCD order and epilogue as the NP = 1 instantiation
-// of gemm_nt_bf16x3_kernel (its general fallback; same products in the same order: bit-identical results).  What is
-// different is the pipeline depth.  A single-product slab is 16 MFMAs per wave - 1024 matrix-pipe cycles per SIMD, about
-// half a microsecond - so the bf16x3 schedule (operands of slab s+1 fetched half a slab before they are needed) leaves a
-// load less time to land than the memory system takes: measured on the NP = 1 instantiation, matrix pipe 0.45 busy, the
-// vector memory unit stalled 62 % of the time (profiles/r04_pmc_bf16_backward.json).  Here every operand is fetched TWO
-// slabs ahead:
-//   * the register-staged A operand lives in two register sets that alternate by slab parity - the set that held slab s+1
-//     is refilled with slab s+3 as soon as its conversion has gone to the LDS;
-//   * the weight plane (pre-rounded once per launch, LDS-DMA) rotates through three LDS buffers;
-//   * addresses: uniform part in SGPRs, per-lane part loop-invariant - no vector instruction is spent on an address in the
-//     slab loop; every wait is a counted vmcnt placed by hand (the loads are issued from inline asm).
-// (The same treatment of the TN weight-gradient kernel - two register sets per operand, buffer loads - does not fit: next
-//  to 128 accumulators hipcc spills 140-600 registers into the slab loop in every variant tried; its NP = 1 instantiation
-//  stays.)
+//   gemm_nt_bf16_kernel    dh = dz W.  Same tile (256 x 256, 8 waves of 64 x 128), LDS images, fragment reads, XCD order and
+//     epilogue as the bf16x3 kernel; what is different is the pipeline depth.  A single-product slab is 16 MFMAs per wave -
+//     1024 matrix-pipe cycles per SIMD, about half a microsecond - so the bf16x3 schedule (operands of slab s+1 fetched half
+//     a slab before they are needed) leaves a load less time to land than the memory system takes: measured on the NP = 1
+//     instantiation, matrix pipe 0.45 busy, the vector memory unit stalled 62 % of the time
+//     (profiles/r04_pmc_bf16_backward.json).  Here the register-staged A operand lives in two register sets that alternate
+//     by slab parity (the set that held slab s+1 is refilled with slab s+3 as soon as its conversion has gone to the LDS),
+//     the weight plane (pre-rounded once per launch, LDS-DMA) rotates through three LDS buffers, addresses are SGPR bases +
+//     loop-invariant per-lane offsets, and every wait is a counted vmcnt placed by hand (the loads are issued from inline
+//     asm).
+//   gemm_tn_bf16tr_kernel  dW = dz^T h.  Operands staged the way they lie in memory (16-byte loads along a row) and
+//     transposed by the LDS read path (ds_read_b64_tr_b16) instead of in registers: a quarter of the load instructions.
 #pragma once
 #include "gemm_bf16x3.hpp"
 #include "gemm_tn_fast.hpp"
@@ -206,5 +204,268 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(const GemmParams p
   gemm_epilogue<EK, WAVES_M, WAVES_N, WM, WN>(p, acc, row0, col0, tile_n, smem);
 }
 constexpr int NT_BF16_LDS_BYTES = 2 * 256 * 36 * 4 + 3 * 256 * 64;
+
+}  // namespace pn
+
+namespace pn {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-product TN contraction (weight gradients of the bf16 backward) with LDS TRANSPOSE reads:
+//     dW[m][n] = sum_r dz[r][m] * h[r][n],  h = relu(s z + t) (TB_AFFINE_RELU) or relu(A'[r % B] + B'[r / B]) (TB_PAIRSUM_RELU).
+// Both operands are K-major in HBM (the contraction index r is the row), the MFMA wants 8 consecutive k per lane.  The bf16x3
+// TN kernel transposes in registers: a thread owns ONE column and loads eight rows of it as single dwords - 32 dword loads
+// per thread and slab, and the vector memory unit, not the matrix pipe, sets the pace once a slab is only 16 MFMAs long
+// (profiles/r04_pmc_bf16_backward.json: matrix pipe 0.35 busy, TCP stalled 54 % of the time).  gfx950 has the transpose in
+// the LDS read path: ds_read_b64_tr_b16 hands lane i of a 16-lane group the i-th 16-bit column of the 4 x 16 block whose
+// four rows the group's lanes point at (lane 4 j + i / 4 supplies the address of row j, 4 columns each; probed on the
+// device: tools/tr_probe.hip).  So the operands are staged the way they lie in memory - 16-byte loads along a row (a
+// wave-load = one whole 1 KiB tile row), converted, written K-major as [32 k-rows][256 columns] bf16 with a 576-byte row
+// stride (the four rows of a read then fall on four different 64-byte bank segments: conflict-free) - and a fragment
+// (32 columns x 16 k, 8 k per lane) is two transpose reads.  8 + 8 (+1) load instructions per thread and slab instead of 32.
+// Preconditions (launcher): M, N multiples of 256, every split a whole number of 32-row slabs, pairB % 32 == 0, 8 rows of an
+// operand span < 2 GB.  Same products in the same order as the bf16x3 kernel's NP = 1 instantiation (natural k-groups in
+// both): bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x4 lds_read_tr4(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<PN_LDS s16x4*>(addr));
+}
+__device__ __forceinline__ uint32_t round2(float a, float b) {
+  const f32x2 x = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+}
+__device__ __forceinline__ void lds_write_bf16x4(unsigned addr, float a, float b, float c, float d) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<PN_LDS u32x2*>(addr) = u32x2{round2(a, b), round2(c, d)};
+}
+
+template <int TB>
+__global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p) {
+  static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the transpose-read TN kernel");
+  constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
+  constexpr unsigned ROWB = 576u;         // LDS bytes of one k-row: 256 bf16 + 64 bytes of padding
+  constexpr unsigned TILEB = BK * ROWB;   // one operand buffer; LDS: A0 | A1 | B0 | B1
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntn = p.N / BN, ntm = p.M / BM;
+  int tile_m, tile_n;
+  int split = blockIdx.y;
+  if (p.task_ns > 0) {  // 32-workgroup region tasks (gemm_tn.hpp)
+    if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
+  } else if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {
+    const int rm = ntm / 4, rn = ntn / 2;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    tile_m = (xcd >> 1) * rm + w / rn;
+    tile_n = (xcd & 1) * rn + w % rn;
+  } else if (PN_XCD && (ntm % 2 == 0) && (ntn % 4 == 0)) {
+    const int rm = ntm / 2, rn = ntn / 4;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    tile_m = (xcd >> 2) * rm + w / rn;
+    tile_n = (xcd & 3) * rn + w % rn;
+  } else {
+    tile_n = blockIdx.x % ntn;
+    tile_m = blockIdx.x / ntn;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long r_begin = (long)split * p.rows_per_split;
+  long r_end = r_begin + p.rows_per_split;
+  if (r_end > p.R) r_end = p.R;
+  const int nsl = r_end > r_begin ? (int)((r_end - r_begin) / BK) : 0;  // whole slabs (launcher's precondition)
+  const unsigned lds0 = lds_addr(smem);
+
+  // ---- staging: thread (wave, lane) loads rows wave + 8 q (q < 4), columns 4 lane .. + 3 of a slab, for both operands
+  const unsigned a_lane = (unsigned)((long)wave * p.lda + 4 * lane) * 4u;
+  const unsigned b_lane = (unsigned)((long)wave * p.ldb + 4 * lane) * 4u;
+  const unsigned b2_lane = 16u * lane;
+  f32x4 ra[NQ], rb[NQ], rb2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bt = bs;
+  if constexpr (TB == TB_AFFINE_RELU) {
+    const float4 s4 = ld4(p.b_s + n0 + 4 * lane), t4 = ld4(p.b_t + n0 + 4 * lane);
+    bs = f32x4{s4.x, s4.y, s4.z, s4.w};
+    bt = f32x4{t4.x, t4.y, t4.z, t4.w};
+  }
+  int pf_i = 0, pf_j = 0, pf_t = 0;  // pair decode of the slab to fetch next (a slab lies inside one label)
+  if constexpr (TB == TB_PAIRSUM_RELU) {
+    pf_j = (int)(r_begin / p.pairB);
+    pf_i = (int)(r_begin - (long)pf_j * p.pairB);
+  }
+  auto fetch_a = [&](int t) {
+    const float* src = p.A + (r_begin + (long)t * BK) * p.lda + m0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) ra[q] = bload4(src + (long)(8 * q) * p.lda, a_lane);
+  };
+  auto fetch_b = [&](int t) {  // t = the previous call's t or that + 1
+    if constexpr (TB == TB_PAIRSUM_RELU) {
+      const bool adv = t != pf_t;
+      pf_t = t;
+      const int ni = pf_i + (adv ? BK : 0);
+      const bool wrap = ni >= p.pairB;
+      pf_i = wrap ? ni - p.pairB : ni;
+      pf_j = wrap ? pf_j + 1 : pf_j;
+      const float* src = p.B + (long)pf_i * p.ldb + n0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rb[q] = bload4(src + (long)(8 * q) * p.ldb, b_lane);
+      rb2 = bload4(p.B2 + (long)pf_j * p.ldb2 + n0, b2_lane);
+    } else {
+      const float* src = p.B + (r_begin + (long)t * BK) * p.ldb + n0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rb[q] = bload4(src + (long)(8 * q) * p.ldb, b_lane);
+    }
+  };
+  auto pin_a = [&]() { asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])); };
+  auto pin_b = [&]() { asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb2)); };
+  unsigned wr_addr = lds0 + (unsigned)wave * ROWB + 8u * lane;  // this thread's 4 columns in tile row `wave` of A buffer 0
+  asm volatile("" : "+v"(wr_addr));
+  auto commit_a = [&](auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      lds_write_bf16x4(wr_addr + (BUF * TILEB + (unsigned)(8 * q) * ROWB), ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+  };
+  auto commit_b = [&](auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      f32x2 lo, hi;
+      if constexpr (TB == TB_AFFINE_RELU) {
+        lo = pk_fma(rb[q].xy, bs.xy, bt.xy);
+        hi = pk_fma(rb[q].zw, bs.zw, bt.zw);
+      } else {
+        lo = pk_add(rb[q].xy, rb2.xy);
+        hi = pk_add(rb[q].zw, rb2.zw);
+      }
+      lds_write_bf16x4(wr_addr + ((2 + BUF) * TILEB + (unsigned)(8 * q) * ROWB), relu_raw(lo.x), relu_raw(lo.y), relu_raw(hi.x),
+                       relu_raw(hi.y));
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment = 32 columns x 16 k of a k-step: lane l takes column l % 32 and k = 8 (l / 32) .. + 7 as two transpose reads of
+  // 4 k each.  Inside its 16-lane group lane i points at k-row (i / 4) of the quad and at columns 16 ((l / 16) % 2) + 4 (i % 4)
+  // of the 32; the hardware returns column i of that 4 x 16 block.
+  const int li = lane & 15, lg = lane >> 4;
+  unsigned fa_addr = lds0 + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB + (unsigned)(wm * 64 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
+  unsigned fb_addr = lds0 + 2u * TILEB + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB +
+                     (unsigned)(wn * 128 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
+  asm volatile("" : "+v"(fa_addr), "+v"(fb_addr));
+  auto compute = [&](auto buf_c, auto ks_c) {
+    constexpr int BUF = decltype(buf_c)::value, KS = decltype(ks_c)::value;
+    bf16x8 a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const s16x4 lo = lds_read_tr4(fa_addr + (BUF * TILEB + (unsigned)(16 * KS) * ROWB + i * 64u));
+      const s16x4 hi = lds_read_tr4(fa_addr + (BUF * TILEB + (unsigned)(16 * KS + 4) * ROWB + i * 64u));
+      a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const s16x4 lo = lds_read_tr4(fb_addr + (BUF * TILEB + (unsigned)(16 * KS) * ROWB + j * 64u));
+      const s16x4 hi = lds_read_tr4(fb_addr + (BUF * TILEB + (unsigned)(16 * KS + 4) * ROWB + j * 64u));
+      b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  // eight MFMAs of a k-step with half a slab's conversion + LDS writes woven between them
+  auto weave = [&](auto nvalu_c) {
+    constexpr int NV = decltype(nvalu_c)::value;
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // the k-step's transpose reads first
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+  };
+
+  using std::integral_constant;
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
+  if (nsl > 0) {
+    const int last = nsl - 1;
+    fetch_a(0);
+    fetch_b(0);
+    pin_a();
+    pin_b();
+    commit_a(I0{});
+    commit_b(I0{});
+    fetch_a(last < 1 ? last : 1);
+    fetch_b(last < 1 ? last : 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // slab t out of buffer CUR: A(t+1) converted and written under k-step 0, then A(t+2) fetched; B(t+1) under k-step 1,
+    // then B(t+2) fetched (past the end the last slab is fetched again; nobody reads it).
+    // (Measured and dropped: a second register set per operand, slab t+3 fetched as soon as slab t+1 has gone to the LDS -
+    //  230 registers, no spill, bit-identical; dW = dz^T relu(bn(z)) 172 -> 188 ms per launch, the pair-sum kind 158 -> 160 ms:
+    //  with both operands streaming from HBM the extra slab in flight costs more in the caches than the latency it hides.)
+    auto slab = [&](int t, auto cur_c) {
+      constexpr int CUR = decltype(cur_c)::value;
+      using C = integral_constant<int, CUR>;
+      using N = integral_constant<int, CUR ^ 1>;
+      const int t2 = t + 2 < last ? t + 2 : last;
+      __builtin_amdgcn_sched_barrier(0);
+      pin_a();
+      compute(C{}, I0{});
+      commit_a(N{});
+      weave(integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_a(t2);
+      __builtin_amdgcn_sched_barrier(0);
+      pin_b();
+      compute(C{}, I1{});
+      commit_b(N{});
+      weave(integral_constant<int, 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_b(t2);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    int t = 0;
+    for (; t + 2 <= last; t += 2) {
+      slab(t, I0{});
+      slab(t + 1, I1{});
+    }
+    if (t < last) slab(t, I0{});
+    // the last slab, out of buffer last % 2 (a run-time buffer offset: an if / else over the two compile-time buffers makes
+    // hipcc keep two copies of the 128 accumulators across the merge and spill ~250 registers)
+    fa_addr += (unsigned)(last & 1) * TILEB;
+    fb_addr += (unsigned)(last & 1) * TILEB;
+    compute(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    compute(I0{}, I1{});
+  }
+
+  float* out = p.Cpart + (long)split * p.M * p.ldc;
+  const int hl = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + (wn * 4 + j) * 32 + cl;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+        out[(long)m * p.ldc + n] = acc[i][j][e];
+      }
+    }
+}
+constexpr int TN_BF16TR_LDS_BYTES = 4 * 32 * 576;
 
 }  // namespace pn

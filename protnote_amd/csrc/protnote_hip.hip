@@ -429,9 +429,9 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
 // dh = dz W of the bf16 backward on the deep-pipelined single-product kernel (gemm_bf16.hpp); preconditions checked by
 // launch_gemm.  pn_set_bwd_deep(0) keeps the NP = 1 instantiation of the bf16x3 kernel (same products in the same order:
 // the bit-identity test compares the two)
-static int g_bwd_deep = 1;
-extern "C" int pn_set_bwd_deep(int on) {
-  g_bwd_deep = on ? 1 : 0;
+static int g_bwd_deep = 3;  // bit 0: the deep-pipelined dh kernel, bit 1: the transpose-read dW kernel
+extern "C" int pn_set_bwd_deep(int mask) {
+  g_bwd_deep = mask & 3;
   return 0;
 }
 static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
@@ -593,7 +593,7 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
     if constexpr (AK == A_PLAIN && EK == E_STORE) {
       if (variant == 0 && p.M >= 4096 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N &&
           p.wsplit != nullptr && p.bias == nullptr && p.e_scale == nullptr && p.col_part == nullptr) {
-        if (g_bwd_deep && p.Kseg >= 96 && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0)
+        if ((g_bwd_deep & 1) && p.Kseg >= 96 && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0)
           return launch_gemm_bf16_single(p, st);
         return launch_gemm_bf16x3<AK, EK, 2, 4, false, true, 1>(p, st);
       }
@@ -1644,10 +1644,13 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   return 0;
 }
 
-template <int TB, int NP = 3>
+// TR (NP = 1 only): the transpose-read kernel of gemm_bf16.hpp (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16)
+template <int TB, int NP = 3, bool TR = false>
 static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
-  auto kern = gemm_tn_bf16x3_kernel<TB, NP>;
-  constexpr int LDS = 2 * 512 * 36 * (int)sizeof(float);
+  void (*kern)(TnParams) = nullptr;
+  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB>;
+  else kern = gemm_tn_bf16x3_kernel<TB, NP>;
+  constexpr int LDS = TR ? TN_BF16TR_LDS_BYTES : 2 * 512 * 36 * (int)sizeof(float);
   static bool attr_done[64] = {false};
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -1704,6 +1707,11 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
   if constexpr (TA == TA_PLAIN && (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {  // pn_set_backward_math(1)
     if (tl_bwd_bf16 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
         (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0)) {
+      // the transpose-read kernel: whole 32-row slabs only, a slab inside one label, 16-byte aligned rows, 32-bit row offsets
+      if ((g_bwd_deep & 2) && p.R % 32 == 0 && (TB != TB_PAIRSUM_RELU || (p.pairB % 32 == 0 && p.ldb2 % 4 == 0)) &&
+          p.lda % 4 == 0 && p.ldb % 4 == 0 && (long)8 * p.lda * 4 < (1L << 31) && (long)8 * p.ldb * 4 < (1L << 31) &&
+          (TB != TB_AFFINE_RELU || p.b_s != nullptr))
+        return launch_tn_bf16x3<TB, 1, true>(p, dst, ldd, part, part_cap_floats, st);
       return launch_tn_bf16x3<TB, 1>(p, dst, ldd, part, part_cap_floats, st);
     }
   }

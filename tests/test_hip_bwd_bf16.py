@@ -170,26 +170,29 @@ def test_backward_bf16_training_tracks_f32():
     assert dev[:50].max() < 0.05 and dev.max() < 0.25, (dev[:50].max(), dev.max())
 
 
-def test_backward_bf16_deep_pipeline_bit_identical():
-    """dh = dz W of the bf16 backward on the deep-pipelined kernel (gemm_bf16.hpp: two register sets for dz, three LDS
-    buffers for the weight plane, every wait a counted vmcnt) against the single-product instantiation of the bf16x3
-    kernel (pn_set_bwd_deep(0)): the same bf16 values meet the same products in the same order - every gradient
-    bit-identical - on a grid with a ragged last row tile, several backward chunks and an odd slab count per chunk."""
+def test_backward_bf16_kernel_variants_agree():
+    """pn_set_bwd_deep (bit mask): bit 0 = dh = dz W on the deep-pipelined kernel (gemm_bf16.hpp: two register sets for dz,
+    three LDS buffers for the weight plane, every wait a counted vmcnt), bit 1 = dW = dz^T h on the transpose-read kernel
+    (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16); 0 = the single-product
+    instantiations of the bf16x3 kernels.  All of them put the same bf16 values into the same products in the same order:
+    EVERY gradient is bit-identical across the masks.  Grid with a ragged last row tile, several backward chunks and an
+    odd slab count per split."""
     import protnote_amd
     from protnote_amd import _lib as L
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
     gen = torch.Generator().manual_seed(41)
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
-    B, NL = 72, 930          # 66 960 pair rows: not a multiple of 256; chunks of 300 labels = 21 600 rows (84.4 row tiles)
-    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    B, NL = 96, 730          # 70 080 pair rows (B % 32 == 0: the pair-sum operand of the transpose-read kernel), not a
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)   # multiple of 256; chunks of 300 labels = 28 800 rows (112.5 row tiles)
     lab = torch.randn(NL, 1024, generator=gen).to(DEV)
     y = (torch.rand(B, NL, generator=gen) < 0.1).float().to(DEV)
     model = _full_width_model(sd)
     model.pair_label_chunk = 300
+    names = [n for n, _ in model.named_parameters()]
 
-    def run(deep):
-        L.check(L.lib().pn_set_bwd_deep(deep))
+    def run(mask):
+        L.check(L.lib().pn_set_bwd_deep(mask))
         for p in model.parameters():
             p.grad = None
         logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
@@ -198,13 +201,13 @@ def test_backward_bf16_deep_pipeline_bit_identical():
 
     protnote_amd.set_backward_math("bf16")
     try:
-        a, b, c = run(1), run(0), run(1)
+        g0, g1, g3, g3b = run(0), run(1), run(3), run(3)
     finally:
-        L.lib().pn_set_bwd_deep(1)
+        L.lib().pn_set_bwd_deep(3)
         protnote_amd.set_backward_math("same")
-    assert all(float(g.abs().max()) > 0 for g in a)
-    for x, z, w in zip(a, b, c):
-        assert torch.equal(x, z) and torch.equal(x, w)
+    assert all(float(g.abs().max()) > 0 for g in g0)
+    for n, a, b, c, d in zip(names, g0, g1, g3, g3b):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d), n
 
 
 def test_backward_bf16_full_size_step():
