@@ -255,3 +255,33 @@ def test_backward_bf16_full_size_step():
         worst = max(worst, (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30))
     assert 1e-6 < worst < 2e-2, worst
     print(f"full size: bf16 backward vs default backward, worst gradient difference {worst:.2e} (Frobenius)")
+
+
+@pytest.mark.parametrize("B,NL,latent,scale,nl", [(64, 1100, 512, 2, 2),     # h = 1024, two hidden layers: 4 x 4 tile grids
+                                                  (96, 700, 256, 3, 3)])    # h = 768: tile grid 3 x 3 (no XCD regions)
+def test_backward_bf16_other_widths_vs_oracle(bwd_bf16, B, NL, latent, scale, nl):
+    """Widths other than the 3072 of the release config: the single-product kernels take any hidden width that is a multiple
+    of 256 (other tile grids, other XCD orders, no region tasks); logits, loss and every gradient against the f64 oracle."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(17)
+    h = latent * scale
+    sd = random_head_sd(gen, 1100, 1024, latent, h, 2, h, nl)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64)
+    model = ProtNote(latent_dim=latent, output_mlp_hidden_dim_scale_factor=scale, output_mlp_num_layers=nl,
+                     projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=scale)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+    loss.backward()
+    assert (logits.detach().double().cpu() - lg64).abs().max().item() < 5e-4
+    np.testing.assert_allclose(loss.item(), ls64, rtol=1e-4)
+    for name, p in model.named_parameters():
+        ref = g64[name]
+        rel = (p.grad.double().cpu() - ref).norm().item() / max(ref.norm().item(), 1e-30)
+        assert rel < 1e-2, (name, rel)
