@@ -371,12 +371,14 @@ int pn_get_math_mode(void);
  * affected; layers with OUTPUT_MLP_DROPOUT > 0 keep the f32 kernels. */
 int pn_set_backward_math(int mode);
 int pn_get_backward_math(void);
-/* Kernels of mode 1, a bit mask (default 3).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
- * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel - same products
- * in the same order, bit-identical.  Bit 1: dW = dz^T h on the transpose-read kernel (16-byte row loads, K-major LDS image,
- * ds_read_b64_tr_b16) instead of the single-product instantiation of the bf16x3 TN
- * kernel - again the same products in the same order, bit-identical.  The switch exists for A/B timing and for the test
- * that asserts exactly that. */
+/* Kernels of mode 1, a bit mask (default 7).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
+ * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel.  Bit 1: dW = dz^T h
+ * on the transpose-read kernel (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16) instead of the single-product
+ * instantiation of the bf16x3 TN kernel.  Masks 0 / 1 / 3 issue the same products in the same order: bit-identical.  Bit 2:
+ * dz is STORED as bf16 (bwd_bf16_dz.hpp: written in place into the first half of each f32 row; both operands of dh = dz W
+ * then go by LDS-DMA, the dW kernel stages dz as it is) wherever a layer's shapes allow - the same bf16 values in the same
+ * products, another k order inside a 16-k MFMA step of the dh GEMM (agrees to f32 summation order).  The switch exists for
+ * A/B timing and for the test that holds the variants to each other. */
 int pn_set_bwd_deep(int mask);
 
 /* Operand staging of the f32 pair-grid GEMMs: 1 (default) = LDS-DMA (global_load_lds, gemm_dma.hpp),

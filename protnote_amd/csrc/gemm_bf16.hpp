@@ -240,7 +240,9 @@ __device__ __forceinline__ void lds_write_bf16x4(unsigned addr, float a, float b
   *reinterpret_cast<PN_LDS u32x2*>(addr) = u32x2{round2(a, b), round2(c, d)};
 }
 
-template <int TB>
+// ABF16: the A operand (dz) is ALREADY bf16 in memory (bwd_bf16_dz.hpp: written in place by k_dz_apply_bf16, row stride
+// p.lda FLOATS, i.e. 4 p.lda bytes): a thread stages 16 bytes = 8 columns of rows 2 wave + lane / 32 (+ 16) as they are.
+template <int TB, bool ABF16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p) {
   static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the transpose-read TN kernel");
   constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
@@ -281,7 +283,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
   const unsigned lds0 = lds_addr(smem);
 
   // ---- staging: thread (wave, lane) loads rows wave + 8 q (q < 4), columns 4 lane .. + 3 of a slab, for both operands
-  const unsigned a_lane = (unsigned)((long)wave * p.lda + 4 * lane) * 4u;
+  const unsigned a_lane = ABF16 ? (unsigned)((long)(2 * wave + (lane >> 5)) * p.lda * 4 + 16 * (lane & 31))
+                                : (unsigned)((long)wave * p.lda + 4 * lane) * 4u;
   const unsigned b_lane = (unsigned)((long)wave * p.ldb + 4 * lane) * 4u;
   const unsigned b2_lane = 16u * lane;
   f32x4 ra[NQ], rb[NQ], rb2 = {0.f, 0.f, 0.f, 0.f};
@@ -297,9 +300,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
     pf_i = (int)(r_begin - (long)pf_j * p.pairB);
   }
   auto fetch_a = [&](int t) {
-    const float* src = p.A + (r_begin + (long)t * BK) * p.lda + m0;
+    if constexpr (ABF16) {  // (m0 bf16 columns = m0 / 2 floats into the row)
+      const float* src = p.A + (r_begin + (long)t * BK) * p.lda + m0 / 2;
+      ra[0] = bload4(src, a_lane);
+      ra[1] = bload4(src + 16L * p.lda, a_lane);
+    } else {
+      const float* src = p.A + (r_begin + (long)t * BK) * p.lda + m0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) ra[q] = bload4(src + (long)(8 * q) * p.lda, a_lane);
+      for (int q = 0; q < NQ; ++q) ra[q] = bload4(src + (long)(8 * q) * p.lda, a_lane);
+    }
   };
   auto fetch_b = [&](int t) {  // t = the previous call's t or that + 1
     if constexpr (TB == TB_PAIRSUM_RELU) {
@@ -319,15 +328,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
       for (int q = 0; q < NQ; ++q) rb[q] = bload4(src + (long)(8 * q) * p.ldb, b_lane);
     }
   };
-  auto pin_a = [&]() { asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])); };
+  auto pin_a = [&]() {
+    if constexpr (ABF16) asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));
+    else asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]));
+  };
   auto pin_b = [&]() { asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb2)); };
   unsigned wr_addr = lds0 + (unsigned)wave * ROWB + 8u * lane;  // this thread's 4 columns in tile row `wave` of A buffer 0
   asm volatile("" : "+v"(wr_addr));
+  unsigned wr16_addr = lds0 + (unsigned)(2 * wave + (lane >> 5)) * ROWB + 16u * (lane & 31);  // ABF16: 8 columns of that row
+  asm volatile("" : "+v"(wr16_addr));
   auto commit_a = [&](auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
+    if constexpr (ABF16) {
+      *reinterpret_cast<PN_LDS f32x4*>(wr16_addr + BUF * TILEB) = ra[0];
+      *reinterpret_cast<PN_LDS f32x4*>(wr16_addr + (BUF * TILEB + 16u * ROWB)) = ra[1];
+    } else {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      lds_write_bf16x4(wr_addr + (BUF * TILEB + (unsigned)(8 * q) * ROWB), ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+      for (int q = 0; q < NQ; ++q)
+        lds_write_bf16x4(wr_addr + (BUF * TILEB + (unsigned)(8 * q) * ROWB), ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+    }
   };
   auto commit_b = [&](auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;

@@ -15,6 +15,7 @@
 #include "gemm_conv_f64.hpp"
 #include "gemm_tn_fast.hpp"
 #include "train_kernels.hpp"
+#include "bwd_bf16_dz.hpp"
 
 using namespace pn;
 
@@ -364,6 +365,8 @@ extern "C" int pn_set_backward_math(int mode) {
 extern "C" int pn_get_backward_math(void) { return g_bwd_math; }
 // set by pn_pairhead_bwd around the GEMMs it applies to; read by launch_gemm / launch_tn
 static thread_local bool tl_bwd_bf16 = false;
+// ... and the dz operand of those GEMMs is already bf16 in memory (bwd_bf16_dz.hpp; decided per layer by pn_pairhead_bwd)
+static thread_local bool tl_dz_bf16 = false;
 struct BwdBf16Scope {
   bool prev;
   explicit BwdBf16Scope(bool on) : prev(tl_bwd_bf16) { tl_bwd_bf16 = on; }
@@ -429,9 +432,9 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
 // dh = dz W of the bf16 backward on the deep-pipelined single-product kernel (gemm_bf16.hpp); preconditions checked by
 // launch_gemm.  pn_set_bwd_deep(0) keeps the NP = 1 instantiation of the bf16x3 kernel (same products in the same order:
 // the bit-identity test compares the two)
-static int g_bwd_deep = 3;  // bit 0: the deep-pipelined dh kernel, bit 1: the transpose-read dW kernel
+static int g_bwd_deep = 7;  // bit 0: the deep-pipelined dh kernel, bit 1: the transpose-read dW kernel, bit 2: dz stored as bf16
 extern "C" int pn_set_bwd_deep(int mask) {
-  g_bwd_deep = mask & 3;
+  g_bwd_deep = mask & 7;
   return 0;
 }
 static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
@@ -461,6 +464,40 @@ static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
   {
     ProfScope ps(1500 + A_PLAIN * 10 + E_STORE, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16_LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// dh = dz W with dz stored as bf16 (bwd_bf16_dz.hpp): both operands by LDS-DMA
+static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
+  auto kern = gemm_nt_bf16dma_kernel<E_STORE>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  if (p.wsplit == nullptr || p.Kseg % 64 != 0 || p.N % 256 != 0 || p.Nstore != p.N || (long)256 * p.lda * 4 >= (1L << 32) ||
+      (long)256 * p.Kseg * 2 >= (1L << 32))
+    return fail("gemm (bf16 dz): shape %d x %d x %d not supported", p.M, p.N, p.Kseg);
+  const long tm = (p.M + 255) / 256, tn = p.N / 256;
+  GemmParams pp = p;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
+  long grid = tm * tn;
+  if (pp.xcd_bc) {
+    const long nblk_ = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk_ + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  pp.w_hi = p.wsplit;
+  hipLaunchKernelGGL(k_round_plane, dim3(nblk((long)p.N * p.Kseg / 4, 256)), dim3(256), 0, st, p.W, p.ldw, p.N, p.Kseg, p.wsplit);
+  {
+    ProfScope ps(1500 + A_PLAIN * 10 + E_STORE, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16DMA_LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -591,6 +628,7 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
   }
   if (tl_bwd_bf16 && PN_BIG) {  // pn_set_backward_math(1): dh = dz W on one bf16 product (weight plane by LDS-DMA)
     if constexpr (AK == A_PLAIN && EK == E_STORE) {
+      if (tl_dz_bf16) return launch_gemm_bf16dma(p, st);
       if (variant == 0 && p.M >= 4096 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N &&
           p.wsplit != nullptr && p.bias == nullptr && p.e_scale == nullptr && p.col_part == nullptr) {
         if ((g_bwd_deep & 1) && p.Kseg >= 96 && (long)256 * p.lda * 4 < (1L << 32) && p.lda % 4 == 0)
@@ -1644,11 +1682,12 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   return 0;
 }
 
-// TR (NP = 1 only): the transpose-read kernel of gemm_bf16.hpp (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16)
-template <int TB, int NP = 3, bool TR = false>
+// TR (NP = 1 only): the transpose-read kernel of gemm_bf16.hpp (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16);
+// ABF16: its A operand is the in-place bf16 dz of bwd_bf16_dz.hpp
+template <int TB, int NP = 3, bool TR = false, bool ABF16 = false>
 static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   void (*kern)(TnParams) = nullptr;
-  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB>;
+  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB, ABF16>;
   else kern = gemm_tn_bf16x3_kernel<TB, NP>;
   constexpr int LDS = TR ? TN_BF16TR_LDS_BYTES : 2 * 512 * 36 * (int)sizeof(float);
   static bool attr_done[64] = {false};
@@ -1705,6 +1744,8 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
     }
   }
   if constexpr (TA == TA_PLAIN && (TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {  // pn_set_backward_math(1)
+    if (tl_bwd_bf16 && tl_dz_bf16)  // (preconditions checked by pn_pairhead_bwd before it wrote dz as bf16)
+      return launch_tn_bf16x3<TB, 1, true, true>(p, dst, ldd, part, part_cap_floats, st);
     if (tl_bwd_bf16 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
         (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0)) {
       // the transpose-read kernel: whole 32-row slabs only, a slab inside one label, 16-byte aligned rows, 32-bit row offsets
@@ -2322,24 +2363,33 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
 
     // dz_l materialised once, in place: over z_l itself for the top layer (its upstream gradient is the rank-1
     // dl * w_out), over the incoming gradient buffer for inner layers.
+    // bf16 backward with pn_set_bwd_deep bit 2: dz is written ROUNDED, into the first half of each of those rows
+    // (bwd_bf16_dz.hpp), when both GEMMs below can take it that way: whole 32-row slabs, hidden width a multiple of 256, and -
+    // for the layer whose activation is the pair sum - a slab inside one label.
+    const bool dz_bf16 = tl_bwd_bf16 && (g_bwd_deep & 4) && h % 256 == 0 && h <= 4096 && R % 32 == 0 && R >= 65536 &&
+                         (l != 1 || hd->fusion == 2 || B % 32 == 0) && (long)32 * h * 4 < (1L << 31);
     float* dz;
     {
       DzParams dp;
       memset(&dp, 0, sizeof(dp));
-      dp.R = R; dp.C = h; dp.rows_per_block = 512;
+      dp.R = R; dp.C = h; dp.rows_per_block = dz_bf16 ? 64 : 512;
       dp.Z = z; dp.ldz = h; dp.s = sv.s[l]; dp.t = sv.t[l]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q; dp.ldo = h;
       const dim3 dg(nblk(h, 1024), nblk(R, 512));
+      const dim3 dgb(1, nblk(R, 64));
       if (top) {
         dp.gvec = dl_pairs; dp.out = z; dz = z;
-        ProfScope ps(ST_DZ_APPLY, (double)R * (8.0 * h + 4.0), st);  // z read, dz written over it
-        hipLaunchKernelGGL((k_dz_apply<1>), dg, dim3(256), 0, st, dp);
+        ProfScope ps(ST_DZ_APPLY, (double)R * ((dz_bf16 ? 6.0 : 8.0) * h + 4.0), st);  // z read, dz written over it
+        if (dz_bf16) hipLaunchKernelGGL((k_dz_apply_bf16<1, 4>), dgb, dim3(h / 4), 0, st, dp);
+        else hipLaunchKernelGGL((k_dz_apply<1>), dg, dim3(256), 0, st, dp);
       } else {
         dp.G = G; dp.ldg = h; dp.out = const_cast<float*>(G); dz = const_cast<float*>(G);
-        ProfScope ps(ST_DZ_APPLY, (double)R * 12.0 * h, st);  // z and G read, dz written over G
-        hipLaunchKernelGGL((k_dz_apply<0>), dg, dim3(256), 0, st, dp);
+        ProfScope ps(ST_DZ_APPLY, (double)R * (dz_bf16 ? 10.0 : 12.0) * h, st);  // z and G read, dz written over G
+        if (dz_bf16) hipLaunchKernelGGL((k_dz_apply_bf16<0, 4>), dgb, dim3(h / 4), 0, st, dp);
+        else hipLaunchKernelGGL((k_dz_apply<0>), dg, dim3(256), 0, st, dp);
       }
       HIP_OK(hipGetLastError());
     }
+    tl_dz_bf16 = dz_bf16;  // read by the launchers of the two GEMMs below; cleared at the end of the layer
 
     // dW_l = dz_l^T h_{l-1}   (h_{l-1} = dropped activation: the B loader regenerates the mask)
     TnParams tp = tn_zero();
@@ -2372,6 +2422,7 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       p.C = sv.zbuf[l] + (size_t)r0 * h; p.ldc = h;
       PN_OK((launch_gemm<A_PLAIN, E_STORE>(p, 0, st)));
     }
+    tl_dz_bf16 = false;
     G = sv.zbuf[l];
     if (hd->dropout_p > 0.f)  // G = gradient wrt the DROPPED h_{l-1}: through the mask (one streaming pass, in place)
       PN_OK(launch_dropout<0>(G, h, sv.zbuf[l], h, R, h, nullptr, nullptr, ds_in, st));
