@@ -242,7 +242,10 @@ __device__ __forceinline__ void lds_write_bf16x4(unsigned addr, float a, float b
 
 // ABF16: the A operand (dz) is ALREADY bf16 in memory (bwd_bf16_dz.hpp: written in place by k_dz_apply_bf16, row stride
 // p.lda FLOATS, i.e. 4 p.lda bytes): a thread stages 16 bytes = 8 columns of rows 2 wave + lane / 32 (+ 16) as they are.
-template <int TB, bool ABF16 = false>
+// SYNC: the 32 workgroups of a region task pace each other every PN_TN_SYNC_SLABS slabs (gemm_tn_fast.hpp: arrival counters
+// in the caller's workspace, bounded wait, an optimisation and never a dependency) - for the kind whose two operands both
+// stream from HBM, so that the task's panels stay in the XCD's L2 while all 32 need them.
+template <int TB, bool ABF16 = false, bool SYNC = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p) {
   static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the transpose-read TN kernel");
   constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
@@ -259,8 +262,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
   const int ntn = p.N / BN, ntm = p.M / BM;
   int tile_m, tile_n;
   int split = blockIdx.y;
+  int* sync_ctr = nullptr;  // this task's four arrival counters (whole-split tasks only: equal work for all 32 workgroups)
   if (p.task_ns > 0) {  // 32-workgroup region tasks (gemm_tn.hpp)
     if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
+    const int T = ((int)blockIdx.x >> 8) * 8 + ((int)blockIdx.x & 7);
+    if (SYNC && p.task_sync != nullptr && T < p.task_ns * 4) sync_ctr = p.task_sync + 4 * T;
   } else if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {
     const int rm = ntm / 4, rn = ntn / 2;
     const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
@@ -433,6 +439,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
     // (Measured and dropped: a second register set per operand, slab t+3 fetched as soon as slab t+1 has gone to the LDS -
     //  230 registers, no spill, bit-identical; dW = dz^T relu(bn(z)) 172 -> 188 ms per launch, the pair-sum kind 158 -> 160 ms:
     //  with both operands streaming from HBM the extra slab in flight costs more in the caches than the latency it hides.)
+    auto checkpoint = [&](int t) {  // (gemm_tn_fast.hpp: epoch e reports into slot e % 4 and waits for epoch e - 1)
+      if (sync_ctr != nullptr && (t & (PN_TN_SYNC_SLABS - 1)) == 0 && wave == 0 && lane == 0) {
+        const int e = t / PN_TN_SYNC_SLABS;
+        __hip_atomic_fetch_add(sync_ctr + (e & 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e > 1) {
+          const int* c = sync_ctr + ((e - 1) & 3);
+          const int want = 32 * (((e - 1) >> 2) + 1);
+          for (int spin = 0; spin < 1024 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+            __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    };
     auto slab = [&](int t, auto cur_c) {
       constexpr int CUR = decltype(cur_c)::value;
       using C = integral_constant<int, CUR>;
@@ -440,6 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
       const int t2 = t + 2 < last ? t + 2 : last;
       __builtin_amdgcn_sched_barrier(0);
       pin_a();
+      if constexpr (SYNC && CUR == 0) checkpoint(t);
       compute(C{}, I0{});
       commit_a(N{});
       weave(integral_constant<int, 1>{});

@@ -1687,7 +1687,8 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
 template <int TB, int NP = 3, bool TR = false, bool ABF16 = false>
 static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   void (*kern)(TnParams) = nullptr;
-  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB, ABF16>;
+  constexpr bool SYNC = TR && TB == TB_AFFINE_RELU;  // pacing for the kind whose two operands both stream from HBM
+  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB, ABF16, SYNC>;
   else kern = gemm_tn_bf16x3_kernel<TB, NP>;
   constexpr int LDS = TR ? TN_BF16TR_LDS_BYTES : 2 * 512 * 36 * (int)sizeof(float);
   static bool attr_done[64] = {false};
@@ -1713,9 +1714,15 @@ static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_
   const unsigned tiles = (unsigned)((p.M / 256) * (p.N / 256));
   dim3 grid(tiles, (unsigned)ns);
   p.task_ns = 0;
+  int* sync_ws = p.task_sync;  // TN_SYNC_INTS ints of the CALLER's workspace (or NULL: unpaced)
+  p.task_sync = nullptr;
   if (p.M == 3072 && p.N == 3072 && ns >= 2) {
     p.task_ns = ns;
     grid = dim3(tn_task_grid(ns), 1);
+    if (SYNC && sync_ws != nullptr && ns * 4 * 4 <= TN_SYNC_INTS) {  // arrival counters of the region tasks: pacing only
+      HIP_OK(hipMemsetAsync(sync_ws, 0, (size_t)ns * 4 * 4 * sizeof(int), st));
+      p.task_sync = sync_ws;
+    }
   }
   {
     ProfScope ps((NP == 3 ? 1100 : 1600) + TB, 2.0 * (double)p.R * (double)p.M * (double)p.N, st);
