@@ -271,11 +271,17 @@ def test_backward_bf16_full_size_step():
     print(f"full size: bf16 backward vs default backward, worst gradient difference {worst:.2e} (Frobenius)")
 
 
-@pytest.mark.parametrize("B,NL,latent,scale,nl", [(64, 1100, 512, 2, 2),     # h = 1024, two hidden layers: 4 x 4 tile grids
-                                                  (96, 700, 256, 3, 3)])    # h = 768: tile grid 3 x 3 (no XCD regions)
+@pytest.mark.parametrize("B,NL,latent,scale,nl", [
+    (64, 1100, 512, 2, 2),    # h = 1024, two hidden layers: 4 x 4 tile grids
+    (96, 700, 256, 3, 3),     # h = 768: tile grid 3 x 3 (no XCD regions)
+    (72, 920, 1024, 3, 3),    # release width, B % 32 != 0: the pair-sum layer keeps dz in f32 and takes the bf16x3 kernel's
+                              # single-product instantiation, the layer above it stores dz as bf16 (R % 32 == 0)
+    (66, 1000, 1024, 3, 3),   # R % 32 != 0 and B % 8 != 0: no layer stores bf16, the pair-sum weight gradient stays on f32
+])
 def test_backward_bf16_other_widths_vs_oracle(bwd_bf16, B, NL, latent, scale, nl):
-    """Widths other than the 3072 of the release config: the single-product kernels take any hidden width that is a multiple
-    of 256 (other tile grids, other XCD orders, no region tasks); logits, loss and every gradient against the f64 oracle."""
+    """Widths other than the 3072 of the release config (the single-product kernels take any hidden width that is a multiple
+    of 256: other tile grids, other XCD orders, no region tasks) and grids on which only some - or none - of the dedicated
+    kernels apply: logits, loss and every gradient against the f64 oracle."""
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
@@ -286,6 +292,7 @@ def test_backward_bf16_other_widths_vs_oracle(bwd_bf16, B, NL, latent, scale, nl
     lab = torch.randn(NL, 1024, generator=gen)
     y = (torch.rand(B, NL, generator=gen) < 0.2).float()
     lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64)
+    torch.cuda.empty_cache()
     model = ProtNote(latent_dim=latent, output_mlp_hidden_dim_scale_factor=scale, output_mlp_num_layers=nl,
                      projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=scale)
     model.load_state_dict(sd)
