@@ -370,7 +370,10 @@ static thread_local bool tl_dz_bf16 = false;
 struct BwdBf16Scope {
   bool prev;
   explicit BwdBf16Scope(bool on) : prev(tl_bwd_bf16) { tl_bwd_bf16 = on; }
-  ~BwdBf16Scope() { tl_bwd_bf16 = prev; }
+  ~BwdBf16Scope() {  // (also on the error returns of pn_pairhead_bwd: no flag outlives the call)
+    tl_bwd_bf16 = prev;
+    tl_dz_bf16 = false;
+  }
 };
 
 // bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; pn_set_b3_dma(0) keeps the register
