@@ -88,6 +88,33 @@ def main(out_dir, tag):
             e["valu_insts_per_mfma"] = u["valu"] / u["mfma"] if u["mfma"] > 0 else None
             e["avg_ms"] = u["sec"] / u["n"] * 1e3
         res["per_kernel"][k] = e
+    # the HBM-bound streaming passes of the step (bench.py `stages`): measured fabric-side bytes of their pair-grid launches
+    # (>= 1 ms; the same kernels also run on the small row-MLP tensors) next to the algorithmic bytes bench.py prices them with
+    h, Rr = 3072.0, 256.0 * 32102.0
+    stage_kernels = {
+        "k_dz_apply<1>": ("dz in place, top layer", Rr * (8 * h + 4)),
+        "k_dz_apply<0>": ("dz in place, inner layer", Rr * 12 * h),
+        "k_dz_apply_bf16<1, 4>": ("dz in place as bf16, top layer (bf16 backward)", Rr * (6 * h + 4)),
+        "k_dz_apply_bf16<0, 4>": ("dz in place as bf16, inner layer (bf16 backward)", Rr * 10 * h),
+        "k_bn_bwd_stats<1, 0>": ("BatchNorm-backward statistics, top layer", Rr * (4 * h + 4)),
+        "k_bn_bwd_stats<0, 0>": ("BatchNorm-backward statistics, inner layer", Rr * 8 * h),
+        "k_pair_mask_reduce_fused": ("layer-1 masked reduction", Rr * 4 * h),
+        "k_rowdot_rows_reg": ("row-dot logits", Rr * (4 * h + 4)),
+    }
+    _, fdur = read_pass(os.path.join(out_dir, "pmc_FETCH_SIZE"))
+    st = {}
+    for sub, (what, alg) in stage_kernels.items():
+        xs = []
+        for key, c in fetch.items():
+            if sub in key[0] and fdur.get(key, 0.0) >= 1e-3:
+                xs.append((2 * c.get("FETCH_SIZE", 0.0) + wr.get(key, 0.0)) * 1024.0)
+        if xs:
+            m = sum(xs) / len(xs)
+            st[sub] = {"stage": what, "launches": len(xs), "hbm_side_GB_per_launch": m / 1e9,
+                       "algorithmic_GB_per_launch": alg / 1e9, "ratio": m / alg}
+    res["stages"] = st
+    res["stages_note"] = ("pair-grid launches (>= 1 ms) of the streaming passes at the bench shape (B = 256, N_L = 32102, h = 3072): "
+                          "2 * FETCH_SIZE + WRITE_SIZE per launch against the algorithmic bytes of bench.py's `stages` block")
     res["bytes_per_launch"] = total_bytes / total_launch if total_launch else None
     res["bytes_per_launch_definition"] = ("mean over the full-pair-grid f32 GEMM launches (dispatches moving >= 100 GB) of "
                                           "2 * FETCH_SIZE + WRITE_SIZE; algorithmic bytes of such a launch: 202 GB")
