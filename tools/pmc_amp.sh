@@ -20,14 +20,14 @@ for sub in ("sq", "lds", "mem", "fetch"):
         seen = set()
         for r in csv.DictReader(open(f, newline="")):
             k = r["Kernel_Name"]
-            if "bf16x3_kernel" not in k: continue
+            if "bf16" not in k or "gemm_" not in k: continue
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
             if d < 20: continue   # full-grid launches only
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if (k, r["Dispatch_Id"]) not in seen:
                 seen.add((k, r["Dispatch_Id"])); n[k] += 1; dur[k] += d
     out[sub] = {k.replace("void pn::", "")[:70]: {"launches": n[k], "avg_ms": dur[k] / n[k], **{c: v / n[k] for c, v in agg[k].items()}} for k in agg}
-json.dump(out, open("gpurun_out/pmc_amp/summary.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/pmc_amp/summary_after.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
 PY
 grep -i -E "^.*(TCP_|TCC_|SQ_.*LDS|SQ_WAIT)" "$OUT/avail.txt" | head -80 > "$OUT/avail_short.txt"
