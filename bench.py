@@ -11,7 +11,9 @@ One "step" = one full optimisation step of the hot path on one batch of syntheti
 ProteInfer encoder forward (train-mode BN) -> W_p / W_l -> pair-grid MLP head with train-mode BatchNorm over
 all B x N_L pairs -> BCE loss -> backward -> (N>1: RCCL all-reduce of the flat gradient) -> clip + Adam.
 Per GPU: B=256 proteins, L=512, N_L=32102 labels (weak scaling).  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0 (metric: protein-label pairs/s, whole job).
+region.  Rank 0's LAST stdout line is ONE compact JSON object (<= 4 kB: the contract keys, `roofline`, `cpu_baseline`,
+a `modes` block of one-liners); the full record (`kernels`, `stages`, every sub-benchmark) goes to bench_detail.json
+beside this script and to an earlier stdout line ({"bench_detail": ...}).
 
 `roofline` describes the dominant kernel family (the 3072x3072 f32-MFMA GEMMs over the 8.2M-row pair grid):
 achieved = 2*rows*h*h FLOP per launch / mean launch duration from hipEvents recorded on the launch stream
@@ -147,7 +149,7 @@ def _cpu_sample(threads):
 CPU_SAMPLE = (4, 512, 32102)  # SURVEY 8d / BASELINE.md 3: the reference materialises [B*N_L, 2d], so B = 4 at the real N_L
 
 
-def cpu_baseline(all_cores_timeout=60.0):
+def cpu_baseline(all_cores_timeout=20.0):
     """Oracle train step (reference algorithm restated, f32, torch-CPU; pinned to reference golden vectors) on a bounded
     sample of the same workload at the QUOTED label set: B=4 proteins, L=512, N_L=32102, full-width model (128 k pairs;
     the whole W_l recompute over the real label table is in it).  Two legs: 32 threads in this process (~20 s; torch-CPU
@@ -348,6 +350,100 @@ def zero_shot_batches(seqs_per_rank, batch, rank, world, dev, seed=5):
                 x[kk, :, lens[i]:] = 0
             batches.append((x.to(dev), lens[r].to(dev)))
     return batches, int(lens.sum()), n_seq, mine_total
+
+
+HEADLINE_MAX_BYTES = 4096  # the driver parses bench.py's LAST stdout line; r04's 24 kB line was not parsed
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+
+
+def _sig(x, n=6):
+    """Floats to n significant digits (the compact line carries numbers, not noise)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if math.isfinite(x) else None
+    return x
+
+
+def _mode_line(blk, ms_key="ms_per_step"):
+    """One-liner of a sub-benchmark block: value, ms_per_step, dtype, roofline.frac only."""
+    if not blk:
+        return None
+    roof = blk.get("roofline") or {}
+    out = {"value": _sig(blk.get("value")), "ms_per_step": _sig(blk.get(ms_key, blk.get("ms_per_step")))}
+    if blk.get("dtype"):
+        out["dtype"] = blk["dtype"]
+    if roof.get("frac") is not None:
+        out["roofline_frac"] = _sig(roof["frac"], 4)
+    return out
+
+
+def headline(full):
+    """The compact (<= HEADLINE_MAX_BYTES) object printed as the LAST stdout line: the contract keys, `roofline`,
+    `cpu_baseline` and a `modes` block of one-liners.  Everything else (`kernels`, `stages`, per-rank lists, notes) lives in
+    bench_detail.json and on an earlier stdout line."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    out = {k: _sig(full[k]) for k in keep if k in full}
+    cfg = full.get("config", {})
+    out["config"] = {"workload": "configs[2] train step fwd+bwd+clip+Adam, BCE, frozen ProteInfer encoder"
+                     if "frozen encoder" in cfg.get("workload", "") else "configs[2] train step, trainable encoder",
+                     **{k: cfg[k] for k in ("global_batch", "seq_len", "n_labels", "parallelism") if k in cfg}}
+    r = full.get("roofline", {})
+    out["roofline"] = {k: _sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "launches",
+                                                    "avg_ms_per_launch", "flops_per_launch", "traffic", "traffic_stale")}
+    out["roofline"]["kernel"] = (r.get("kernel") or "")[:80]
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": _sig(c["value"]), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                               "host_cores": c.get("host_cores"), "sample": c["sample"][:160]}
+    modes = {}
+    if full.get("fast_mode"):
+        modes["fast_mode"] = {**_mode_line(full["fast_mode"]), "dtype": "bf16x3"}
+    for k, v in (full.get("amp_backward") or {}).items():
+        modes["amp_backward." + k] = _mode_line(v)
+    for k in ("frozen_output_layer", "ragged_lengths"):
+        if full.get(k):
+            modes[k] = {**_mode_line(full[k]), "dtype": full.get("dtype")}
+    for k, v in (full.get("forward_only") or {}).items():
+        if isinstance(v, dict):
+            modes["forward_only." + k] = {**_mode_line(v, "ms_per_forward"), "dtype": k}
+    for mode, tables in (full.get("zero_shot") or {}).items():
+        if isinstance(tables, dict) and mode in ("f32", "bf16x3", "fp16x2"):
+            for name, v in tables.items():
+                modes[f"zero_shot.{mode}.{name.split(' ')[0]}"] = {
+                    "value": _sig(v["value"]), "ms_per_step": _sig(v["seconds"] * 1e3), "dtype": mode,
+                    "roofline_frac": _sig(v["roofline"]["frac"], 4)}
+    sh = full.get("similarity_head") or {}
+    if sh.get("train"):
+        modes["similarity_head.train"] = {**_mode_line(sh["train"]), "dtype": "f32"}
+    if sh.get("eval"):
+        modes["similarity_head.eval"] = {**_mode_line(sh["eval"], "ms_per_forward"), "dtype": "f32"}
+    if modes:
+        out["modes"] = modes
+    if full.get("comm"):
+        out["comm"] = {k: _sig(full["comm"].get(k)) for k in ("backend", "rccl_ranks", "replicas_in_sync",
+                                                               "ms_per_step_total", "share_of_step")}
+    for k in ("build_hash", "detail"):
+        if k in full:
+            out[k] = full[k]
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > HEADLINE_MAX_BYTES:  # never let the headline go unparsed again: shed the optional blocks
+        out.pop("modes", None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= HEADLINE_MAX_BYTES, len(line)
+    return line
+
+
+def emit(full):
+    """Detail to bench_detail.json and an EARLIER stdout line; the compact headline is the LAST stdout line."""
+    full = dict(full)
+    full["detail"] = "bench_detail.json (also the previous stdout line)"
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:  # a read-only checkout must not cost the headline
+        full["detail"] = f"previous stdout line (bench_detail.json not written: {e})"
+    print(json.dumps({"bench_detail": full}), flush=True)
+    print(headline(full), flush=True)
 
 
 def main():
@@ -685,7 +781,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.math == "f32" else "bf16x3 (f32 split into bf16 hi+lo, 3 MFMAs, f32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic", "build_hash": _lib.build_hash(),
             "config": {"workload": "BASELINE configs[2]/[3]: train step fwd+bwd+clip+Adam, BCE loss, per-GPU batch "
                                    f"{B} x L={L}, {NL} GO-sized label set, random-init ProteInfer(1100ch,5 blocks)+"
                                    "ProtNote(concatenation head 3x3072, 4-layer projections), "
@@ -712,7 +808,7 @@ def main():
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

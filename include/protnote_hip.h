@@ -41,6 +41,9 @@ extern "C" {
 
 const char* pn_last_error(void);
 int pn_version(void);
+/* 16 hex digits: sha256 over the sources this binary was built from (csrc/*.hip, *.hpp, *.cpp and this header;
+ * protnote_amd/build.py csrc_hash()).  The binding refuses a binary whose hash differs from the sources beside it. */
+const char* pn_build_hash(void);
 
 /* torch.nn.BatchNorm1d state: weight, bias, running_mean, running_var (each [C]) */
 typedef struct pn_bn {

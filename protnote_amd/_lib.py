@@ -72,6 +72,7 @@ _lib = None
 _SIGS = {
     "pn_last_error": (C.c_char_p, []),
     "pn_version": (C.c_int, []),
+    "pn_build_hash": (C.c_char_p, []),
     "pn_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pn_encoder_ws_bytes": (C.c_size_t, [C.POINTER(pn_encoder), C.c_int, C.c_int]),
     "pn_encoder_fwd": (C.c_int, [C.POINTER(pn_encoder), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -179,19 +180,39 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def _ensure_current():
+    """The .so must exist AND be built from the sources beside it.  With csrc/ present the content hash stamped into the
+    binary (pn_build_hash) is compared with build.csrc_hash(): a missing or stale binary is rebuilt when hipcc is there
+    and refused otherwise - never served silently (a stale .so once produced a null experiment)."""
+    from . import build
+
+    have_src = os.path.isdir(build.CSRC) and os.path.exists(os.path.join(build.CSRC, "protnote_hip.hip"))
+    if os.path.exists(LIB_PATH) and (not have_src or os.environ.get("PN_SKIP_HASH_CHECK") == "1"):
+        return
+    if os.path.exists(LIB_PATH) and not build.stale():
+        return
+    why = "is missing" if not os.path.exists(LIB_PATH) else (
+        f"was built from other sources (binary {build.embedded_hash()}, csrc/ {build.csrc_hash()})")
+    if not build.have_hipcc():
+        raise RuntimeError(f"{LIB_PATH} {why} and hipcc is not available to rebuild it; build it with "
+                           "`python -m protnote_amd.build` (protnote_amd has no CPU/eager fallback)")
+    try:  # in-tree build with hipcc; never a CPU/eager fallback
+        build.build_lib(verbose=False)
+    except Exception as exc:  # noqa: BLE001
+        raise RuntimeError(f"{LIB_PATH} {why} and could not be rebuilt ({exc}); build it with "
+                           "`python -m protnote_amd.build` (protnote_amd has no CPU/eager fallback)") from exc
+
+
+def build_hash() -> str:
+    """Source hash compiled into the loaded library."""
+    return lib().pn_build_hash().decode()
+
+
 def lib():
-    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    """Load (once) and return the C-ABI library; raises if it is missing or stale and cannot be rebuilt."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            try:  # in-tree build with hipcc when the toolchain is there; never a CPU/eager fallback
-                from .build import build_lib
-
-                build_lib(verbose=False)
-            except Exception as exc:  # noqa: BLE001
-                raise RuntimeError(
-                    f"{LIB_PATH} is missing and could not be built ({exc}); build it with "
-                    "`python -m protnote_amd.build` (protnote_amd has no CPU/eager fallback)") from exc
+        _ensure_current()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)

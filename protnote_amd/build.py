@@ -9,78 +9,106 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 API = os.path.join(os.path.dirname(HERE), "include", "protnote_hip.h")
-# translation unit -> headers it depends on
-UNITS = {
-    "protnote_hip.hip": ["gemm_engine.hpp", "gemm_bf16x3.hpp", "gemm_dma.hpp", "gemm_conv_dma.hpp", "gemm_conv_f64.hpp", "gemm_tn_fast.hpp", "gemm_tn.hpp", "train_kernels.hpp", "common.hpp"],
-    "metrics.hip": ["common.hpp"],
-}
+# translation units; EVERY unit depends on every csrc/*.hpp and on the API header (found by glob at call time - a hand-kept
+# list once omitted two new headers and served a stale binary silently)
+UNITS = ["protnote_hip.hip", "metrics.hip", "build_hash.cpp"]
 SRC = [os.path.join(CSRC, u) for u in UNITS]
 LIB = os.path.join(HERE, "libprotnote_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
+HASH_MARKER = b"PN_CSRC_HASH="
+
+
+def headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+
+
+def sources():
+    """Every file the binary is made of: csrc/*.hip, csrc/*.hpp, csrc/*.cpp and the API header."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))) + [API]
 
 
 def _extra():
     return os.environ.get("PN_EXTRA_HIPCC_FLAGS", "").split()
 
 
-def _flag_stamp():
-    return " ".join(FLAGS + _extra())
+def _unit_flags(unit):
+    fl = FLAGS + _extra()
+    if unit == "build_hash.cpp":  # the one unit that carries the source hash: recompiled (1 s) whenever any source changes
+        fl = fl + [f'-DPN_CSRC_HASH="{csrc_hash()}"']
+    return fl
 
 
 def _obj(unit):
-    return os.path.join(OBJ, unit.replace(".hip", ".o"))
+    return os.path.join(OBJ, os.path.splitext(unit)[0] + ".o")
 
 
 def _unit_stale(unit) -> bool:
     o = _obj(unit)
-    if not os.path.exists(o) or not os.path.exists(o + ".flags") or open(o + ".flags").read() != _flag_stamp():
+    if not os.path.exists(o) or not os.path.exists(o + ".flags") or open(o + ".flags").read() != " ".join(_unit_flags(unit)):
         return True
+    if unit == "build_hash.cpp":
+        return os.path.getmtime(os.path.join(CSRC, unit)) > os.path.getmtime(o)
     t = os.path.getmtime(o)
-    deps = [os.path.join(CSRC, unit), API] + [os.path.join(CSRC, h) for h in UNITS[unit]]
-    return any(os.path.getmtime(f) > t for f in deps)
-
-
-def stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = set(SRC + [API])
-    for u, hs in UNITS.items():
-        deps.update(os.path.join(CSRC, h) for h in hs)
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in deps)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, unit), API] + headers())
 
 
 def csrc_hash() -> str:
-    """sha256 over the device sources (csrc/*.hip, csrc/*.hpp), file names included: profiles that describe kernel
-    behaviour (profiles/*_hbm_traffic.json) are stamped with it so bench.py can tell when they no longer belong to the
-    kernels it is running (.git does not travel to the GPU box)."""
+    """sha256 over every source of the binary (csrc/*.hip, *.hpp, *.cpp, include/protnote_hip.h), file names included.
+    Compiled into the .so (pn_build_hash()); _lib.lib() refuses a binary whose hash differs from the sources beside it,
+    and profiles that describe kernel behaviour (profiles/*_hbm_traffic.json) are stamped with it so bench.py can tell
+    when they no longer belong to the kernels it is running (.git does not travel to the GPU box)."""
     import hashlib
 
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
-    for f in [os.path.join(CSRC, f) for f in files]:
+    for f in sources():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
+def embedded_hash(path: str = None):
+    """The source hash stamped into a built .so, read from the file's bytes (no dlopen); None if there is none."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    blob = open(path, "rb").read()
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    return blob[i + len(HASH_MARKER): i + len(HASH_MARKER) + 16].decode("ascii", "replace")
+
+
+def stale() -> bool:
+    """True when the .so is missing or was not built from the sources now in csrc/ (content hash, not mtimes: the
+    snapshot that travels to the GPU box does not keep them)."""
+    return embedded_hash() != csrc_hash()
+
+
+def have_hipcc():
+    import shutil
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return hipcc if os.path.exists(hipcc) else shutil.which("hipcc")
+
+
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale() and not _extra():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
+    hipcc = have_hipcc()
+    if not hipcc:
+        raise RuntimeError("hipcc not found (set HIPCC)")
     os.makedirs(OBJ, exist_ok=True)
 
     def compile_unit(unit):
         if not force and not _unit_stale(unit):
             return
-        cmd = [hipcc] + FLAGS + _extra() + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit)]
+        lang = ["-x", "hip"] if unit.endswith(".hip") else []
+        cmd = [hipcc] + _unit_flags(unit) + lang + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         with open(_obj(unit) + ".flags", "w") as f:
-            f.write(_flag_stamp())
+            f.write(" ".join(_unit_flags(unit)))
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
         list(ex.map(compile_unit, UNITS))
@@ -88,6 +116,9 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    if embedded_hash() != csrc_hash():
+        raise RuntimeError(f"built {LIB} carries hash {embedded_hash()} but the sources hash to {csrc_hash()} "
+                           "(a source changed during the build?)")
     return LIB
 
 

@@ -1,0 +1,61 @@
+"""bench.py's LAST stdout line is what the driver parses (BENCH_rNN.parsed).  Round 4's line grew to 24 kB and was not
+parsed; the headline is now a separate compact object and every detail block goes to bench_detail.json / an earlier line."""
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORDS = ["r04_bench_20steps.json", "r03_bench_20steps.json"]
+
+
+@pytest.mark.parametrize("record", RECORDS)
+def test_headline_is_compact_and_complete(record):
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", record)))
+    line = bench.headline(full)
+    assert "\n" not in line and len(line) < 4096, len(line)
+    h = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in h, k
+    assert h["value"] == pytest.approx(full["value"], rel=1e-5) and h["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert set(h["config"]) >= {"workload", "global_batch", "seq_len", "n_labels", "parallelism"}
+    assert "model" not in h["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_ms_per_launch"):
+        assert k in h["roofline"], k
+    assert h["roofline"]["frac"] == pytest.approx(h["roofline"]["achieved"] / h["roofline"]["peak"], rel=1e-4)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in h["cpu_baseline"], k
+    # the detail blocks stay out of the headline
+    assert "kernels" not in h and "stages" not in h
+    for name, m in h.get("modes", {}).items():
+        assert set(m) <= {"value", "ms_per_step", "dtype", "roofline_frac"}, (name, m)
+
+
+def test_headline_sheds_modes_rather_than_overflow():
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", RECORDS[0])))
+    full["zero_shot"]["f32"] = {f"table{i} (x)": dict(next(iter(full["zero_shot"]["f32"].values()))) for i in range(80)}
+    line = bench.headline(full)
+    assert len(line) <= bench.HEADLINE_MAX_BYTES and "modes" not in json.loads(line)
+
+
+def test_emit_prints_detail_first_and_headline_last(tmp_path, monkeypatch):
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", RECORDS[0])))
+    monkeypatch.setattr(bench, "DETAIL_PATH", str(tmp_path / "bench_detail.json"))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(full)
+    lines = buf.getvalue().strip().splitlines()
+    assert len(lines) == 2 and len(lines[-1]) < 4096
+    assert json.loads(lines[-1])["metric"] == full["metric"]
+    detail = json.loads(lines[0])["bench_detail"]
+    assert detail["kernels"] == full["kernels"] and detail["stages"] == full["stages"]
+    assert json.load(open(tmp_path / "bench_detail.json"))["kernels"] == full["kernels"]

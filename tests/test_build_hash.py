@@ -1,0 +1,110 @@
+"""The binary knows which sources it was built from, and the binding refuses any other (build.py's
+hand-kept header list omitted two headers and `_lib.lib()` built only when the .so was MISSING, so an edited header
+silently measured the old kernels).  All CPU: nothing here launches a kernel."""
+import os
+import shutil
+
+import pytest
+
+from protnote_amd import build
+
+
+def _clone_sources(tmp_path):
+    """A scratch copy of the package's source layout (csrc/ + include/) with the built .so beside it."""
+    pkg = tmp_path / "protnote_amd"
+    (pkg / "csrc").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    for f in os.listdir(build.CSRC):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            shutil.copy(os.path.join(build.CSRC, f), pkg / "csrc" / f)
+    shutil.copy(build.API, tmp_path / "include" / "protnote_hip.h")
+    shutil.copy(build.build_lib(verbose=False), pkg / "libprotnote_hip.so")
+    return pkg
+
+
+@pytest.fixture
+def scratch(tmp_path, monkeypatch):
+    pkg = _clone_sources(tmp_path)
+    monkeypatch.setattr(build, "CSRC", str(pkg / "csrc"))
+    monkeypatch.setattr(build, "API", str(tmp_path / "include" / "protnote_hip.h"))
+    monkeypatch.setattr(build, "LIB", str(pkg / "libprotnote_hip.so"))
+    monkeypatch.setattr(build, "OBJ", str(pkg / "csrc" / "_obj"))
+    return pkg
+
+
+def test_built_library_reports_the_hash_of_its_sources():
+    from protnote_amd import _lib
+
+    build.build_lib(verbose=False)
+    assert not build.stale()
+    h = build.csrc_hash()
+    assert len(h) == 16 and build.embedded_hash() == h and _lib.build_hash() == h
+
+
+def test_every_header_is_a_dependency(scratch):
+    """Touching ANY csrc/*.hpp (content, not mtime), any translation unit or the API header makes the binary stale."""
+    assert not build.stale()
+    names = [os.path.basename(f) for f in build.sources()]
+    for must in ("gemm_bf16.hpp", "bwd_bf16_dz.hpp", "gemm_engine.hpp", "train_kernels.hpp", "protnote_hip.hip",
+                 "metrics.hip", "protnote_hip.h"):
+        assert must in names, must
+    assert len([n for n in names if n.endswith(".hpp")]) == len(build.headers())
+    for f in build.sources():
+        orig = open(f, "rb").read()
+        try:
+            with open(f, "ab") as fh:
+                fh.write(b"\n// touched\n")
+            assert build.stale(), f
+            assert build._unit_stale("build_hash.cpp") or not os.path.exists(build._obj("build_hash.cpp"))
+        finally:
+            with open(f, "wb") as fh:
+                fh.write(orig)
+        assert not build.stale(), f
+
+
+def test_new_header_is_picked_up(scratch):
+    (scratch / "csrc" / "brand_new.hpp").write_text("// not yet included anywhere\n")
+    assert build.stale()
+
+
+def test_stale_binary_is_refused_without_a_compiler(scratch, monkeypatch):
+    from protnote_amd import _lib
+
+    monkeypatch.setattr(_lib, "LIB_PATH", build.LIB)
+    monkeypatch.setattr(build, "have_hipcc", lambda: None)
+    monkeypatch.delenv("PN_SKIP_HASH_CHECK", raising=False)
+    _lib._ensure_current()  # current binary: accepted
+    with open(scratch / "csrc" / "gemm_bf16.hpp", "a") as fh:
+        fh.write("\n// edited after the build\n")
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib._ensure_current()
+    os.remove(build.LIB)
+    with pytest.raises(RuntimeError, match="is missing"):
+        _lib._ensure_current()
+
+
+def test_wrong_hash_in_binary_is_rejected(scratch, monkeypatch):
+    from protnote_amd import _lib
+
+    blob = open(build.LIB, "rb").read()
+    i = blob.find(build.HASH_MARKER) + len(build.HASH_MARKER)
+    with open(build.LIB, "wb") as fh:
+        fh.write(blob[:i] + b"0123456789abcdef" + blob[i + 16:])
+    assert build.embedded_hash() == "0123456789abcdef" and build.stale()
+    monkeypatch.setattr(_lib, "LIB_PATH", build.LIB)
+    monkeypatch.setattr(build, "have_hipcc", lambda: None)
+    with pytest.raises(RuntimeError, match="0123456789abcdef"):
+        _lib._ensure_current()
+
+
+def test_stale_binary_is_rebuilt_when_hipcc_is_there(scratch, monkeypatch):
+    """With a compiler the stale binary is rebuilt, not served (the compile itself is stubbed: it takes a minute)."""
+    from protnote_amd import _lib
+
+    calls = []
+    monkeypatch.setattr(_lib, "LIB_PATH", build.LIB)
+    monkeypatch.setattr(build, "build_lib", lambda verbose=True, force=False: calls.append(1) or build.LIB)
+    with open(scratch / "csrc" / "common.hpp", "a") as fh:
+        fh.write("\n// edited\n")
+    _lib._ensure_current()
+    assert calls == [1]
