@@ -96,6 +96,8 @@ def input_dropout_p(seq) -> float:
 
 
 class ProtNote(nn.Module):
+    _warned_eval_stored = False  # the eval-mode + autograd path warns once per process (see forward)
+
     def __init__(self, protein_embedding_dim=1100, label_embedding_dim=1024, label_embedding_pooling_method="mean",
                  inference_descriptions_per_label=1, latent_dim=1024, label_encoder=None, sequence_encoder=None,
                  label_encoder_num_trainable_layers=False, train_sequence_encoder=False,
@@ -393,6 +395,14 @@ class ProtNote(nn.Module):
         #   eval mode otherwise           -> the fused inference kernels (nothing stored).
         stored = self.training or (torch.is_grad_enabled() and not save_embeddings
                                    and self._needs_graph(sequence_embeddings, label_embeddings))
+        if stored and not self.training and not ProtNote._warned_eval_stored:
+            ProtNote._warned_eval_stored = True
+            import warnings
+
+            warnings.warn("ProtNote: eval-mode forward with autograd enabled takes the activation-storing path (differentiable "
+                          "logits, as in the reference) - it stores B x N_L x h activations per layer and bypasses the fused "
+                          "inference kernels and the label-projection cache.  Run inference under torch.no_grad() or "
+                          "torch.inference_mode().", stacklevel=2)
         if pool_all:
             # token embeddings [N, T, d] + tokenized_labels["attention_mask"] (ProtNote.py:266-267).  On the stored path
             # the pooling happens inside forward_train (after the label noise, as in the reference, and inside the

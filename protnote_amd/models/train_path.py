@@ -50,8 +50,12 @@ def _backward_pending(model) -> bool:
 def _save_buf(model, tag, nbytes, device, temporary=False, private=None):
     if private is not None:  # a store owned by ONE forward's autograd context (see _HeadsTrainFn.forward)
         buf = private.get(tag)
-        if buf is None:
-            buf = private[tag] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        if buf is None:  # carved from the block _try_private_store allocated (and proved allocatable) up front
+            start = (private.used + 255) // 256 * 256
+            if start + int(nbytes) > private.block.numel():
+                raise RuntimeError("private activation store too small for this forward (internal sizing error)")
+            buf = private[tag] = private.block[start:start + int(nbytes)]
+            private.used = start + int(nbytes)
         return buf
     if temporary:  # a no_grad forward while another forward's backward is pending: do not touch the shared store
         return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -82,7 +86,32 @@ def _try_private_store(model, P_f, L_f):
         need += lib.pn_pairhead_train_save_bytes(C.byref(hd), B, NL, model._train_chunk(B, NL))
     free, _total = torch.cuda.mem_get_info(dev)
     cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    return {} if need * 1.1 < free + cached else None
+    # every private store is memory a caller holds for as long as it keeps grad-enabled logits alive (collecting outputs
+    # in a list without calling backward): cap how many can exist, beyond that the shared store is reused
+    live = model.__dict__.setdefault("_pn_private_stores", weakref.WeakSet())
+    if len(live) >= MAX_PRIVATE_STORES or need * 1.1 >= free + cached:
+        return None
+    try:  # free + cached can be fragmented: the allocation itself decides, and failing it means "use the shared store"
+        store = _PrivateStore(torch.empty(int(need) + 4 * 256, dtype=torch.uint8, device=dev))
+    except torch.cuda.OutOfMemoryError:
+        return None
+    live.add(store)
+    return store
+
+
+MAX_PRIVATE_STORES = 2
+
+
+class _PrivateStore(dict):
+    """Save buffers of one differentiable forward that overlaps an earlier one (released with its autograd context)."""
+    __slots__ = ("block", "used", "__weakref__")
+
+    def __init__(self, block):
+        super().__init__()
+        self.block, self.used = block, 0
+
+    __hash__ = object.__hash__  # dict subclasses are unhashable by default; the WeakSet of live stores needs identity
+    __eq__ = object.__eq__
 
 
 class _HeadsTrainFn(torch.autograd.Function):

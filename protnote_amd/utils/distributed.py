@@ -129,8 +129,9 @@ def sync_initial_state(model, optimizer=None, src: int = 0):
 
     _bump_generation()  # weights change under caches of weight-derived tensors (the eval-mode L_e cache)
     if optimizer is not None and hasattr(optimizer, "flat_w"):
-        for name in ("flat_w", "flat_m", "flat_v"):
-            t = getattr(optimizer, name)
+        bufs = optimizer.state_buffers() if hasattr(optimizer, "state_buffers") else [
+            t for t in (getattr(optimizer, n, None) for n in ("flat_w", "flat_m", "flat_v")) if t is not None]
+        for t in bufs:  # SGD keeps no second moment, and no velocity when momentum is 0
             with _Timed("initial_state_broadcast", t):
                 dist.broadcast(t, src=src)
         step = torch.tensor([optimizer.step_count], dtype=torch.int64, device=optimizer.flat_w.device)

@@ -30,7 +30,9 @@ def strip_ddp_prefix(state_dict):
 
 def load_checkpoint_into(model, checkpoint_path: str, map_location="cpu", strict: bool = True):
     """Load `model_state_dict` of a reference-format checkpoint into a protnote_amd (or reference) model.
-    Returns the rest of the checkpoint (epoch, optimizer_state_dict, best_val_metric)."""
+    Returns the rest of the checkpoint (epoch, optimizer_state_dict, best_val_metric).
+    Checkpoints are unpickled in full (weights_only=False, as the reference's torch.load does, utils/models.py:347):
+    only load files you trust."""
     ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
     model.load_state_dict(strip_ddp_prefix(ckpt["model_state_dict"]), strict=strict)
     return {k: v for k, v in ckpt.items() if k != "model_state_dict"}
@@ -49,7 +51,7 @@ def load_model(trainer, checkpoint_path: str, rank: int = 0, from_checkpoint: bo
     opt = getattr(trainer, "optimizer", None)
     if opt is not None and hasattr(opt, "repack"):
         opt.repack()  # load_state_dict copied INTO the flat views; make sure nothing was re-assigned
-    if "optimizer_state_dict" in ckpt and from_checkpoint:
+    if "optimizer_state_dict" in ckpt and from_checkpoint and opt is not None:  # an evaluation-only trainer has none
         opt.load_state_dict(ckpt["optimizer_state_dict"])
     if "epoch" in ckpt and from_checkpoint:
         trainer.starting_epoch = ckpt["epoch"]

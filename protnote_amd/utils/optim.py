@@ -25,7 +25,7 @@ def _bump_generation():
 
 class FusedClipAdam:
     def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
-                 param_ids=None, n_param_ids=None):
+                 param_ids=None, n_param_ids=None, _moments=2):
         """`param_ids[i]` = the id parameter i carries in state_dict() / load_state_dict() and `n_param_ids` the length of
         the id space: the position of the parameter in the list the REFERENCE builds its torch.optim.Adam from
         (model.named_parameters() filtered by requires_grad, ProtNoteTrainer.py:199-231), which may hold parameters this
@@ -53,8 +53,9 @@ class FusedClipAdam:
         n = sum(sizes)
         self.flat_w = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        # `_moments`: how many per-parameter state blocks the update rule keeps (Adam 2; SGD 1 with momentum, else 0)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev) if _moments >= 1 else None
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev) if _moments >= 2 else None
         off = 0
         with torch.no_grad():
             for p, sz in zip(self.params, sizes):
@@ -65,6 +66,11 @@ class FusedClipAdam:
                 off += sz
         self.step_count = 0
         self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def state_buffers(self):
+        """The flat blocks a replica must share with rank 0 at start / resume (distributed.sync_initial_state): the
+        weights and whatever moment blocks this update rule keeps (SGD without momentum keeps none)."""
+        return [t for t in (self.flat_w, self.flat_m, self.flat_v) if t is not None]
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
@@ -171,11 +177,8 @@ class FusedClipSGD(FusedClipAdam):
 
     def __init__(self, params, lr=3e-4, momentum=0.0, weight_decay=0.0, max_norm=1.0, param_ids=None, n_param_ids=None):
         super().__init__(params, lr=lr, weight_decay=weight_decay, max_norm=max_norm, param_ids=param_ids,
-                         n_param_ids=n_param_ids)
+                         n_param_ids=n_param_ids, _moments=1 if float(momentum) != 0.0 else 0)  # no second moment
         self.momentum = float(momentum)
-        self.flat_v = None  # no second moment
-        if self.momentum == 0.0:
-            self.flat_m = None
 
     def step(self):
         for p, off in self._offsets():
@@ -193,12 +196,12 @@ class FusedClipSGD(FusedClipAdam):
                                          L.ptr(ws), ws.numel(), L.stream_ptr()))
 
     def state_dict(self):
-        """torch.optim.SGD.state_dict() layout for the reference's parameter list."""
+        """torch.optim.SGD.state_dict() layout for the reference's parameter list (momentum 0: torch keeps an EMPTY
+        state, so does this)."""
         state = {}
-        if self.step_count > 0:
+        if self.step_count > 0 and self.flat_m is not None:
             for i, (p, off) in zip(self.param_ids, self._offsets()):
-                buf = None if self.flat_m is None else self.flat_m[off:off + p.numel()].view_as(p).clone()
-                state[i] = {"momentum_buffer": buf}
+                state[i] = {"momentum_buffer": self.flat_m[off:off + p.numel()].view_as(p).clone()}
         group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
                  "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
                  "params": list(range(self.n_param_ids))}
@@ -221,5 +224,6 @@ class FusedClipSGD(FusedClipAdam):
                 seen = True
                 if self.flat_m is not None and st.get("momentum_buffer") is not None:
                     self.flat_m[off:off + p.numel()].view_as(p).copy_(st["momentum_buffer"])
-        # torch's SGD keeps no step count; the fused kernel only needs "first step or not" for the velocity
+        # torch's SGD keeps no step count; the fused kernel only needs "first step or not" for the velocity (momentum 0:
+        # the state is empty and the count is irrelevant to the update)
         self.step_count = 1 if seen else 0

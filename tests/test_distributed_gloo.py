@@ -187,3 +187,60 @@ def test_zero_shot_dealing_balances_eight_ranks():
     assert min(b for _, b, _ in shares) >= 4, shares
     pads = [p for _, _, p in shares]
     assert max(pads) <= 1.06 * min(pads), pads
+
+
+def _sgd_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from protnote_amd.utils import distributed as D
+
+    D.init_from_env(backend="gloo")
+    out = []
+    for momentum in (0.0, 0.9):
+        lin = torch.nn.Linear(3, 5)
+
+        class SGDShaped:  # the flat blocks FusedClipSGD keeps: no second moment, no velocity when momentum is 0
+            params = [lin.weight]
+            flat_w = torch.full((15,), float(rank + 1))
+            flat_m = None if momentum == 0.0 else torch.full((15,), 10.0 * (rank + 1))
+            flat_v = None
+            step_count = 5 * (rank + 1)
+
+            @classmethod
+            def state_buffers(cls):
+                return [t for t in (cls.flat_w, cls.flat_m, cls.flat_v) if t is not None]
+
+        lin.weight.data = SGDShaped.flat_w.view(5, 3)
+        D.sync_initial_state(lin, SGDShaped)  # round 4 crashed here: dist.broadcast(None)
+        out.append((SGDShaped.flat_w.clone(), None if SGDShaped.flat_m is None else SGDShaped.flat_m.clone(),
+                    SGDShaped.step_count, lin.bias.detach().clone()))
+    import pickle
+
+    q.put(pickle.dumps((rank, out)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sync_with_sgd_shaped_optimizer():
+    """OPTIMIZER: SGD under data parallelism (reference ProtNoteTrainer.py:238-243 + DDP): the optimiser has no second
+    moment and, with momentum 0, no velocity block either; sync_initial_state must broadcast only what exists."""
+    import pickle
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sgd_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(pickle.loads(q.get(timeout=120)) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for case in range(2):
+        w0, m0, s0, b0 = res[0][case]
+        w1, m1, s1, b1 = res[1][case]
+        assert torch.all(w1 == 1.0) and torch.equal(w0, w1) and s0 == s1 == 5 and torch.equal(b0, b1)
+        if case == 0:
+            assert m0 is None and m1 is None
+        else:
+            assert torch.all(m1 == 10.0) and torch.equal(m0, m1)

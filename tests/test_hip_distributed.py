@@ -146,6 +146,74 @@ def test_two_ranks_rccl():
     np.testing.assert_allclose(res[0][6], ref[0][6], rtol=0, atol=1e-6)
 
 
+def _sgd_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PN_SHARE_GPU="1")
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.utils import distributed as D
+    from protnote_amd.utils.configs import build_training
+    from tests.helpers import make_protnote
+
+    r, _, w = D.init_from_env()
+    dev = f"cuda:{torch.cuda.current_device()}"
+    g = np.load(os.path.join(GOLDEN, "protnote_small_concatenation.npz"))
+    x, lens, yy = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"]), torch.from_numpy(g["multihots"]).float()
+    rows = D.shard_batch(x.shape[0], r, w)
+    batch = {"sequence_onehots": x[rows].to(dev), "sequence_lengths": lens[rows].to(dev),
+             "label_embeddings": torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(dev),
+             "label_multihots": yy[rows].to(dev)}
+    out = []
+    for momentum in (0.0, 0.9):
+        torch.manual_seed(10 + r)  # differently initialised replicas
+        model, _ = make_protnote(g, dev)
+        with torch.no_grad():
+            for q_ in model.parameters():
+                q_.mul_(1.0 + 0.05 * r)
+        model.train()
+        cfg = {"params": {"LOSS_FN": "BCE", "BCE_POS_WEIGHT": 1, "OPTIMIZER": "SGD", "LEARNING_RATE": 1e-2,
+                          "WEIGHT_DECAY": 1e-3, "CLIP_VALUE": 1, "TRAIN_SEQUENCE_ENCODER": False}}
+        loss_fn, opt, trainer = build_training(cfg, model, world_size=w)  # Trainer.__init__ -> sync_initial_state
+        if momentum:
+            from protnote_amd.utils.optim import FusedClipSGD
+
+            opt = FusedClipSGD(opt.params, lr=1e-2, momentum=momentum, weight_decay=1e-3, max_norm=1.0)
+            with torch.no_grad():
+                opt.flat_m.add_(0.25 * r)
+            D.sync_initial_state(model, opt)
+        assert opt.flat_v is None and (opt.flat_m is None) == (momentum == 0.0)
+        for _ in range(2):
+            train_step(model, loss_fn, opt, batch, world_size=w)
+        sd = opt.state_dict()
+        assert (len(sd["state"]) == 0) == (momentum == 0.0)
+        out.append(opt.flat_w.cpu().numpy())
+    q.put((r, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_sgd_through_build_training():
+    """OPTIMIZER: SGD with world_size 2 (reference ProtNoteTrainer.py:238-243 under DDP): Trainer.__init__ syncs the
+    initial state of an optimiser that keeps no moment blocks (it crashed on them in round 4), and after two averaged
+    steps both replicas hold identical weights - with and without momentum."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sgd_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for case in range(2):
+        np.testing.assert_array_equal(res[0][case], res[1][case])
+        assert np.isfinite(res[0][case]).all()
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with NO torchrun environment must run two ranks and say so (n_gpus: 2, dp2, comm
     block).  With >= 2 GPUs this is the real RCCL path; on a 1-GPU box both ranks share device 0 over gloo (dry run of
