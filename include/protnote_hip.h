@@ -118,7 +118,7 @@ typedef struct pn_pairhead {
   int d;        /* latent dim: P_e [B][d], L_e [NL][d] */
   int in_dim;   /* 2d (concatenation) or 3d (concatenation_diff / _prod) */
   int fusion;   /* 0 concatenation, 1 concatenation_diff, 2 concatenation_prod */
-  int nlayers;  /* hidden layers (>= 2) */
+  int nlayers;  /* hidden layers (>= 1; OUTPUT_MLP_NUM_LAYERS: 1 has no pair-grid GEMM at all) */
   int h;        /* hidden width */
   const float* w[PN_MAX_LAYERS];    /* w[0]: [h][in_dim]; w[i>0]: [h][h] */
   const float* bias[PN_MAX_LAYERS]; /* hidden-layer bias when there is no BN, else NULL */
@@ -239,6 +239,11 @@ int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, const float* 
 int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL, const float* dl_pairs,
                     const pn_pairhead_grads* gr, float* dP_e, float* dL_e, int label_chunk, void* save,
                     size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+/* save_embeddings=True on this path (ProtNote.py:292-302 in train mode; the trainer passes the flag through,
+ * ProtNoteTrainer.py:288): hidden_pairs [NL*B][h] = relu(bn(z_last)), the penultimate activations of the forward whose
+ * activations `save` holds (label-major pair grid).  Call between pn_pairhead_fwd_train and pn_pairhead_bwd. */
+int pn_pairhead_train_hidden(const pn_pairhead* hd, int B, int NL, int label_chunk, const void* save, size_t save_bytes,
+                             float* hidden_pairs, void* stream);
 
 /* Backward of the similarity head (ProtNote.py:281-284 under autograd): dlogits [B][NL] -> dP_e [B][d],
  * dL_e [NL][d]; the L2 normalisations are recomputed. */

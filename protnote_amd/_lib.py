@@ -119,6 +119,8 @@ _SIGS = {
     "pn_pairhead_bwd": (C.c_int, [C.POINTER(pn_pairhead), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.POINTER(pn_pairhead_grads), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_pairhead_train_hidden": (C.c_int, [C.POINTER(pn_pairhead), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]),
     "pn_similarity_train_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pn_similarity_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1313,7 +1313,7 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
   w.B1 = bp.take<float>((size_t)NL * h);
   w.weff = hd->fusion == 1 ? bp.take<float>((size_t)h * 2 * hd->d) : nullptr;
   // stored chunk activations: layers 2..n-1 (ping-pong), plus z1 itself for concatenation_prod
-  const int nstored = hd->nlayers - 2 + (hd->fusion == 2 ? 1 : 0);
+  const int nstored = (hd->nlayers > 2 ? hd->nlayers - 2 : 0) + (hd->fusion == 2 ? 1 : 0);
   const int nz = nstored >= 2 ? 2 : nstored;
   w.z[0] = nz >= 1 ? bp.take<float>((size_t)crow * h) : nullptr;
   w.z[1] = nz >= 2 ? bp.take<float>((size_t)crow * h) : nullptr;
@@ -1344,7 +1344,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
                                     void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h, d = hd->d;
-  if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 2..%d)", hd->nlayers, PN_MAX_LAYERS);
+  if (hd->nlayers < 1 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 1..%d)", hd->nlayers, PN_MAX_LAYERS);
   if (hd->fusion < 0 || hd->fusion > 2) return fail("pairhead: fusion %d not implemented", hd->fusion);
   if (d % 4 || h % 4) return fail("pairhead: d and h must be multiples of 4");
   const int chunk = clamp_chunk(label_chunk, NL);
@@ -1387,6 +1387,14 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
     HIP_OK(hipGetLastError());
   }
 
+  if (hd->nlayers == 1 && !prod) {
+    // OUTPUT_MLP_NUM_LAYERS: 1 (get_mlp, ProtNote.py:337-378: one hidden layer + the output neuron).  The hidden layer is
+    // the separable one, so there is no pair-grid GEMM at all: logit[i,j] = w_out . relu(A'[i] + B'[j]) + b_out in one pass
+    hipLaunchKernelGGL(k_pairsum_rowdot, dim3(nblk(B, 64), nblk(NL, 64)), dim3(256), 0, st, (const float*)w.A1, (long)h,
+                       (const float*)w.B1, (long)h, B, NL, h, hd->w_out, hd->b_out, logits_pairs);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   for (int j0 = 0; j0 < NL; j0 += chunk) {
     const int nj = (NL - j0 < chunk) ? NL - j0 : chunk;
     const long rows = (long)nj * B;
@@ -1438,6 +1446,12 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
         in = out;
         in_act = true;
       }
+    }
+    if (hd->nlayers == 1) {  // concatenation_prod with one hidden layer: the stored z1 of this chunk -> logits
+      hipLaunchKernelGGL(k_rowdot_rows, dim3(nblk(rows, 4)), dim3(256), 0, st, in, (long)h, rows, h, (const float*)w.s[0],
+                         (const float*)w.t[0], hd->w_out, hd->b_out, logits_pairs + (long)j0 * B);
+      HIP_OK(hipGetLastError());
+      continue;
     }
     hipLaunchKernelGGL(k_rowdot_reduce, dim3(nblk(rows, 256)), dim3(256), 0, st, w.partials, w.nparts, rows,
                        hd->b_out, logits_pairs + (long)j0 * B);
@@ -2078,6 +2092,7 @@ struct PairSave {
   float *A1, *B1, *Ap, *Bp;
   float *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS], *mean[PN_MAX_LAYERS], *invstd[PN_MAX_LAYERS];
   float* zbuf[PN_MAX_LAYERS];  // l >= 1: (R + S) rows x h; z_l lives at row offset S
+  float* dq;  // concatenation_prod with ONE hidden layer: dQ [R][d] (deeper heads put it over the then-dead z1 buffer)
 };
 
 static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& bp, PairSave& s) {
@@ -2095,6 +2110,7 @@ static bool pair_save_carve(const pn_pairhead* hd, int B, int NL, long S, Bump& 
   }
   s.zbuf[0] = hd->fusion == 2 ? bp.take<float>((size_t)(R + S) * h) : nullptr;  // concatenation_prod stores z1 too
   for (int l = 1; l < hd->nlayers; ++l) s.zbuf[l] = bp.take<float>((size_t)(R + S) * h);
+  s.dq = (hd->fusion == 2 && hd->nlayers == 1) ? bp.take<float>((size_t)R * hd->d) : nullptr;
   return bp.ok;
 }
 
@@ -2103,6 +2119,8 @@ struct PairTrainWs {
   float *cs, *p, *q, *WT, *weff, *dweff, *part, *dA1, *dB1;
   float* m1part;  // B <= 256: per-label-chunk partials of M1 (k_pair_mask_reduce_fused), [m1_chunks][B][h]
   int m1_chunks;
+  float* dwpart;  // one hidden layer: partial rows of dw_out, [m1_chunks][h] (B <= 256) or [NL][h]
+  long dwpart_rows;
   size_t part_floats;
   ColScr colscr;
   StatScr statscr;
@@ -2140,6 +2158,8 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   if (w.m1_chunks < 1) w.m1_chunks = 1;
   if (w.m1_chunks > 128) w.m1_chunks = 128;
   w.m1part = (B <= 256 && hd->fusion != 2) ? bp.take<float>((size_t)w.m1_chunks * B * h) : nullptr;
+  w.dwpart_rows = w.m1part != nullptr ? w.m1_chunks : NL;
+  w.dwpart = (hd->nlayers == 1 && hd->fusion != 2) ? bp.take<float>((size_t)w.dwpart_rows * h) : nullptr;
   colscr_carve(bp, (long)B * NL, h, w.colscr);
   statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
@@ -2168,7 +2188,7 @@ extern "C" size_t pn_pairhead_train_ws_bytes(const pn_pairhead* hd, int B, int N
 }
 
 static int pair_check(const pn_pairhead* hd, int B, int NL) {
-  if (hd->nlayers < 2 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported", hd->nlayers);
+  if (hd->nlayers < 1 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 1..%d)", hd->nlayers, PN_MAX_LAYERS);
   if (hd->fusion < 0 || hd->fusion > 2) return fail("pairhead: fusion %d not implemented", hd->fusion);
   if (hd->d % 4 || hd->h % 4) return fail("pairhead: d and h must be multiples of 4");
   if ((long)B * NL > 0x7fffffffL) return fail("pairhead: pair grid too large");
@@ -2291,6 +2311,15 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
                        (const double*)w.S2, (double)R, hd->bn_eps, hd->bn_momentum, h, h, sv.s[l], sv.t[l],
                        sv.mean[l], sv.invstd[l]));
     HIP_OK(hipGetLastError());
+  }
+  if (n == 1 && !prod) {
+    // OUTPUT_MLP_NUM_LAYERS: 1: the separable layer is the only hidden layer - its BatchNorm statistics came in closed form
+    // from the two tables above, and the logits are one fused pair-sum -> ReLU -> row-dot pass (no pair-grid GEMM, nothing
+    // stored over the grid)
+    hipLaunchKernelGGL(k_pairsum_rowdot, dim3(nblk(B, 64), nblk(NL, 64)), dim3(256), 0, st, (const float*)sv.Ap, (long)h,
+                       (const float*)sv.Bp, (long)h, B, NL, h, hd->w_out, hd->b_out, logits_pairs);
+    HIP_OK(hipGetLastError());
+    return 0;
   }
   if (h <= 3072) {
     const int rpw = 32;  // rows per wave: 128 rows (1.5 MB) per workgroup
@@ -2451,12 +2480,35 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
     rp.A = sv.A1; rp.lda = h; rp.Bm = sv.B1; rp.ldb = h;
     rp.s = sv.s[0]; rp.t = sv.t[0];
     rp.out = w.dB1; rp.ldo = h;
-    if (w.m1part != nullptr) {  // B <= 256: both tables from one pass over the gradient
+    if (n == 1) {
+      // OUTPUT_MLP_NUM_LAYERS: 1: the separable layer is the top layer.  Its upstream gradient is the rank-1 dl[r] * w_out[c],
+      // generated inside the same masked reductions (nothing [R][h] exists in this configuration); the same pass leaves the
+      // partial rows of dw_out[c] = sum_r dl[r] relu(bn(z1))[r][c]
+      rp.DH = nullptr; rp.gvec = dl_pairs; rp.w = hd->w_out; rp.dwpart = w.dwpart;
+      long dw_rows;
+      if (w.m1part != nullptr) {
+        const int per = (NL + w.m1_chunks - 1) / w.m1_chunks;
+        const int nch = (NL + per - 1) / per;
+        hipLaunchKernelGGL((k_pair_mask_reduce_fused<true>), dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part,
+                           per);
+        hipLaunchKernelGGL(k_pair_m1_reduce, dim3(nblk((long)B * h / 4, 256)), dim3(256), 0, st, (const float*)w.m1part, nch,
+                           (long)B * h, h, w.dA1, (long)h);
+        dw_rows = nch;
+      } else {
+        hipLaunchKernelGGL((k_pair_mask_reduce<0, true>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, rp);
+        rp.out = w.dA1;
+        hipLaunchKernelGGL((k_pair_mask_reduce<1, true>), dim3(nblk(h, 1024), B), dim3(256), 0, st, rp);
+        dw_rows = NL;
+      }
+      if (gr->dw_out != nullptr)
+        hipLaunchKernelGGL(k_colsum_rows, dim3(nblk(h, 256)), dim3(256), 0, st, (const float*)w.dwpart, dw_rows, h, gr->dw_out);
+      HIP_OK(hipGetLastError());
+    } else if (w.m1part != nullptr) {  // B <= 256: both tables from one pass over the gradient
       const int per = (NL + w.m1_chunks - 1) / w.m1_chunks;
       const int nch = (NL + per - 1) / per;
       {
         ProfScope ps(ST_PAIR_MASK_REDUCE, (double)R * 4.0 * h, st);  // one read of the 101 GB gradient
-        hipLaunchKernelGGL(k_pair_mask_reduce_fused, dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part, per);
+        hipLaunchKernelGGL((k_pair_mask_reduce_fused<false>), dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part, per);
       }
       hipLaunchKernelGGL(k_pair_m1_reduce, dim3(nblk((long)B * h / 4, 256)), dim3(256), 0, st, (const float*)w.m1part, nch,
                          (long)B * h, h, w.dA1, (long)h);
@@ -2494,25 +2546,40 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   } else {
     // concatenation_prod: z1 is stored; dz1 is materialised over G, then summed / contracted
     float* z0 = sv.zbuf[0] + (size_t)S * h;
+    const bool top0 = (n == 1);  // one hidden layer: layer 0 is the top layer, its upstream gradient is dl (x) w_out
     StatsParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.R = R; sp.C = h; sp.rows_per_block = stats_rows; sp.pairB = 1;
-    sp.Z = z0; sp.ldz = h; sp.G = G; sp.ldg = h;
+    sp.Z = z0; sp.ldz = h;
+    if (top0) { sp.gvec = dl_pairs; sp.w = hd->w_out; }
+    else { sp.G = G; sp.ldg = h; }
     sp.s = sv.s[0]; sp.t = sv.t[0]; sp.mean = sv.mean[0]; sp.invstd = sv.invstd[0];
     sp.part = w.statscr.part;
-    hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
-    PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
+    if (top0) {
+      hipLaunchKernelGGL((k_bn_bwd_stats<1, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+      PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 3 * h, h, w.S1, w.S2, w.dwacc, w.statscr.red, st));
+    } else {
+      hipLaunchKernelGGL((k_bn_bwd_stats<0, 0>), dim3(nblk(h, 1024), nblk(R, stats_rows)), dim3(256), 0, st, sp);
+      PN_OK(reduce_parts<double>(w.statscr.part, nblk(R, stats_rows), 2 * h, h, w.S1, w.S2, nullptr, w.statscr.red, st));
+    }
     PN_OK(bwd_finalize(st, (const double*)w.S1,
-                       (const double*)w.S2, (const double*)nullptr, (double)R, h, hd->bn[0].weight,
+                       (const double*)w.S2, (const double*)(top0 ? w.dwacc : nullptr), (double)R, h, hd->bn[0].weight,
                        (const float*)sv.s[0], (const float*)sv.mean[0], (const float*)sv.invstd[0],
-                       (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0], (float*)nullptr));
+                       top0 ? hd->w_out : (const float*)nullptr, w.cs, w.p, w.q, gr->dgamma[0], gr->dbeta[0],
+                       top0 ? gr->dw_out : (float*)nullptr));
     DzParams dp;
     memset(&dp, 0, sizeof(dp));
     dp.R = R; dp.C = h; dp.rows_per_block = 512;
-    dp.Z = z0; dp.ldz = h; dp.G = G; dp.ldg = h; dp.s = sv.s[0]; dp.t = sv.t[0]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q;
-    float* dz0 = const_cast<float*>(G);
+    dp.Z = z0; dp.ldz = h; dp.s = sv.s[0]; dp.t = sv.t[0]; dp.cs = w.cs; dp.p = w.p; dp.q = w.q;
+    float* dz0 = top0 ? z0 : const_cast<float*>(G);  // top layer: dz over z1 itself (as the deeper heads' top layer)
     dp.out = dz0; dp.ldo = h;
-    hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(h, 1024), nblk(R, 512)), dim3(256), 0, st, dp);
+    if (top0) {
+      dp.gvec = dl_pairs;
+      hipLaunchKernelGGL((k_dz_apply<1>), dim3(nblk(h, 1024), nblk(R, 512)), dim3(256), 0, st, dp);
+    } else {
+      dp.G = G; dp.ldg = h;
+      hipLaunchKernelGGL((k_dz_apply<0>), dim3(nblk(h, 1024), nblk(R, 512)), dim3(256), 0, st, dp);
+    }
     hipLaunchKernelGGL((k_pair_sum<0>), dim3(nblk(h, 1024), NL), dim3(256), 0, st, (const float*)dz0, (long)h, B, NL, h,
                        (const float*)nullptr, 0L, w.dB1, (long)h, 0);
     hipLaunchKernelGGL((k_pair_sum<1>), dim3(nblk(h, 1024), B), dim3(256), 0, st, (const float*)dz0, (long)h, B, NL, h,
@@ -2525,8 +2592,8 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       tp.B = P_e; tp.ldb = d; tp.B2 = L_e; tp.ldb2 = d; tp.pairB = B;
       PN_OK((launch_tn<TA_PLAIN, TB_PAIRPROD>(tp, gr->dw[0] + 2 * d, hd->in_dim, w.part, w.part_floats, st)));
     }
-    // dQ = dz1 W1c  ([R][d], over the dead z1 buffer)
-    dQ = sv.zbuf[0];
+    // dQ = dz1 W1c  ([R][d], over the dead z1 buffer; with one hidden layer dz1 lives IN that buffer -> its own block)
+    dQ = top0 ? sv.dq : sv.zbuf[0];
     PN_OK(transpose_into(hd->w[0] + 2 * d, hd->in_dim, h, d, w.WT, h, st));  // WT[d][h]
     GemmParams p = gp_zero();
     p.M = (int)R; p.N = d; p.Nstore = d; p.Kseg = h;
@@ -2834,7 +2901,25 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h;
   const long R = (long)B * NL;
-  if (hd->nlayers < 2) return fail("pairhead hidden: nlayers < 2 unsupported");
+  if (hd->nlayers < 1) return fail("pairhead hidden: nlayers < 1 unsupported");
+  if (hd->nlayers == 1) {
+    // one hidden layer: the penultimate activation is relu(bn(z1)) itself - relu(A'[i] + B'[j]) from the two folded tables,
+    // or (concatenation_prod) the stored z1 of the single chunk through its fold
+    const size_t base1 = pn_pairhead_eval_ws_bytes(hd, B, NL, NL);
+    if (ws_bytes < base1) return fail("pairhead hidden: workspace too small");
+    PN_OK(pn_pairhead_fwd_eval(hd, P_e, L_e, B, NL, logits_pairs, NL, ws, base1, stream));
+    Bump bp1(ws, base1);
+    PairWs w1;
+    if (!pair_carve(hd, B, NL, NL, bp1, w1)) return fail("pairhead hidden: workspace carve failed");
+    if (hd->fusion == 2)
+      hipLaunchKernelGGL(k_affine_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)w1.z[0], (long)h,
+                         hidden_pairs, (long)h, R, h, (const float*)w1.s[0], (const float*)w1.t[0]);
+    else
+      hipLaunchKernelGGL(k_pairsum_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)w1.A1, (long)h,
+                         (const float*)w1.B1, (long)h, B, R, h, hidden_pairs, (long)h);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   // Run the eval head with one layer fewer and a unit "output neuron" trick is not possible (the row-dot epilogue
   // never stores), so: layers 1..n-2 through the normal path into a scratch z, the last hidden layer stored too.
   const size_t base = pn_pairhead_eval_ws_bytes(hd, B, NL, NL);
@@ -2867,6 +2952,30 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
   }
   hipLaunchKernelGGL(k_affine_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)zlast, (long)h,
                      hidden_pairs, (long)h, R, h, (const float*)w.s[li], (const float*)w.t[li]);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// save_embeddings on the activation-storing path (ProtNote.py:292-302 under model.train(), or eval mode with autograd on):
+// the penultimate activations relu(bn(z_last)) [NL*B][h] of the forward whose activations `save` holds - read back from
+// the store (the last hidden pre-activation and its BatchNorm fold), nothing is recomputed.  Call after
+// pn_pairhead_fwd_train and before pn_pairhead_bwd (the backward consumes the store in place).
+extern "C" int pn_pairhead_train_hidden(const pn_pairhead* hd, int B, int NL, int label_chunk, const void* save,
+                                        size_t save_bytes, float* hidden_pairs, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PN_OK(pair_check(hd, B, NL));
+  const int h = hd->h, n = hd->nlayers;
+  const long R = (long)B * NL, S = pair_chunk_rows(B, NL, label_chunk);
+  Bump bs(const_cast<void*>(save), save_bytes);
+  PairSave sv;
+  if (!pair_save_carve(hd, B, NL, S, bs, sv)) return fail("pairhead train hidden: save buffer too small");
+  if (n == 1 && hd->fusion != 2)
+    hipLaunchKernelGGL(k_pairsum_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st, (const float*)sv.Ap, (long)h,
+                       (const float*)sv.Bp, (long)h, B, R, h, hidden_pairs, (long)h);
+  else
+    hipLaunchKernelGGL(k_affine_relu_rows, dim3(nblk(R * h, 256)), dim3(256), 0, st,
+                       (const float*)(sv.zbuf[n - 1] + (size_t)S * h), (long)h, hidden_pairs, (long)h, R, h,
+                       (const float*)sv.s[n - 1], (const float*)sv.t[n - 1]);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -382,6 +382,12 @@ struct PairRedParams {
   const float *s, *t, *cs, *p, *q;
   float* out;
   long ldo;
+  // RANK1 kernels (OUTPUT_MLP_NUM_LAYERS: 1 - the hidden layer IS the top layer): the upstream gradient is the rank-1
+  // dl[r] * w_out[c], never a matrix: gvec = dl over the label-major pair grid [NL*B], w = w_out [C]; dwpart receives the
+  // partial rows of dw_out[c] = sum_r dl[r] relu(s z1 + t) (one row per label chunk / per label, summed by k_colsum_rows)
+  const float* gvec;
+  const float* w;
+  float* dwpart;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +402,7 @@ struct PairRedParams {
 // (dz1 = cs du + p + q z1 with cs, p, q as in k_bn_bwd_finalize).  The separate statistics pass over the 101 GB
 // gradient is gone; the small-table work is k_pair_colsums -> k_pair_bn0_finalize -> k_pair_apply.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool RANK1 = false>
 __global__ __launch_bounds__(256) void k_pair_mask_reduce(const PairRedParams P) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= P.C) return;
@@ -406,23 +412,51 @@ __global__ __launch_bounds__(256) void k_pair_mask_reduce(const PairRedParams P)
   const float4 zf = MODE == 0 ? ld4(P.Bm + (long)fixed * P.ldb + c) : ld4(P.A + (long)fixed * P.lda + c);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;  // RANK1, MODE 0: this label's share of dw_out
+  double e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   int cnt = 0;
 #pragma unroll 4
   for (int k = 0; k < n; ++k) {
     const long r = MODE == 0 ? (long)fixed * P.B + k : (long)k * P.B + fixed;
     const float4 zv = MODE == 0 ? ld4(P.A + (long)k * P.lda + c) : ld4(P.Bm + (long)k * P.ldb + c);
-    const float4 g = ld4(P.DH + r * P.ldh + c);
-    a0 += fmaf(zf.x + zv.x, s.x, t.x) > 0.f ? g.x : 0.f;
-    a1 += fmaf(zf.y + zv.y, s.y, t.y) > 0.f ? g.y : 0.f;
-    a2 += fmaf(zf.z + zv.z, s.z, t.z) > 0.f ? g.z : 0.f;
-    a3 += fmaf(zf.w + zv.w, s.w, t.w) > 0.f ? g.w : 0.f;
+    float4 g;
+    if (RANK1) {
+      const float gv = P.gvec[r];
+      g = make_float4(gv, gv, gv, gv);
+    } else {
+      g = ld4(P.DH + r * P.ldh + c);
+    }
+    const float h0 = fmaf(zf.x + zv.x, s.x, t.x), h1 = fmaf(zf.y + zv.y, s.y, t.y);
+    const float h2 = fmaf(zf.z + zv.z, s.z, t.z), h3 = fmaf(zf.w + zv.w, s.w, t.w);
+    a0 += h0 > 0.f ? g.x : 0.f;
+    a1 += h1 > 0.f ? g.y : 0.f;
+    a2 += h2 > 0.f ? g.z : 0.f;
+    a3 += h3 > 0.f ? g.w : 0.f;
+    if (RANK1 && MODE == 0) {
+      w0 = fmaf(fmaxf(h0, 0.f), g.x, w0);
+      w1 = fmaf(fmaxf(h1, 0.f), g.x, w1);
+      w2 = fmaf(fmaxf(h2, 0.f), g.x, w2);
+      w3 = fmaf(fmaxf(h3, 0.f), g.x, w3);
+    }
     if (++cnt == 256) {
       d0 += a0; d1 += a1; d2 += a2; d3 += a3;
       a0 = a1 = a2 = a3 = 0.f;
+      if (RANK1 && MODE == 0) {
+        e0 += w0; e1 += w1; e2 += w2; e3 += w3;
+        w0 = w1 = w2 = w3 = 0.f;
+      }
       cnt = 0;
     }
   }
   d0 += a0; d1 += a1; d2 += a2; d3 += a3;
+  if (RANK1) {  // du = mask * dl * w_out: the column factor leaves the sums
+    const float4 wv = ld4(P.w + c);
+    d0 *= wv.x; d1 *= wv.y; d2 *= wv.z; d3 *= wv.w;
+    if (MODE == 0) {
+      e0 += w0; e1 += w1; e2 += w2; e3 += w3;
+      *reinterpret_cast<float4*>(P.dwpart + (long)fixed * P.C + c) = make_float4((float)e0, (float)e1, (float)e2, (float)e3);
+    }
+  }
   *reinterpret_cast<float4*>(P.out + (long)fixed * P.ldo + c) =
       make_float4((float)d0, (float)d1, (float)d2, (float)d3);
 }
@@ -435,6 +469,7 @@ __global__ __launch_bounds__(256) void k_pair_mask_reduce(const PairRedParams P)
 // in chunk order by k_pair_m1_reduce: deterministic, no atomics.  Reads the 101 GB gradient once instead of twice.
 constexpr int PMR_JB = 2;   // labels per barrier pair
 constexpr int PMR_IG = 16;  // protein groups: 512 threads = 16 groups x 32 column quads, 16 proteins per thread
+template <bool RANK1 = false>
 __global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const PairRedParams P, float* __restrict__ m1part,
                                                                         int labels_per_chunk) {
   constexpr int RPT = 256 / PMR_IG;  // proteins per thread
@@ -449,6 +484,9 @@ __global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const Pa
   if (j1 > P.NL) j1 = P.NL;
   const float4 s = ld4(P.s + c), t = ld4(P.t + c);
   float4 a[RPT], m1[RPT];
+  float4 dwo = make_float4(0.f, 0.f, 0.f, 0.f);  // RANK1: this thread's share of dw_out over its proteins and label chunk
+  float4 wq = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (RANK1) wq = ld4(P.w + c);
   unsigned roff[RPT];  // element offset of protein i's row inside one label's block of the gradient (< 2^31: B * ldh)
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
@@ -465,6 +503,28 @@ __global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const Pa
       float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j + jj < j1) {
         const float4 zb = ld4(P.Bm + (long)(j + jj) * P.ldb + c);
+        if (RANK1) {
+          // upstream gradient dl[r] * w_out[c]: one scalar per (protein, label), shared by the 32 column quads of a group
+          const float* dlrow = P.gvec + (long)(j + jj) * P.B;  // uniform
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            const int i = ig + PMR_IG * k;
+            const float gk = i < P.B ? dlrow[i] : 0.f;
+            const float4 av = a[k];
+            const float hx = fmaf(av.x + zb.x, s.x, t.x), hy = fmaf(av.y + zb.y, s.y, t.y);
+            const float hz = fmaf(av.z + zb.z, s.z, t.z), hw = fmaf(av.w + zb.w, s.w, t.w);
+            const float dx = hx > 0.f ? gk : 0.f, dy = hy > 0.f ? gk : 0.f;
+            const float dz = hz > 0.f ? gk : 0.f, dw = hw > 0.f ? gk : 0.f;
+            m0.x += dx; m0.y += dy; m0.z += dz; m0.w += dw;
+            float4& acc = m1[k];
+            acc.x += dx; acc.y += dy; acc.z += dz; acc.w += dw;
+            dwo.x = fmaf(fmaxf(hx, 0.f), gk, dwo.x);  // (fmaxf(NaN, 0) = 0: the proteins past the batch add nothing)
+            dwo.y = fmaf(fmaxf(hy, 0.f), gk, dwo.y);
+            dwo.z = fmaf(fmaxf(hz, 0.f), gk, dwo.z);
+            dwo.w = fmaf(fmaxf(hw, 0.f), gk, dwo.w);
+          }
+          m0.x *= wq.x; m0.y *= wq.y; m0.z *= wq.z; m0.w *= wq.w;
+        } else {
         const float* base = P.DH + (long)(j + jj) * P.B * P.ldh;  // uniform
 #pragma unroll
         for (int k0 = 0; k0 < RPT; k0 += 8) {  // eight 16-byte loads in flight per thread
@@ -483,6 +543,7 @@ __global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const Pa
             acc.x += dx; acc.y += dy; acc.z += dz; acc.w += dw;
           }
           __builtin_amdgcn_sched_barrier(0);  // keep the next batch of loads behind this batch's arithmetic (registers)
+        }
         }
       }
       red[jj][ig][cq] = m0;
@@ -508,9 +569,108 @@ __global__ __launch_bounds__(PMR_IG * 32) void k_pair_mask_reduce_fused(const Pa
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const int i = ig + PMR_IG * k;
-      if (i < P.B) *reinterpret_cast<float4*>(dst + (long)i * P.C) = m1[k];
+      if (i < P.B) {
+        float4 v = m1[k];
+        if (RANK1) { v.x *= wq.x; v.y *= wq.y; v.z *= wq.z; v.w *= wq.w; }
+        *reinterpret_cast<float4*>(dst + (long)i * P.C) = v;
+      }
     }
   }
+  if (RANK1) {  // this label chunk's row of the dw_out partials: fixed-order sum over the protein groups
+    red[0][ig][cq] = dwo;
+    __syncthreads();
+    if (tid < 32) {
+      const int cc = blockIdx.x * 128 + tid * 4;
+      if (cc < P.C) {
+        float4 v = red[0][0][tid];
+#pragma unroll
+        for (int g2 = 1; g2 < PMR_IG; ++g2) {
+          const float4 w2 = red[0][g2][tid];
+          v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
+        }
+        *reinterpret_cast<float4*>(P.dwpart + (long)blockIdx.y * P.C + cc) = v;
+      }
+    }
+  }
+}
+
+// out[c] = sum over rows of part[row][c], f64, row order (dw_out of the one-hidden-layer head from its partial rows)
+__global__ void k_colsum_rows(const float* __restrict__ part, long nrows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0;
+  for (long r = 0; r < nrows; ++r) a += (double)part[r * C + c];
+  out[c] = (float)a;
+}
+
+// OUTPUT_MLP_NUM_LAYERS: 1 - the whole output MLP over the pair grid in one pass, no pair-grid GEMM:
+//   out[j*B + i] = b + sum_c w[c] * relu(Ap[i][c] + Bp[j][c])        (Ap = s*A1 + t, Bp = s*B1: BatchNorm folded in)
+// 64 proteins x 64 labels per workgroup, columns staged through the LDS 32 at a time (transposed: a thread reads the 4
+// proteins / 4 labels of its 4 x 4 pairs as one 16-byte LDS read each); every pair sums its columns in index order.
+__global__ __launch_bounds__(256) void k_pairsum_rowdot(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp,
+                                                        long ldb, int B, int NL, int C, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out) {
+  constexpr int T = 64, KC = 32;
+  __shared__ float As[KC][T + 4];
+  __shared__ float Bs[KC][T + 4];
+  __shared__ float Ws[KC];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+  float acc[4][4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) acc[jj][ii] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += KC) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = tid + 256 * q, row = idx >> 3, cq = (idx & 7) * 4;
+      const bool cin = c0 + cq < C;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 av = (cin && i0 + row < B) ? ld4(Ap + (long)(i0 + row) * lda + c0 + cq) : z4;
+      const float4 bv = (cin && j0 + row < NL) ? ld4(Bp + (long)(j0 + row) * ldb + c0 + cq) : z4;
+      As[cq][row] = av.x; As[cq + 1][row] = av.y; As[cq + 2][row] = av.z; As[cq + 3][row] = av.w;
+      Bs[cq][row] = bv.x; Bs[cq + 1][row] = bv.y; Bs[cq + 2][row] = bv.z; Bs[cq + 3][row] = bv.w;
+    }
+    if (tid < KC) Ws[tid] = c0 + tid < C ? w[c0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < KC; ++c) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[c][tx * 4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[c][ty * 4]);
+      const float wv = Ws[c];
+      const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) acc[jj][ii] = fmaf(fmaxf(a4[ii] + b4[jj], 0.f), wv, acc[jj][ii]);
+    }
+    __syncthreads();
+  }
+  const float bias = b[0];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = j0 + ty * 4 + jj;
+    if (j >= NL) continue;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = i0 + tx * 4 + ii;
+      if (i < B) out[(long)j * B + i] = acc[jj][ii] + bias;
+    }
+  }
+}
+
+// hidden[r = j*B + i][c] = relu(Ap[i][c] + Bp[j][c]): the penultimate activations of the one-hidden-layer head
+// (save_embeddings, small evaluation subsets only)
+__global__ void k_pairsum_relu_rows(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb, int B,
+                                    long R, int C, float* __restrict__ out, long ldo) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * C) return;
+  const long r = e / C;
+  const int c = (int)(e - r * C);
+  const long j = r / B;
+  const int i = (int)(r - j * B);
+  out[r * ldo + c] = fmaxf(Ap[(long)i * lda + c] + Bp[j * ldb + c], 0.f);
 }
 
 // M1[i][c] = sum over the label chunks of k_pair_mask_reduce_fused's partials, in chunk order (f64)

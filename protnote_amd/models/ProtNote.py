@@ -320,16 +320,22 @@ class ProtNote(nn.Module):
         L.check(lib.pn_pairhead_fwd_eval_hidden(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), L.ptr(hidden),
                                                 L.ptr(ws), ws.numel(), L.stream_ptr()))
         del keep
-        pe, le = P_e.cpu(), L_e.cpu()
+        out_emb = hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu()
+        return pairs, {"output_layer_embeddings": out_emb, "joint_embeddings": self._joint_embeddings_cpu(P_e, L_e)}
+
+    def _joint_embeddings_cpu(self, P_e, L_e):
+        """The reference's joint tensor (_get_joint_embeddings, ProtNote.py:112-152) as save_embeddings returns it
+        (:326-328: detached, on the CPU), protein-major rows i * N_L + j.  Only ever built for save_embeddings - the kernels
+        never materialise it."""
+        pe, le = P_e.detach().cpu(), L_e.detach().cpu()
+        B, NL, d = pe.shape[0], le.shape[0], pe.shape[1]
         joint = torch.cat([pe[:, None, :].expand(B, NL, -1), le[None, :, :].expand(B, NL, -1)], dim=2)
         joint = joint.reshape(B * NL, -1)
-        d = pe.shape[1]
         if self.feature_fusion == "concatenation_diff":
             joint = torch.cat([joint, joint[:, :d] - joint[:, d:]], dim=-1)
         if self.feature_fusion == "concatenation_prod":
             joint = torch.cat([joint, joint[:, :d] * joint[:, d:]], dim=-1)
-        out_emb = hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu()
-        return pairs, {"output_layer_embeddings": out_emb, "joint_embeddings": joint}
+        return joint
 
     def additive_attention(self, hidden_states, attention_mask):
         """Reference ProtNote.additive_attention (ProtNote.py:154-166), inference: masked-softmax attention pooling of
@@ -385,16 +391,18 @@ class ProtNote(nn.Module):
         L.require_hip(L_f)
         pool_all = self.label_embedding_pooling_method == "all"
         attn_mask = None
-        if save_embeddings and (self.training or not self.feature_fusion.startswith("concatenation")):
-            raise NotImplementedError("save_embeddings=True is implemented for inference with the concatenation heads")
+        # save_embeddings (ProtNote.py:292-302,324-332; the trainer passes the flag through, ProtNoteTrainer.py:288) is accepted
+        # in every mode, as in the reference: with `similarity` there is nothing to save (both lists stay empty); with the
+        # concatenation heads the joint tensor and the penultimate output-MLP activations come back detached on the CPU -
+        # from the fused inference kernels in eval mode under no_grad, from the activation store otherwise.
+        want_embeddings = bool(save_embeddings) and self.feature_fusion.startswith("concatenation")
         # Which kernels run.  The reference puts no restriction on (mode, autograd) combinations (ProtNote.py:168-334):
         #   train mode, autograd on / off -> the activation-storing path (train-mode BatchNorm: batch statistics, buffers
         #                                    advance - also under torch.no_grad());
         #   eval mode, autograd on and something to differentiate -> the same path with BatchNorm on its running
         #                                    statistics (pn_*.bn_use_running): logits are differentiable;
         #   eval mode otherwise           -> the fused inference kernels (nothing stored).
-        stored = self.training or (torch.is_grad_enabled() and not save_embeddings
-                                   and self._needs_graph(sequence_embeddings, label_embeddings))
+        stored = self.training or (torch.is_grad_enabled() and self._needs_graph(sequence_embeddings, label_embeddings))
         if stored and not self.training and not ProtNote._warned_eval_stored:
             ProtNote._warned_eval_stored = True
             import warnings
@@ -417,11 +425,19 @@ class ProtNote(nn.Module):
             if stored:
                 from .train_path import ensemble_logits, forward_train
 
-                logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
-                                       label_token_counts, attn_mask)
+                if want_embeddings:
+                    self.__dict__["_pn_want_embeddings"] = True  # read (and cleared) by _HeadsTrainFn.forward
+                try:
+                    logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
+                                           label_token_counts, attn_mask)
+                finally:
+                    self.__dict__.pop("_pn_want_embeddings", None)
+                    saved = self.__dict__.pop("_pn_saved_embeddings", None)
                 ndesc = 1 if self.training else int(self.inference_descriptions_per_label)
                 if ndesc != 1:  # ProtNote.py:308-322, differentiable
                     logits = ensemble_logits(logits, ndesc)
+                if want_embeddings and saved is not None:
+                    return logits, saved
                 return logits, {"output_layer_embeddings": [], "joint_embeddings": []}
 
             with torch.no_grad():
@@ -446,7 +462,7 @@ class ProtNote(nn.Module):
                     if ndesc != 1:
                         logits = self._ensemble(logits, B, NL, ndesc, protein_major=True)
                 elif self.feature_fusion.startswith("concatenation"):
-                    if save_embeddings:
+                    if want_embeddings:
                         pairs, embeddings = self._pairhead_eval_with_embeddings(P_e, L_e)
                         return self._ensemble(pairs, B, NL, ndesc), embeddings
                     pairs = self._pairhead_eval(P_e, L_e)

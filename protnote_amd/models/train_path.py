@@ -188,6 +188,15 @@ class _HeadsTrainFn(torch.autograd.Function):
         pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
         L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
                                           L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), st))
+        if model.__dict__.pop("_pn_want_embeddings", False):
+            # save_embeddings=True (reference ProtNote.py:292-302,324-332): the penultimate output-MLP activations are read
+            # back from the store this forward just filled; rows in the reference's protein-major order i * N_L + j
+            hidden = torch.empty(NL, B, hd.h, dtype=torch.float32, device=dev)
+            L.check(lib.pn_pairhead_train_hidden(C.byref(hd), B, NL, chunk, L.ptr(save), save.numel(), L.ptr(hidden), st))
+            model.__dict__["_pn_saved_embeddings"] = {
+                "output_layer_embeddings": hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu(),
+                "joint_embeddings": model._joint_embeddings_cpu(P_e, L_e)}
+            del hidden
         if model.training:
             tracked += [bn.num_batches_tracked for _, bn in hl[:-1] if bn is not None]
         if tracked:
