@@ -116,12 +116,17 @@ def mlp_rows(sd: SD, prefix: str, x: Tensor, training: bool, masks: Optional[dic
     return x
 
 
-def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool, masks: Optional[dict] = None) -> Tensor:
+def output_mlp(sd: SD, prefix: str, x: Tensor, training: bool, masks: Optional[dict] = None,
+               aux: Optional[dict] = None) -> Tensor:
     """get_mlp ProtNote.py:337-378 with batch_norm=True: (Linear no-bias, BN, ReLU[, Dropout]) x n, Linear(h,1); the
-    Dropout follows every hidden layer except the last (:369-371).  `masks`: keep / (1 - p) tensors keyed
-    f"{prefix}{n}" with rows in the joint tensor's protein-major order."""
+    Dropout follows every hidden layer except the last (:369-371).  n >= 1 (OUTPUT_MLP_NUM_LAYERS: 1 = one hidden layer).
+    `masks`: keep / (1 - p) tensors keyed f"{prefix}{n}" with rows in the joint tensor's protein-major order.
+    `aux` receives "output_layer_embeddings": the input of the output neuron, i.e. what save_embeddings returns
+    (ProtNote.py:294-302: the layers are applied one by one up to index len - 2, the last ReLU)."""
     lin = _linear_indices(sd, prefix)
     for n, i in enumerate(lin):
+        if n == len(lin) - 1 and aux is not None:
+            aux["output_layer_embeddings"] = x
         x = F.linear(x, sd[f"{prefix}{i}.weight"], sd.get(f"{prefix}{i}.bias"))
         if n < len(lin) - 1:
             if f"{prefix}{i + 1}.running_mean" in sd:
@@ -188,7 +193,10 @@ def protnote_forward(sd: SD, onehots: Optional[Tensor], lens: Optional[Tensor], 
     if fusion == "similarity":
         logits = torch.mm(F.normalize(P_e, dim=-1, p=2), F.normalize(L_e, dim=-1, p=2).t()) / temperature
     elif fusion.startswith("concatenation"):
-        logits = output_mlp(sd, "output_layer.", joint_embeddings(P_e, L_e, fusion), training, dropout_masks)
+        joint = joint_embeddings(P_e, L_e, fusion)
+        if aux is not None:  # save_embeddings (ProtNote.py:324-332)
+            aux["joint_embeddings"] = joint
+        logits = output_mlp(sd, "output_layer.", joint, training, dropout_masks, aux)
     else:
         raise ValueError("feature fusion method not implemented")
     if training or descriptions_per_label == 1:
@@ -537,7 +545,8 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                adam_state: Optional[dict] = None, temperature: float = 0.07, apply_update: bool = True,
                train_sequence_encoder: bool = False, attention_mask: Optional[Tensor] = None,
                dropout_masks: Optional[dict] = None, train_projection_head: bool = True, optimizer: str = "Adam",
-               weight_decay: float = 0.0, **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
+               weight_decay: float = 0.0, aux: Optional[dict] = None,
+               **loss_kw) -> Tuple[Tensor, Tensor, Dict[str, Tensor], Tensor]:
     """Train-step body ProtNoteTrainer.py:728-755 (fp32; autocast/GradScaler are no-ops on CPU) with the optimiser
     _set_optimizer built (:230-243): Adam(lr) | AdamW(lr, weight_decay) | SGD(lr, weight_decay) at torch's defaults.
 
@@ -551,7 +560,7 @@ def train_step(sd: SD, onehots: Tensor, lens: Tensor, label_embeddings: Tensor, 
                               noise_alpha=noise_alpha, noise_u=noise_u, temperature=temperature,
                               label_token_counts=label_token_counts, dilation_base=dilation_base,
                               train_sequence_encoder=train_sequence_encoder, attention_mask=attention_mask,
-                              dropout_masks=dropout_masks)
+                              dropout_masks=dropout_masks, aux=aux)
     y = multihots.float()
     l = bce_loss(logits, y, **loss_kw) if loss == "BCE" else focal_loss(logits, y, **loss_kw)
     grads_t = torch.autograd.grad(l, [leaves[k] for k in names], allow_unused=True)

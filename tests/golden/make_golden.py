@@ -1053,6 +1053,111 @@ def golden_grid_samplers():
     print("grid_samplers.npz", len(out))
 
 
+# --------------------------------------------------------------------------------------------
+def golden_config_holes():
+    """Two corners of the reference's config surface (VERDICT r04 missing 3-4):
+      * OUTPUT_MLP_NUM_LAYERS: 1 (get_mlp, ProtNote.py:337-378: ONE hidden layer + the output neuron) for the three
+        concatenation fusions (+ one case without BatchNorm): eval logits (raw / ensembled), eval save_embeddings, one
+        train step (BCE) with gradients and post-Adam weights, and the train-mode save_embeddings outputs;
+      * save_embeddings=True in TRAIN mode on the 3-layer head (ProtNote.py:292-302,324-332; the trainer passes the flag
+        through, ProtNoteTrainer.py:288) and with `similarity` (nothing to save: both lists stay empty)."""
+    from protnote.models.protein_encoders import ProteInfer
+    from protnote.models.ProtNote import ProtNote
+    from protnote.utils.losses import get_loss
+    import protnote.models.ProtNote as PN
+
+    enc_cfg = dict(num_labels=7, input_channels=20, output_channels=28, kernel_size=9,
+                   dilation_base=3, num_resnet_blocks=2, bottleneck_factor=0.5)
+    base = dict(protein_embedding_dim=28, label_embedding_dim=24, latent_dim=16,
+                output_mlp_hidden_dim_scale_factor=3, outout_mlp_add_batchnorm=True, projection_head_num_layers=4,
+                projection_head_hidden_dim_scale_factor=3, dropout=0.0, label_embedding_noising_alpha=20.0,
+                temperature=0.07)
+    lens = [50, 3, 21, 50, 17, 44, 9]
+    lmax, n_labels = 50, 11
+    cases = [("1layer_concatenation", "concatenation", 1, True), ("1layer_concatenation_diff", "concatenation_diff", 1, True),
+             ("1layer_concatenation_prod", "concatenation_prod", 1, True), ("1layer_concatenation_nobn", "concatenation", 1, False),
+             ("3layer_concatenation", "concatenation", 3, True), ("3layer_concatenation_prod", "concatenation_prod", 3, True),
+             ("3layer_similarity", "similarity", 3, True)]
+    for name, fusion, nlayers, out_bn in cases:
+        head_cfg = dict(base, output_mlp_num_layers=nlayers, outout_mlp_add_batchnorm=out_bn)
+        g = torch.Generator().manual_seed(4321)
+        torch.manual_seed(3)
+        enc = ProteInfer(activation=torch.nn.ReLU, **enc_cfg)
+        model = ProtNote(sequence_encoder=enc, label_encoder=None, feature_fusion=fusion,
+                         inference_descriptions_per_label=2, **head_cfg)
+        randomize_(model, g)
+        for n, p in model.named_parameters():
+            if n.startswith("sequence_encoder"):
+                p.requires_grad = False
+        out = {"fusion": np.array(fusion)}
+        out.update({"enc_cfg_" + k: np.array(v) for k, v in enc_cfg.items()})
+        out.update({"head_cfg_" + k: np.array(v) for k, v in head_cfg.items()})
+        out.update(sd_np(model, "sd/"))
+        x, _ = onehots(g, lens, lmax)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        lab = torch.randn(n_labels * 2, 24, generator=g)
+        counts = torch.randint(3, 30, (n_labels * 2,), generator=g)
+        y = (torch.rand(len(lens), n_labels, generator=g) < 0.3).to(torch.int64)
+        out.update(x=x.numpy(), lens=lens_t.numpy(), label_embeddings=lab.numpy(),
+                   label_token_counts=counts.numpy(), multihots=y.numpy())
+
+        def emb_np(prefix, emb):
+            for k in ("output_layer_embeddings", "joint_embeddings"):
+                v = emb[k]
+                out[prefix + k + "_is_empty_list"] = np.array(isinstance(v, list) and len(v) == 0)
+                if not isinstance(v, list):
+                    out[prefix + k] = v.numpy().copy()
+
+        model.eval()
+        with torch.no_grad():
+            lg, emb = model(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab, save_embeddings=True)
+            out["eval/logits_ens2"] = lg.numpy()
+            emb_np("eval/", emb)
+            model.inference_descriptions_per_label = 1
+            lg1, _ = model(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab)
+            out["eval/logits_raw"] = lg1.numpy()
+            model.inference_descriptions_per_label = 2
+
+        lab1 = lab[0::2].contiguous()
+        cnt1 = counts[0::2].contiguous()
+        u = torch.rand(lab1.shape, generator=g)
+        out["train/noise_u"] = u.numpy()
+        real_rand_like = torch.rand_like
+        PN.torch.rand_like = lambda t, *a, **k: u.clone()
+        try:
+            m2 = ProtNote(sequence_encoder=ProteInfer(activation=torch.nn.ReLU, **enc_cfg), label_encoder=None,
+                          feature_fusion=fusion, inference_descriptions_per_label=2, **head_cfg)
+            m2.load_state_dict(model.state_dict())
+            for n, p in m2.named_parameters():
+                if n.startswith("sequence_encoder"):
+                    p.requires_grad = False
+            m2.train()
+            loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+            from torch.nn.utils import clip_grad_norm_
+
+            params = [p for n, p in m2.named_parameters() if p.requires_grad and not n.startswith("sequence_encoder")]
+            opt = torch.optim.Adam(params, lr=3e-4)
+            # the train step with save_embeddings=True: the flag does not change the logits or the graph (ProtNote.py:292-302)
+            logits, emb = m2(sequence_onehots=x, sequence_lengths=lens_t, label_embeddings=lab1, label_token_counts=cnt1,
+                             save_embeddings=True)
+            emb_np("train/", emb)
+            loss = loss_fn(logits, y.float())
+            loss.backward()
+            out["train/logits"] = logits.detach().numpy().copy()
+            out["train/loss"] = np.array(float(loss.detach()), dtype=np.float32)
+            for n, p in m2.named_parameters():
+                if p.grad is not None:
+                    out["train/grad/" + n] = p.grad.detach().numpy().copy()
+            out["train/grad_norm"] = np.array(float(clip_grad_norm_(m2.parameters(), max_norm=1.0)), dtype=np.float32)
+            opt.step()
+            out.update(sd_np(m2, "train/sd_after/"))
+        finally:
+            PN.torch.rand_like = real_rand_like
+        fn = os.path.join(OUT, f"config_holes_{name}.npz")
+        np.savez_compressed(fn, **out)
+        print(os.path.basename(fn), os.path.getsize(fn) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
@@ -1062,7 +1167,7 @@ if __name__ == "__main__":
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers,
             "config0": golden_config0_full_width, "optimizer_branches": golden_optimizer_branches,
-            "disk_formats": golden_disk_formats}
+            "disk_formats": golden_disk_formats, "config_holes": golden_config_holes}
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -1,0 +1,206 @@
+"""GPU parity for two corners of the reference's config surface (VERDICT r04 missing 3-4), against vectors the REFERENCE
+generated (tests/golden/make_golden.py --config_holes) and against the CPU oracle at the real width:
+  * OUTPUT_MLP_NUM_LAYERS: 1 - get_mlp with one hidden layer (ProtNote.py:337-378).  With the layer-1 factorisation there is
+    no pair-grid GEMM: logits = fused pair-sum -> BN fold -> ReLU -> row-dot, backward = rank-1 masked reductions;
+  * save_embeddings=True in every mode (ProtNote.py:292-302,324-332; ProtNoteTrainer.py:288 passes the flag through)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import make_protnote, random_encoder_sd, random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HOLES = ["1layer_concatenation", "1layer_concatenation_diff", "1layer_concatenation_prod", "1layer_concatenation_nobn",
+         "3layer_concatenation", "3layer_concatenation_prod", "3layer_similarity"]
+
+
+def _g(golden_dir, case):
+    return np.load(os.path.join(golden_dir, f"config_holes_{case}.npz"))
+
+
+def _freeze_encoder(model):
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+
+
+def _check_embeddings(emb, g, mode, fusion):
+    if fusion == "similarity":  # nothing to save: both stay the reference's empty lists
+        assert emb["output_layer_embeddings"] == [] and emb["joint_embeddings"] == []
+        assert bool(g[mode + "joint_embeddings_is_empty_list"])
+        return
+    for k in ("output_layer_embeddings", "joint_embeddings"):
+        got = emb[k]
+        assert torch.is_tensor(got) and got.device.type == "cpu" and not got.requires_grad  # .detach().cpu(), :326-332
+        np.testing.assert_allclose(got.numpy(), g[mode + k], atol=2e-4, rtol=1e-4, err_msg=mode + k)
+
+
+@pytest.mark.parametrize("case", HOLES)
+def test_eval_logits_and_saved_embeddings_golden(golden_dir, case):
+    g = _g(golden_dir, case)
+    fusion = str(g["fusion"])
+    model, _ = make_protnote(g, DEV)
+    model.eval()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"]).to(DEV)
+    with torch.no_grad():
+        model.inference_descriptions_per_label = 2
+        ens, emb = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, save_embeddings=True)
+        ens_plain, emb_plain = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+        model.inference_descriptions_per_label = 1
+        raw, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+    np.testing.assert_allclose(raw.cpu().numpy(), g["eval/logits_raw"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(ens.cpu().numpy(), g["eval/logits_ens2"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(ens_plain.cpu().numpy(), g["eval/logits_ens2"], atol=5e-4, rtol=1e-4)
+    assert emb_plain["output_layer_embeddings"] == [] and emb_plain["joint_embeddings"] == []
+    _check_embeddings(emb, g, "eval/", fusion)
+
+
+@pytest.mark.parametrize("case", HOLES)
+def test_train_step_with_save_embeddings_golden(golden_dir, case, monkeypatch):
+    """One optimisation step in train mode WITH save_embeddings=True: logits, loss, every gradient, the post-Adam weights and
+    BatchNorm buffers, and the two saved tensors (penultimate activations under batch statistics, joint tensor)."""
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+    from tests.test_hip_train import _assert_adam_close
+
+    g = _g(golden_dir, case)
+    fusion = str(g["fusion"])
+    model, _ = make_protnote(g, DEV)
+    _freeze_encoder(model)
+    model.train()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
+    y = torch.from_numpy(g["multihots"]).to(DEV)
+    u = torch.from_numpy(g["train/noise_u"]).to(DEV)
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
+    logits, emb = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, label_token_counts=cnt,
+                        save_embeddings=True)
+    _check_embeddings(emb, g, "train/", fusion)
+    l = loss_fn(logits, y.float())
+    l.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["train/logits"], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(l.item(), float(g["train/loss"]), rtol=1e-4)
+    named = dict(model.named_parameters())
+    n_grads = 0
+    for k in g.files:
+        if k.startswith("train/grad/"):
+            name, ref = k[len("train/grad/"):], g[k]
+            np.testing.assert_allclose(named[name].grad.cpu().numpy(), ref, atol=2e-5 + 2e-4 * np.abs(ref).max(), err_msg=name)
+            n_grads += 1
+    assert n_grads >= 14
+    opt.step()
+    np.testing.assert_allclose(opt.last_grad_norm.item(), float(g["train/grad_norm"]), rtol=2e-4)
+    got = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for k in g.files:
+        if k.startswith("train/sd_after/"):
+            name = k[len("train/sd_after/"):]
+            if name.endswith(("running_mean", "running_var", "num_batches_tracked")) or name.startswith("sequence_encoder"):
+                np.testing.assert_allclose(got[name], g[k], atol=3e-5, rtol=2e-4, err_msg=name)
+            else:
+                _assert_adam_close(got[name], g[k], name)
+
+
+def _wide_sd(gen, n_out, in_mult=2):
+    ecfg = dict(num_labels=8, input_channels=20, output_channels=1100, kernel_size=9, dilation_base=3, num_resnet_blocks=5,
+                bottleneck_factor=0.5)
+    sd = {"sequence_encoder." + k: v for k, v in random_encoder_sd(ecfg, gen).items()}
+    sd.update(random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, n_out, in_mult=in_mult))
+    return ecfg, sd
+
+
+def _wide_model(ecfg, sd, fusion, n_out):
+    from protnote_amd.models.ProtNote import ProtNote
+    from tests.helpers import make_encoder
+
+    enc = make_encoder(sd, "sequence_encoder.", ecfg, "cpu")
+    model = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024, sequence_encoder=enc,
+                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=n_out, outout_mlp_add_batchnorm=True,
+                     projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
+                     label_embedding_noising_alpha=0.0, feature_fusion=fusion)
+    model.load_state_dict(sd)
+    _freeze_encoder(model)
+    return model.to(DEV)
+
+
+@pytest.mark.parametrize("fusion,B,NL", [("concatenation", 37, 150), ("concatenation", 300, 70), ("concatenation_diff", 64, 129),
+                                         ("concatenation_prod", 20, 90)])
+def test_one_hidden_layer_real_width_vs_oracle(fusion, B, NL):
+    """The one-hidden-layer head at the real width (h = 3072, d = 1024) on ragged sizes (B not a multiple of the 64-protein
+    tile, B > 256 = the two-pass reductions, N_L not a multiple of 64): eval logits, train logits and every head gradient
+    against the CPU oracle's autograd on precomputed sequence embeddings."""
+    gen = torch.Generator().manual_seed(B * 1000 + NL)
+    ecfg, sd = _wide_sd(gen, 1, in_mult=2 if fusion == "concatenation" else 3)
+    model = _wide_model(ecfg, sd, fusion, 1)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.1).to(torch.int64)
+    model.eval()
+    with torch.no_grad():
+        got, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    ref = O.protnote_forward(sd, None, None, lab, fusion=fusion, sequence_embeddings=P_f)
+    scale = ref.abs().max().item()
+    assert (got.cpu() - ref).abs().max().item() < 1e-4 * max(scale, 1.0), (got.cpu() - ref).abs().max().item()
+
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    model.train()
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV).float())
+    loss.backward()
+    names = O.trainable_names(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    rl = O.protnote_forward(work, None, None, lab, fusion=fusion, training=True, sequence_embeddings=P_f)
+    rloss = O.bce_loss(rl, y.float())
+    rg = torch.autograd.grad(rloss, [leaves[k] for k in names], allow_unused=True)
+    assert (logits.detach().cpu() - rl.detach()).abs().max().item() < 2e-4 * max(rl.abs().max().item(), 1.0)
+    assert abs(loss.item() - float(rloss)) < 1e-5 * max(abs(float(rloss)), 1.0)
+    named = dict(model.named_parameters())
+    checked = 0
+    for k, gr in zip(names, rg):
+        if gr is None:
+            continue
+        got_g = named[k].grad
+        assert got_g is not None, k
+        err = (got_g.cpu() - gr).abs().max().item()
+        assert err <= 1e-6 + 5e-4 * gr.abs().max().item(), (k, err, gr.abs().max().item())
+        checked += 1
+    assert checked >= 14
+
+
+def test_save_embeddings_does_not_change_the_train_step(golden_dir):
+    """The flag only reads the store back: logits and gradients with and without it are bit-identical, in train mode and in
+    eval mode with autograd on (BatchNorm on its running statistics)."""
+    g = _g(golden_dir, "3layer_concatenation")
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    for mode in ("train", "eval"):
+        outs = []
+        for flag in (False, True):
+            model, _ = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
+            _freeze_encoder(model)
+            model.train(mode == "train")
+            model.inference_descriptions_per_label = 1
+            logits, emb = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, save_embeddings=flag)
+            logits.sum().backward()
+            grads = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+            outs.append((logits.detach().clone(), grads, emb))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert len(outs[0][1]) == len(outs[1][1]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+        assert outs[0][2]["output_layer_embeddings"] == [] and tuple(outs[1][2]["output_layer_embeddings"].shape) == (
+            x.shape[0] * lab.shape[0], 48)
+        if mode == "eval":  # eval-mode statistics: the saved activations equal the fused inference path's
+            with torch.no_grad():
+                _, e2 = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, save_embeddings=True)
+            np.testing.assert_allclose(outs[1][2]["output_layer_embeddings"].numpy(), e2["output_layer_embeddings"].numpy(),
+                                       atol=1e-5, rtol=1e-5)

@@ -361,3 +361,63 @@ def test_optimizer_branches_vs_reference_trainer(golden_dir, case):
             np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-4, err_msg=name)
         else:
             _adam_close(got, ref, name, lr, n)
+
+
+HOLES = ["1layer_concatenation", "1layer_concatenation_diff", "1layer_concatenation_prod", "1layer_concatenation_nobn",
+         "3layer_concatenation", "3layer_concatenation_prod", "3layer_similarity"]
+
+
+@pytest.mark.parametrize("case", HOLES)
+def test_config_holes_one_hidden_layer_and_save_embeddings(golden_dir, case):
+    """OUTPUT_MLP_NUM_LAYERS: 1 (get_mlp with ONE hidden layer, ProtNote.py:337-378) and save_embeddings=True in eval
+    AND train mode (ProtNote.py:292-302,324-332), generated by the reference itself (make_golden.py --config_holes)."""
+    g = _load(golden_dir, f"config_holes_{case}.npz")
+    fusion = str(g["fusion"])
+    nl = int(g["head_cfg_output_mlp_num_layers"])
+    sd = O.as_torch_sd(g, "sd/")
+    if fusion != "similarity":
+        n_lin = len(O._linear_indices(sd, "output_layer."))
+        assert n_lin == nl + 1  # nl hidden layers + the output neuron
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab = torch.from_numpy(g["label_embeddings"])
+    T = float(g["head_cfg_temperature"])
+    aux = {}
+    raw = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=T, aux=aux)
+    np.testing.assert_allclose(raw.numpy(), g["eval/logits_raw"], atol=1e-4, rtol=1e-5)
+    ens = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=T, descriptions_per_label=2)
+    np.testing.assert_allclose(ens.numpy(), g["eval/logits_ens2"], atol=1e-4, rtol=1e-5)
+    for mode in ("eval/", "train/"):
+        empty = fusion == "similarity"
+        assert bool(g[mode + "output_layer_embeddings_is_empty_list"]) == empty
+        assert bool(g[mode + "joint_embeddings_is_empty_list"]) == empty
+    if fusion != "similarity":
+        np.testing.assert_allclose(aux["joint_embeddings"].numpy(), g["eval/joint_embeddings"], atol=5e-5, rtol=1e-5)
+        np.testing.assert_allclose(aux["output_layer_embeddings"].numpy(), g["eval/output_layer_embeddings"], atol=1e-4,
+                                   rtol=1e-5)
+    lab1 = lab[0::2].contiguous()
+    cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous()
+    y = torch.from_numpy(g["multihots"])
+    u = torch.from_numpy(g["train/noise_u"])
+    taux = {}
+    logits, l, grads, gn = O.train_step(sd, x, lens, lab1, y, loss="BCE", fusion=fusion, noise_u=u, label_token_counts=cnt,
+                                        noise_alpha=float(g["head_cfg_label_embedding_noising_alpha"]), temperature=T,
+                                        aux=taux)
+    np.testing.assert_allclose(logits.numpy(), g["train/logits"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(float(l), float(g["train/loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(gn), float(g["train/grad_norm"]), rtol=1e-4)
+    if fusion != "similarity":
+        np.testing.assert_allclose(taux["joint_embeddings"].detach().numpy(), g["train/joint_embeddings"], atol=5e-5,
+                                   rtol=1e-5)
+        np.testing.assert_allclose(taux["output_layer_embeddings"].detach().numpy(), g["train/output_layer_embeddings"],
+                                   atol=1e-4, rtol=1e-5)
+    n_grads = 0
+    for k in g.files:
+        if k.startswith("train/grad/"):
+            name, ref = k[len("train/grad/"):], g[k]
+            np.testing.assert_allclose(grads[name].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), err_msg=name)
+            n_grads += 1
+    assert n_grads >= 14
+    for k in g.files:
+        if k.startswith("train/sd_after/"):
+            name = k[len("train/sd_after/"):]
+            np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
