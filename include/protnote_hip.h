@@ -71,6 +71,9 @@ typedef struct pn_encoder {
   /* pn_encoder_fwd_train / pn_encoder_bwd only: != 0 = BatchNorm in EVAL mode inside a differentiable forward (see
    * pn_mlp.bn_use_running); pn_encoder_fwd takes its mode from the `training` argument */
   int bn_use_running;
+  /* arithmetic of this call's big GEMMs: 0 = the library default (pn_set_math_mode), 1 = f32 MFMA, 2 = bf16x3.  Per call
+   * and per calling thread: two host threads may drive two models in different modes at the same time. */
+  int math_mode;
 } pn_encoder;
 
 /* torch Conv1d weight [Cout][Cin][k] -> packed [Cout][k][ld4(Cin)] (zero pad lanes). */
@@ -104,6 +107,7 @@ typedef struct pn_mlp {
    * ProtNote.py:243-309): normalise with the RUNNING statistics, update nothing; the backward treats them as
    * constants (dz = relu' * g * gamma/sigma; dgamma / dbeta as usual). */
   int bn_use_running;
+  int math_mode; /* as pn_encoder.math_mode */
 } pn_mlp;
 
 size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows);
@@ -131,6 +135,10 @@ typedef struct pn_pairhead {
   float dropout_p;
   unsigned dropout_seed;
   int bn_use_running; /* as in pn_mlp: eval-mode BatchNorm inside pn_pairhead_fwd_train / pn_pairhead_bwd */
+  int math_mode;      /* as pn_encoder.math_mode */
+  /* pn_pairhead_bwd: arithmetic of the hidden layers' backward pair-grid GEMMs: 0 = the library default
+   * (pn_set_backward_math), 1 = as the forward, 2 = one bf16 product with f32 accumulation (AMP class) */
+  int backward_math;
 } pn_pairhead;
 
 size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);

@@ -29,7 +29,7 @@ class pn_res_block(C.Structure):
 class pn_encoder(C.Structure):
     _fields_ = [("Cin", C.c_int), ("C", C.c_int), ("Cb", C.c_int), ("ksize", C.c_int), ("nblocks", C.c_int),
                 ("dil_base", C.c_int), ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p),
-                ("blk", pn_res_block * PN_MAX_BLOCKS), ("bn_use_running", C.c_int)]
+                ("blk", pn_res_block * PN_MAX_BLOCKS), ("bn_use_running", C.c_int), ("math_mode", C.c_int)]
 
 
 class pn_mlp(C.Structure):
@@ -37,7 +37,7 @@ class pn_mlp(C.Structure):
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint), ("dropout_stream", C.c_int),
-                ("bn_use_running", C.c_int)]
+                ("bn_use_running", C.c_int), ("math_mode", C.c_int)]
 
 
 class pn_pairhead(C.Structure):
@@ -45,7 +45,7 @@ class pn_pairhead(C.Structure):
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint),
-                ("bn_use_running", C.c_int)]
+                ("bn_use_running", C.c_int), ("math_mode", C.c_int), ("backward_math", C.c_int)]
 
 
 class pn_res_block_grads(C.Structure):
@@ -246,6 +246,19 @@ def get_math_mode() -> str:
     return "bf16x3" if lib().pn_get_math_mode() == 1 else "f32"
 
 
+def math_field(mode=None) -> int:
+    """Value of a descriptor's `math_mode` field (include/protnote_hip.h: 1 = f32, 2 = bf16x3).  The mode travels WITH the
+    call: `mode` None reads the process default (set_math_mode / PN_MATH_MODE) now, at descriptor-build time, so the C side
+    never consults its global for a call made through this binding - two host threads driving two models can run different
+    modes (set `model.math_mode`), and flipping the default on one thread cannot change a call another thread is making."""
+    if mode is None:
+        return 1 + int(lib().pn_get_math_mode())
+    key = str(mode).lower()
+    if key not in _MATH_MODES:
+        raise ValueError(f"math mode must be 'f32' or 'bf16x3', got {mode!r}")
+    return 1 + _MATH_MODES[key]
+
+
 _BWD_MODES = {"same": 0, "0": 0, "bf16": 1, "1": 1}
 
 
@@ -261,6 +274,16 @@ def set_backward_math(mode) -> None:
 
 def get_backward_math() -> str:
     return "bf16" if lib().pn_get_backward_math() == 1 else "same"
+
+
+def backward_math_field(mode=None) -> int:
+    """Value of pn_pairhead.backward_math (1 = as the forward, 2 = bf16); None = the process default, read now."""
+    if mode is None:
+        return 1 + int(lib().pn_get_backward_math())
+    key = str(mode).lower()
+    if key not in _BWD_MODES:
+        raise ValueError(f"backward math must be 'same' or 'bf16', got {mode!r}")
+    return 1 + _BWD_MODES[key]
 
 
 def check(rc: int):

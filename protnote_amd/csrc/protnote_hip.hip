@@ -79,6 +79,7 @@ struct Bump {
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing of the GEMM kernels (hipEvents on the launch stream; bench.py roofline)
 // ------------------------------------------------------------------------------------------------
+#include <atomic>
 #include <mutex>
 #include <vector>
 struct ProfRec {
@@ -307,7 +308,7 @@ template <int AK, int EK, int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool
 static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
   using Cfg = GemmCfg<WAVES_M, WAVES_N, WM, WN, BK>;
   auto kern = gemm_nt_kernel<AK, EK, WAVES_M, WAVES_N, WM, WN, BK, DROP>;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -344,19 +345,37 @@ static int launch_gemm_cfg(const GemmParams& p, hipStream_t st) {
 }
 
 // Arithmetic of the pair-grid GEMMs: 0 = exact f32 MFMA (default), 1 = bf16x3 split (gemm_bf16x3.hpp).
-static int g_math_mode = 0;
+// Per CALL: every descriptor (pn_encoder / pn_mlp / pn_pairhead) carries `math_mode` (and pn_pairhead `backward_math`);
+// the entry point that receives it installs the value for the duration of the call on the CALLING THREAD (MathScope), and
+// the launchers read cur_math().  Two host threads driving two models on two streams can therefore run different modes.
+// pn_set_math_mode / pn_set_backward_math only set the process DEFAULT that a descriptor field of 0 falls back to.
+static std::atomic<int> g_math_mode{0};
 extern "C" int pn_set_math_mode(int mode) {
   if (mode != 0 && mode != 1) return fail("pn_set_math_mode: 0 (f32) or 1 (bf16x3)");
   g_math_mode = mode;
   return 0;
 }
 extern "C" int pn_get_math_mode(void) { return g_math_mode; }
+static thread_local int tl_math = -1;  // -1: no descriptor in scope -> the process default
+static inline int cur_math() { return tl_math >= 0 ? tl_math : g_math_mode.load(std::memory_order_relaxed); }
+struct MathScope {  // descriptor field: 0 = process default, 1 = f32, 2 = bf16x3
+  int prev;
+  explicit MathScope(int field) : prev(tl_math) {
+    if (field == 1 || field == 2) tl_math = field - 1;
+  }
+  ~MathScope() { tl_math = prev; }
+};
+static int math_field_check(int field, const char* what) {
+  if (field < 0 || field > 2) return fail("%s: math_mode %d (0 = library default, 1 = f32, 2 = bf16x3)", what, field);
+  return 0;
+}
 
 // Arithmetic of the BACKWARD pair-grid GEMMs of the hidden layers (dW_l = dz_l^T h_{l-1} and dh_{l-1} = dz_l W_l, l >= 1):
 // 0 = the forward's mode (default), 1 = ONE product of the bf16-rounded operands with f32 accumulation (the NP = 1 kernels
 // of gemm_bf16x3.hpp) - the arithmetic class of the reference's autocast backward (ProtNoteTrainer.py:728-738).  The
 // forward, every reduction, the BatchNorm backward and the row MLPs keep the forward's mode: logits are bit-identical.
-static int g_bwd_math = 0;
+// Per call through pn_pairhead.backward_math (0 = this process default, 1 = as the forward, 2 = bf16).
+static std::atomic<int> g_bwd_math{0};
 extern "C" int pn_set_backward_math(int mode) {
   if (mode != 0 && mode != 1) return fail("pn_set_backward_math: 0 (as the forward) or 1 (bf16, one product)");
   g_bwd_math = mode;
@@ -378,7 +397,7 @@ struct BwdBf16Scope {
 
 // bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; pn_set_b3_dma(0) keeps the register
 // path (the bit-identity test compares the two)
-static int g_b3_dma = 1;
+static std::atomic<int> g_b3_dma{1};
 static bool use_b3_dma() { return g_b3_dma == 1; }
 extern "C" int pn_set_b3_dma(int on) {
   g_b3_dma = on ? 1 : 0;
@@ -394,7 +413,7 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
   }
   auto kern = gemm_nt_bf16x3_kernel<AK, EK, 4, WAVES_N, 2, WN, GEN, BDMA, NP>;
   constexpr int LDS_BYTES = BDMA ? 2 * (256 * 36 + 2 * 256 * 16) * (int)sizeof(float) : Cfg::LDS_BYTES;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -435,14 +454,14 @@ static int launch_gemm_bf16x3(const GemmParams& p, hipStream_t st) {
 // dh = dz W of the bf16 backward on the deep-pipelined single-product kernel (gemm_bf16.hpp); preconditions checked by
 // launch_gemm.  pn_set_bwd_deep(0) keeps the NP = 1 instantiation of the bf16x3 kernel (same products in the same order:
 // the bit-identity test compares the two)
-static int g_bwd_deep = 7;  // bit 0: the deep-pipelined dh kernel, bit 1: the transpose-read dW kernel, bit 2: dz stored as bf16
+static std::atomic<int> g_bwd_deep{7};  // bit 0: the deep-pipelined dh kernel, bit 1: the transpose-read dW kernel, bit 2: dz stored as bf16
 extern "C" int pn_set_bwd_deep(int mask) {
   g_bwd_deep = mask & 7;
   return 0;
 }
 static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
   auto kern = gemm_nt_bf16_kernel<E_STORE>;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -475,7 +494,7 @@ static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
 // dh = dz W with dz stored as bf16 (bwd_bf16_dz.hpp): both operands by LDS-DMA
 static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
   auto kern = gemm_nt_bf16dma_kernel<E_STORE>;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -510,20 +529,20 @@ static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
 // (the bit-identity tests compare the two)
 // float64 accumulation in the forward convolutions of a trainable encoder (gemm_conv_f64.hpp): on by default; the switch
 // exists for the A/B measurement (tools/encoder_grad_error.py) and the test that shows what it buys
-static int g_enc_f64 = 1;
+static std::atomic<int> g_enc_f64{1};
 extern "C" int pn_set_encoder_f64(int on) {
   g_enc_f64 = on ? 1 : 0;
   return 0;
 }
 
 // conv1 on one-hot input as a gather-sum (k_conv1_gather); 0 = always the general convolution (A/B, bit-identity test)
-static int g_conv1_gather = 1;
+static std::atomic<int> g_conv1_gather{1};
 extern "C" int pn_set_conv1_gather(int on) {
   g_conv1_gather = on ? 1 : 0;
   return 0;
 }
 
-static int g_f32_dma = 1;
+static std::atomic<int> g_f32_dma{1};
 static bool use_f32_dma() { return g_f32_dma == 1; }
 
 extern "C" int pn_set_f32_dma(int on) {
@@ -537,7 +556,7 @@ static const int g_dma_min_rows = 16384;
 template <int AK, int EK, bool DROP = false>
 static int launch_gemm_dma(const GemmParams& p, hipStream_t st) {
   auto kern = gemm_nt_dma_kernel<AK, EK, DROP>;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -571,7 +590,7 @@ static int launch_conv_dma(const GemmParams& p, int Lp, int ktrue, hipStream_t s
   constexpr int WN = 3;
   auto kern = gemm_conv_dma_kernel<WN>;
   constexpr int LDS = conv_dma_lds_bytes<WN>();
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -640,7 +659,7 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
       }
     }
   }
-  if (g_math_mode == 1 && PN_BIG) {  // opt-in bf16x3 arithmetic (gemm_bf16x3.hpp)
+  if (cur_math() == 1 && PN_BIG) {  // opt-in bf16x3 arithmetic (gemm_bf16x3.hpp)
     if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
       // pair-grid shapes: no masks needed
       if (variant == 0 && p.M >= 65536 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N)
@@ -1068,7 +1087,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
     p.col_sum = csum; p.col_sumsq = csq;
     if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
     p.run_if = conv_run_if;
-    if (sv != nullptr && s != nullptr && g_math_mode == 0 && g_enc_f64 && w.H != nullptr) {
+    if (sv != nullptr && s != nullptr && cur_math() == 0 && g_enc_f64 && w.H != nullptr) {
       // trainable encoder (pn_encoder_fwd_train): the two wide convolutions of a block accumulate in float64 so that
       // the stored pre-activations - and with them the ReLU masks the backward multiplies by - are the correctly
       // rounded ones (gemm_conv_f64.hpp).  conv1 (K = 9 x 20) keeps the f32 kernel.
@@ -1096,7 +1115,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       return 0;
     }
     const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
-    if (g_math_mode == 0 && use_f32_dma() && s != nullptr && w.H != nullptr && conv_dma_shape(ld_in, ld_out, P)) {
+    if (cur_math() == 0 && use_f32_dma() && s != nullptr && w.H != nullptr && conv_dma_shape(ld_in, ld_out, P)) {
       // f32 default: stage relu(bn(in)) once (masked, K padded to 32, guard rows between sequences), re-lay the weights,
       // then the all-LDS-DMA kernel - bit-identical to the register-staged tap gather below
       const int Kpad = round_up(ld_in, 32), G = (ntap / 2) * dil, Lp = L + G, Cpad = round_up(Cout, 192);
@@ -1129,7 +1148,7 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       const int BM = big ? 256 : 128;  // row-tile height of the general kernel's statistics partials
       const int tiles = P >= 65536 ? 4 : 1;
       const size_t lds = conv1_gather_lds(e, BM);
-      static bool attr_done[64] = {false};
+      static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
       int dev = 0;
       HIP_OK(hipGetDevice(&dev));
       if (dev < 64 && !attr_done[dev]) {
@@ -1207,6 +1226,8 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
 
 extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
                               float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(e->math_mode, "pn_encoder_fwd"));
+  MathScope math_scope(e->math_mode);
   if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
   if (B <= 0 || L <= 0) return fail("encoder: empty batch");
   Bump bp(ws, ws_bytes);
@@ -1219,6 +1240,8 @@ extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const i
 extern "C" int pn_encoder_fwd_train(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
                                     float* emb, int ld_emb, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
                                     void* stream) {
+  PN_OK(math_field_check(e->math_mode, "pn_encoder_fwd_train"));
+  MathScope math_scope(e->math_mode);
   if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
   if (B <= 0 || L <= 0) return fail("encoder: empty batch");
   Bump bp(ws, ws_bytes), bs(save, save_bytes);
@@ -1244,6 +1267,8 @@ extern "C" size_t pn_mlp_rows_ws_bytes(const pn_mlp* m, int rows) {
 
 extern "C" int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* ws,
                                     size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(m->math_mode, "pn_mlp_rows_fwd_eval"));
+  MathScope math_scope(m->math_mode);
   hipStream_t st = (hipStream_t)stream;
   if (m->nlayers < 1 || m->nlayers > PN_MAX_LAYERS) return fail("mlp: bad layer count %d", m->nlayers);
   for (int i = 0; i <= m->nlayers; ++i)
@@ -1342,6 +1367,8 @@ extern "C" size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL
 extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
                                     float* logits_pairs, int label_chunk, void* ws, size_t ws_bytes,
                                     void* stream) {
+  PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_eval"));
+  MathScope math_scope(hd->math_mode);
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h, d = hd->d;
   if (hd->nlayers < 1 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 1..%d)", hd->nlayers, PN_MAX_LAYERS);
@@ -1579,7 +1606,7 @@ static int launch_tn_cfg(TnParams p, float* dst, long ldd, float* part, size_t p
   auto kern = gemm_tn_kernel<TA, TB, BIG, ADMA, DROP>;
   constexpr int TILE = BIG ? 256 : 128;
   constexpr int LDS = BIG ? TN_LDS_BYTES_BIG : TN_LDS_BYTES;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -1633,7 +1660,7 @@ static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t 
   // pacing only for the kind whose second operand streams from HBM too (the pair-sum kind's tables are L2-resident: 0.22 TB)
   constexpr bool SYNC = TB == TB_AFFINE_RELU;
   auto kern = gemm_tn_fast_kernel<TB, SYNC>;
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -1708,7 +1735,7 @@ static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_
   if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB, ABF16, SYNC>;
   else kern = gemm_tn_bf16x3_kernel<TB, NP>;
   constexpr int LDS = TR ? TN_BF16TR_LDS_BYTES : 2 * 512 * 36 * (int)sizeof(float);
-  static bool attr_done[64] = {false};
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
@@ -1781,7 +1808,7 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
     }
   }
   if constexpr (TA == TA_PLAIN && (TB == TB_PLAIN || TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU)) {
-    if (g_math_mode == 1 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
+    if (cur_math() == 1 && PN_BIG && p.M % 256 == 0 && p.N % 256 == 0 && p.R >= 65536 &&
         (TB != TB_PAIRSUM_RELU || p.pairB % 8 == 0))
       return launch_tn_bf16x3<TB>(p, dst, ldd, part, part_cap_floats, st);
   }
@@ -1923,6 +1950,8 @@ static int mlp_check(const pn_mlp* m, int ldx) {
 
 extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, int rows, float* y, void* save,
                                      size_t save_bytes, void* ws, size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(m->math_mode, "pn_mlp_rows_fwd_train"));
+  MathScope math_scope(m->math_mode);
   hipStream_t st = (hipStream_t)stream;
   PN_OK(mlp_check(m, ldx));
   BnMode bn_mode(m->bn_use_running != 0);
@@ -1975,7 +2004,7 @@ extern "C" int pn_mlp_rows_fwd_train(const pn_mlp* m, const float* x, int ldx, i
 
 // pn_set_mlp_materialize(0): the row-MLP backward regenerates dY in the operand loaders for every row count
 // (the path the small-size oracle tests pin) - an A/B switch for tests and measurements
-static int g_mlp_mat = 1;
+static std::atomic<int> g_mlp_mat{1};
 extern "C" int pn_set_mlp_materialize(int on) {
   g_mlp_mat = on ? 1 : 0;
   return 0;
@@ -1984,6 +2013,8 @@ extern "C" int pn_set_mlp_materialize(int on) {
 extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int rows, const float* dy,
                                const pn_mlp_grads* gr, float* dx, void* save, size_t save_bytes, void* ws,
                                size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(m->math_mode, "pn_mlp_rows_bwd"));
+  MathScope math_scope(m->math_mode);
   hipStream_t st = (hipStream_t)stream;
   PN_OK(mlp_check(m, ldx));
   BnMode bn_mode(m->bn_use_running != 0);
@@ -2029,7 +2060,7 @@ extern "C" int pn_mlp_rows_bwd(const pn_mlp* m, const float* x, int ldx, int row
     // Big row counts (W_l over the label table): dY_l is materialised once, in place over the incoming gradient (our
     // scratch), and both GEMMs take it as a plain operand - the 256-tile LDS-DMA NT kernel and the big TN tiles - instead of
     // regenerating it in the operand loaders of the 128-tile engine (0.70 of peak).  Same dz arithmetic (k_dz_apply).
-    const bool mat = !last && g_mlp_mat && rows >= g_dma_min_rows && g_math_mode == 0 && use_f32_dma();
+    const bool mat = !last && g_mlp_mat && rows >= g_dma_min_rows && cur_math() == 0 && use_f32_dma();
     if (mat) {
       DzParams dp;
       memset(&dp, 0, sizeof(dp));
@@ -2214,6 +2245,8 @@ __global__ void k_diff_weight_grad(const float* __restrict__ dweff, float* __res
 extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
                                      float* logits_pairs, int label_chunk, void* save, size_t save_bytes, void* ws,
                                      size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_train"));
+  MathScope math_scope(hd->math_mode);
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
   BnMode bn_mode(hd->bn_use_running != 0);
@@ -2339,6 +2372,8 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
                                const float* dl_pairs, const pn_pairhead_grads* gr, float* dP_e, float* dL_e,
                                int label_chunk, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
                                void* stream) {
+  PN_OK(math_field_check(hd->math_mode, "pn_pairhead_bwd"));
+  MathScope math_scope(hd->math_mode);
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
   BnMode bn_mode(hd->bn_use_running != 0);
@@ -2367,7 +2402,10 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
   const long stats_rows = PAIR_STATS_ROWS;
   // pn_set_backward_math(1): the two pair-grid GEMMs of every hidden layer below run on one bf16 product (the dropped
   // layers keep the f32 kernels that carry the mask code)
-  BwdBf16Scope bwd_scope(g_bwd_math == 1 && hd->dropout_p == 0.f);
+  if (hd->backward_math < 0 || hd->backward_math > 2)
+    return fail("pairhead bwd: backward_math %d (0 = library default, 1 = as the forward, 2 = bf16)", hd->backward_math);
+  const int bwd_math = hd->backward_math == 0 ? g_bwd_math.load(std::memory_order_relaxed) : hd->backward_math - 1;
+  BwdBf16Scope bwd_scope(bwd_math == 1 && hd->dropout_p == 0.f);
   for (int l = n - 1; l >= 1; --l) {
     const bool top = (l == n - 1);
     float* z = sv.zbuf[l] + (size_t)S * h;
@@ -2898,6 +2936,8 @@ extern "C" size_t pn_pairhead_hidden_ws_bytes(const pn_pairhead* hd, int B, int 
 extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P_e, const float* L_e, int B, int NL,
                                            float* logits_pairs, float* hidden_pairs, void* ws, size_t ws_bytes,
                                            void* stream) {
+  PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_eval_hidden"));
+  MathScope math_scope(hd->math_mode);
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h;
   const long R = (long)B * NL;
@@ -3176,6 +3216,8 @@ extern "C" size_t pn_encoder_bwd_ws_bytes(const pn_encoder* enc, int B, int L) {
 extern "C" int pn_encoder_bwd(const pn_encoder* e, int B, int L, const float* demb, int ld_demb,
                               const pn_encoder_grads* gr, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
                               void* stream) {
+  PN_OK(math_field_check(e->math_mode, "pn_encoder_bwd"));
+  MathScope math_scope(e->math_mode);
   hipStream_t st = (hipStream_t)stream;
   if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder bwd: too many blocks");
   BnMode bn_mode(e->bn_use_running != 0);

@@ -97,6 +97,23 @@ def input_dropout_p(seq) -> float:
 
 class ProtNote(nn.Module):
     _warned_eval_stored = False  # the eval-mode + autograd path warns once per process (see forward)
+    # Arithmetic of THIS model's big GEMMs: None = the process default at call time (protnote_amd.set_math_mode /
+    # set_backward_math), or "f32" | "bf16x3" and "same" | "bf16".  Carried in every descriptor this model builds
+    # (pn_*.math_mode / pn_pairhead.backward_math), so models driven from different host threads can differ.
+    _math_mode = None
+    backward_math = None
+
+    @property
+    def math_mode(self):
+        return self._math_mode
+
+    @math_mode.setter
+    def math_mode(self, mode):
+        L.math_field(mode) if mode is not None else None  # validates
+        self.__dict__["_math_mode"] = mode
+        enc = self.__dict__.get("_modules", {}).get("sequence_encoder")
+        if enc is not None:
+            enc.math_mode = mode
 
     def __init__(self, protein_embedding_dim=1100, label_embedding_dim=1024, label_embedding_pooling_method="mean",
                  inference_descriptions_per_label=1, latent_dim=1024, label_encoder=None, sequence_encoder=None,
@@ -171,6 +188,7 @@ class ProtNote(nn.Module):
             if bn is not None:
                 eps, mom = bn.eps, bn.momentum
         m.bn_eps, m.bn_momentum = eps, mom
+        m.math_mode = L.math_field(self.math_mode)
         if drop_seed is not None and self.mlp_dropout > 0:
             m.dropout_p, m.dropout_seed, m.dropout_stream = self.mlp_dropout, int(drop_seed), int(drop_stream)
         return m, layers
@@ -196,6 +214,8 @@ class ProtNote(nn.Module):
         hd.w_out = out.weight.data_ptr()
         hd.b_out = out.bias.data_ptr()
         hd.bn_eps, hd.bn_momentum = eps, mom
+        hd.math_mode = L.math_field(self.math_mode)
+        hd.backward_math = L.backward_math_field(self.backward_math)
         if drop_seed is not None and self.mlp_dropout > 0:
             hd.dropout_p, hd.dropout_seed = self.mlp_dropout, int(drop_seed)
         return hd, layers
@@ -226,7 +246,7 @@ class ProtNote(nn.Module):
         if any(t.is_inference() for t in ts):  # no version counters (model built under torch.inference_mode()): no cache
             return None
         vs = tuple((t.data_ptr(), t._version) for t in ts)
-        return (weights_generation(), L.get_math_mode(), vs)
+        return (weights_generation(), L.math_field(self.math_mode), vs)
 
     def _label_projection_eval(self, label_embeddings):
         """L_e = W_l(L_f) in eval mode depends only on the label table and W_l (reference ProtNote.py:192-196,270-271

@@ -90,6 +90,8 @@ class ProteInfer(torch.nn.Module):
         enc = L.pn_encoder()
         enc.Cin, enc.C, enc.Cb = d["Cin"], d["C"], d["Cb"]
         enc.ksize, enc.nblocks, enc.dil_base = d["ksize"], d["nblocks"], d["dil_base"]
+        # per-call arithmetic (None = the process default now); ProtNote.math_mode's setter writes it through
+        enc.math_mode = L.math_field(getattr(self, "math_mode", None))
         keep = [self._pack("conv1", self.conv1)]
         enc.conv1_w = keep[-1].data_ptr()
         enc.conv1_b = self.conv1.bias.data_ptr()
@@ -185,6 +187,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         B, _, Lmax = x.shape
         enc, keep = enc_mod._descriptor()
         ctx.bn_running = enc.bn_use_running = 0 if enc_mod.training else 1
+        ctx.math_field = enc.math_mode  # the backward runs in the arithmetic its forward ran in
         lib = L.lib()
         save = torch.empty(lib.pn_encoder_train_save_bytes(C.byref(enc), B, Lmax), dtype=torch.uint8, device=x.device)
         ws = L.workspace(lib.pn_encoder_ws_bytes(C.byref(enc), B, Lmax), x.device, "enc")
@@ -202,6 +205,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         enc_mod, (B, Lmax) = ctx.enc_mod, ctx.shape
         enc, keep = enc_mod._descriptor()
         enc.bn_use_running = ctx.bn_running
+        enc.math_mode = ctx.math_field
         lib = L.lib()
         demb = demb.contiguous().float()
         grads = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in ctx.params]

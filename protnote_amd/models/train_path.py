@@ -158,6 +158,10 @@ class _HeadsTrainFn(torch.autograd.Function):
         mp, lp = model._mlp_desc(model.W_p, seed, 100)
         ml, ll = model._mlp_desc(model.W_l, seed, 200)
         mp.bn_use_running = ml.bn_use_running = bn_running
+        # the arithmetic of this step travels with it: the backward re-builds its descriptors with the forward's modes even
+        # if the model's (or the process default's) mode is changed in between
+        ctx.math_field = mp.math_mode
+        ctx.bwd_field = L.backward_math_field(model.backward_math)
         ctx.P_f, ctx.L_f = P_f, L_f
 
         def mlp_fwd(m, x, tag):
@@ -252,6 +256,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         # ---- pair head ----
         hd, hl = model._pair_desc(ctx.drop_seed)
         hd.bn_use_running = ctx.bn_running
+        hd.math_mode, hd.backward_math = ctx.math_field, ctx.bwd_field
         hidden, out = hl[:-1], hl[-1][0]
         gr = L.pn_pairhead_grads()
         for i, (lin, bn) in enumerate(hidden):
@@ -279,6 +284,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         def mlp_bwd(seq, x, dy, tag, dx=None):
             m, layers = model._mlp_desc(seq, ctx.drop_seed, 100 if tag == "W_p" else 200)
             m.bn_use_running = ctx.bn_running
+            m.math_mode = ctx.math_field
             g = L.pn_mlp_grads()
             for i, (lin, bn) in enumerate(layers):
                 g.dw[i] = gbuf(lin.weight)

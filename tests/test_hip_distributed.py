@@ -232,8 +232,13 @@ def test_bench_self_launches_its_ranks():
                           "--zero-shot-seqs", "8"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    j = json.loads(lines[0])
+    # rank 0 prints the full record first ({"bench_detail": ...}) and the compact headline (what the driver parses) LAST
+    assert len(lines) == 2 and len(lines[-1]) < 4096, out.stdout[-2000:]
+    head = json.loads(lines[-1])
+    j = json.loads(lines[0])["bench_detail"]
+    assert head["n_gpus"] == 2 and head["config"]["parallelism"] == "dp2" and head["value"] == pytest.approx(j["value"], rel=1e-5)
+    assert head["comm"]["rccl_ranks"] == 2 and head["comm"]["replicas_in_sync"] is True
+    assert "roofline" in head and "kernels" not in head
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 32
     assert j["comm"]["rccl_ranks"] == 2 and j["comm"]["backend"] == ("nccl" if two else "gloo")
     c = j["comm"]["collectives_rank0"]
