@@ -1,6 +1,7 @@
 """GPU parity tests of the training path (train-mode BatchNorm over the pair grid, backward, fused loss,
 clip + Adam) against the reference-generated golden vectors and the CPU oracle."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1574,7 +1575,27 @@ def test_two_models_on_two_streams_concurrently_equal_serial():
     take one train step each (forward, BCE, backward, clip + Adam) at the same time - two host threads, two streams of one
     device, grids large enough for every big kernel incl. the paced weight-gradient kernel whose arrival counters used to
     be one static buffer per device - and end with exactly the bits of the same two steps run one after the other."""
+    _two_models_two_streams(modes=(None, None))
+
+
+def test_two_models_on_two_streams_in_different_math_modes():
+    """The arithmetic travels with the call (pn_*.math_mode / pn_pairhead.backward_math, set from `model.math_mode` /
+    `model.backward_math`), not with the process: thread 0 trains a model in exact f32, thread 1 another one on the bf16x3
+    forward + bf16 backward, AT THE SAME TIME, while a third thread keeps flipping the process defaults
+    (protnote_amd.set_math_mode / set_backward_math) - and each ends with exactly the bits of its own serial run.  (Round 4's
+    switches were process globals: a flip on one thread changed the other's next launch.)"""
+    out = _two_models_two_streams(modes=(("f32", "same"), ("bf16x3", "bf16")), flip_defaults=True)
+    # ... and the second model really ran another arithmetic than the first one's: its serial f32 run differs
+    plain = _two_models_two_streams(modes=(("f32", "same"), ("f32", "same")), serial_only=True)
+    assert torch.equal(out[0][0], plain[0][0])
+    assert not torch.equal(out[1][0], plain[1][0]) and not torch.equal(out[1][1], plain[1][1])
+    assert (out[1][0] - plain[1][0]).abs().max().item() < 5e-3
+
+
+def _two_models_two_streams(modes, flip_defaults=False, serial_only=False):
     import threading
+
+    import protnote_amd
 
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.models.train_path import head_parameters
@@ -1589,11 +1610,13 @@ def test_two_models_on_two_streams_concurrently_equal_serial():
                           P_f=torch.randn(B, 1100, generator=gen).to(DEV), lab=torch.randn(NL, 1024, generator=gen).to(DEV),
                           y=(torch.rand(B, NL, generator=gen) < 0.05).float().to(DEV)))
 
-    def build(c):
+    def build(c, mode):
         m = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
                      projection_head_hidden_dim_scale_factor=3)
         m.load_state_dict(c["sd"])
         m = m.to(DEV).train()
+        if mode is not None:
+            m.math_mode, m.backward_math = mode
         return m, FusedClipAdam(head_parameters(m), lr=1e-3, max_norm=1.0)
 
     def step(m, opt, c, stream, out, k, reps=3):
@@ -1612,18 +1635,42 @@ def test_two_models_on_two_streams_concurrently_equal_serial():
 
     serial, conc = {}, {}
     for k, c in enumerate(cases):
-        m, opt = build(c)
+        m, opt = build(c, modes[k])
         step(m, opt, c, torch.cuda.current_stream(), serial, k)
     torch.cuda.synchronize()
-    built = [build(c) for c in cases]
+    if serial_only:
+        for k in range(2):
+            assert not isinstance(serial[k], Exception), serial[k]
+        return serial
+    built = [build(c, modes[k]) for k, c in enumerate(cases)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     torch.cuda.synchronize()
     threads = [threading.Thread(target=step, args=(built[k][0], built[k][1], cases[k], streams[k], conc, k))
                for k in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    stop = threading.Event()
+
+    def flipper():  # the process defaults change under the two training threads
+        k = 0
+        while not stop.is_set():
+            protnote_amd.set_math_mode(("bf16x3", "f32")[k & 1])
+            protnote_amd.set_backward_math(("bf16", "same")[k & 1])
+            k += 1
+            time.sleep(0.001)
+
+    fl = threading.Thread(target=flipper) if flip_defaults else None
+    try:
+        if fl is not None:
+            fl.start()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        stop.set()
+        if fl is not None:
+            fl.join()
+        protnote_amd.set_math_mode("f32")
+        protnote_amd.set_backward_math("same")
     torch.cuda.synchronize()
     for k in range(2):
         assert not isinstance(conc[k], Exception), conc[k]
@@ -1633,6 +1680,7 @@ def test_two_models_on_two_streams_concurrently_equal_serial():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), k
         for x, z in zip(a[3], b[3]):
             assert torch.equal(x, z), k
+    return conc
 
 
 def test_reference_ddp_checkpoint_resumes_on_the_fused_optimizer(golden_dir):
