@@ -63,6 +63,9 @@ def csrc_hash() -> str:
     for f in sources():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    # extra compile flags (PN_EXTRA_HIPCC_FLAGS: A/B builds of an experiment macro) are part of what the binary IS: a build
+    # made with them is only accepted by a process that runs with the same flags in its environment
+    h.update(" ".join(_extra()).encode())
     return h.hexdigest()[:16]
 
 
@@ -92,7 +95,7 @@ def have_hipcc():
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
-    if not force and not stale() and not _extra():
+    if not force and not stale():  # (the hash covers PN_EXTRA_HIPCC_FLAGS)
         return LIB
     hipcc = have_hipcc()
     if not hipcc:

@@ -265,6 +265,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
   int* sync_ctr = nullptr;  // this task's four arrival counters (whole-split tasks only: equal work for all 32 workgroups)
   if (p.task_ns > 0) {  // 32-workgroup region tasks (gemm_tn.hpp)
     if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
+#ifdef PN_TN_TASKS_T
+    // A/B build switch (round 5, PN_EXTRA_HIPCC_FLAGS=-DPN_TN_TASKS_T=1; tools/tn_tasks_ab.py): region tasks taken transposed
+    // for the kind whose two operands both stream from HBM - 8 dz x 4 activation panels instead of 4 x 8 (an f32 activation
+    // panel is twice the bytes of a bf16 dz panel).  The 12 x 12 tile grid is symmetric, so the transpose is a swap.
+    if (TB == TB_AFFINE_RELU) {
+      const int t_ = tile_m;
+      tile_m = tile_n;
+      tile_n = t_;
+    }
+#endif
     const int T = ((int)blockIdx.x >> 8) * 8 + ((int)blockIdx.x & 7);
     if (SYNC && p.task_sync != nullptr && T < p.task_ns * 4) sync_ctr = p.task_sync + 4 * T;
   } else if (PN_XCD && TB == TB_PAIRSUM_RELU && (ntm % 4 == 0) && (ntn % 2 == 0)) {

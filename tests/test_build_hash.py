@@ -108,3 +108,14 @@ def test_stale_binary_is_rebuilt_when_hipcc_is_there(scratch, monkeypatch):
         fh.write("\n// edited\n")
     _lib._ensure_current()
     assert calls == [1]
+
+
+def test_extra_compile_flags_are_part_of_the_hash(scratch, monkeypatch):
+    """An A/B build of an experiment macro (PN_EXTRA_HIPCC_FLAGS) is a different binary: the default process rejects it and
+    vice versa, so a measurement cannot silently run on the other variant."""
+    assert not build.stale()
+    h0 = build.csrc_hash()
+    monkeypatch.setenv("PN_EXTRA_HIPCC_FLAGS", "-DPN_TN_TASKS_T=1")
+    assert build.csrc_hash() != h0 and build.stale()
+    monkeypatch.delenv("PN_EXTRA_HIPCC_FLAGS")
+    assert build.csrc_hash() == h0 and not build.stale()

@@ -51,6 +51,16 @@ def main():
         y = (torch.rand(B, NL, generator=gen) < 2e-3).float().to(dev)
         row = {"B": B, "label_rows": NL, "pair_rows": B * NL, "note": note}
         need_gb = 2 * (B * NL + 300000) * 3072 * 4 / 1e9
+        if need_gb > 60:
+            # a big activation store is about to be allocated: hand every cached block (the previous case's store and
+            # workspaces, whatever their size) back to the driver FIRST.  Round 4 freed only after big cases, so 250 x 32 102
+            # (190 GB) came after 20 x 32 102 (23 GB, not freed) and died of fragmentation - the record held an OOM string
+            # where DESIGN quoted a number.
+            import protnote_amd
+
+            model.__dict__.pop("_pn_train_save", None)
+            protnote_amd.free_workspaces()
+            torch.cuda.empty_cache()
         try:
             if need_gb < 230:
                 model.train()
