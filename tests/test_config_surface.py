@@ -77,6 +77,29 @@ def test_build_models_matches_reference_parameter_counts():
         assert k in keys, k
 
 
+def test_output_mlp_num_layers_one_builds_the_reference_key_layout(golden_dir):
+    """`OUTPUT_MLP_NUM_LAYERS: 1` (configs/base_config.yaml:34; get_mlp, ProtNote.py:337-378): Linear(2d, h, no bias), BatchNorm,
+    ReLU, Linear(h, 1) - the key set of a state dict the REFERENCE built with that setting (config_holes_1layer_*.npz)."""
+    import copy
+
+    import numpy as np
+    import os
+
+    cfg = copy.deepcopy(CFG)
+    cfg["params"]["OUTPUT_MLP_NUM_LAYERS"] = 1
+    cfg["embed_sequences_params"]["PROTEINFER_NUM_GO_LABELS"] = 8
+    _, model = CF.build_models(cfg)
+    keys = {k for k in model.state_dict() if k.startswith("output_layer.")}
+    g = np.load(os.path.join(golden_dir, "config_holes_1layer_concatenation.npz"))
+    ref = {k[3:] for k in g.files if k.startswith("sd/output_layer.")}
+    assert keys == ref == {"output_layer.0.weight", "output_layer.1.weight", "output_layer.1.bias", "output_layer.1.running_mean",
+                           "output_layer.1.running_var", "output_layer.1.num_batches_tracked", "output_layer.3.weight",
+                           "output_layer.3.bias"}
+    assert tuple(model.output_layer[0].weight.shape) == (3072, 2048) and tuple(model.output_layer[3].weight.shape) == (1, 3072)
+    hd, _ = model._pair_desc()
+    assert hd.nlayers == 1 and hd.h == 3072
+
+
 def test_build_training_rejects_unknown_optimizer():
     import copy
 

@@ -1565,9 +1565,36 @@ def test_sgd_state_interchange_with_torch_sgd(golden_dir):
         for p, r in zip(ps, ref):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), atol=1e-6, rtol=1e-6)
     sd = opt.state_dict()
+    # momentum 0: torch's SGD keeps NO per-parameter state, and neither does the fused one (round 4 emitted
+    # {'momentum_buffer': None} per parameter: it loaded, but the layout was not torch's)
+    assert sd["state"] == {} and tref.state_dict()["state"] == {}
+    assert opt.flat_m is None and opt.flat_v is None
     tref.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})  # torch accepts the layout
     opt.load_state_dict(tref.state_dict())
-    assert opt.step_count == 1
+    # with momentum the velocity block exists, travels both ways, and "first step or not" survives the round trip
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref2 = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt2 = FusedClipSGD(ps2, lr=0.05, momentum=0.9, weight_decay=0.01, max_norm=1.0)
+    tref2 = torch.optim.SGD(ref2, lr=0.05, momentum=0.9, weight_decay=0.01)
+    for step in range(3):
+        for p, r in zip(ps2, ref2):
+            gr = torch.randn(p.shape, generator=gen)
+            p.grad.copy_(gr.to(DEV))
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref2, 1.0)
+        tref2.step()
+        opt2.step()
+        for p, r in zip(ps2, ref2):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), atol=1e-6, rtol=1e-6)
+    sd2 = opt2.state_dict()
+    assert sorted(sd2["state"]) == [0, 1, 2] and opt2.flat_v is None
+    for i, r in enumerate(ref2):
+        np.testing.assert_allclose(sd2["state"][i]["momentum_buffer"].cpu().numpy(),
+                                   tref2.state_dict()["state"][i]["momentum_buffer"].numpy(), atol=1e-6, rtol=1e-6)
+    tref2.load_state_dict({"state": {k: {"momentum_buffer": v["momentum_buffer"].cpu()} for k, v in sd2["state"].items()},
+                           "param_groups": sd2["param_groups"]})
+    opt2.load_state_dict(tref2.state_dict())
+    assert opt2.step_count == 1
 
 
 def test_two_models_on_two_streams_concurrently_equal_serial():
