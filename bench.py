@@ -65,6 +65,12 @@ STAGE_NAMES = {
     2008: ("row-dot logits (k_rowdot_rows_reg)", "top pre-activation read (4 B x h per row), 4 B written"),
     2009: ("conv operand staging (k_conv_stage_act)", "activation read + staged image written"),
 }
+# VALU-bound stages (pn_prof kinds >= 3000; the library reports their algorithmic vector instructions per lane-element)
+VALU_STAGE_NAMES = {
+    3001: ("one-hidden-layer head forward (k_pairsum_rowdot)", "add + max + fma per pair and hidden column"),
+    3002: ("one-hidden-layer head backward reductions (k_pair_mask_reduce_fused<rank-1>)", "8 vector instructions per pair and hidden column"),
+}
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3 T lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: Peak BF16 MFMA, dense
 HBM_PEAK_TBPS = 8.0  # same guide: HBM3E spec (measured copy rate there: 6.29 TB/s)
@@ -210,6 +216,13 @@ def stages_block(prof, steps):
     for kind, (cnt, ms, nbytes) in sorted(prof.items()):
         if kind < 2000 or cnt == 0:
             continue
+        if kind >= 3000:  # VALU-bound: lane-instructions against the vector unit's issue rate
+            name, what = VALU_STAGE_NAMES.get(kind, (str(kind), ""))
+            tops = nbytes / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out[name] = {"bound": "valu", "launches_per_step": cnt / max(steps, 1), "lane_instructions_per_launch": nbytes / cnt,
+                         "ms_per_launch": ms / cnt, "ms_per_step": ms / max(steps, 1), "achieved_Tops": round(tops, 2),
+                         "peak_Tops": round(VALU_PEAK_TOPS, 1), "frac": round(tops / VALU_PEAK_TOPS, 4), "instructions": what}
+            continue
         name, what = STAGE_NAMES.get(kind, (str(kind), ""))
         tbps = nbytes / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out[name] = {"bound": "hbm", "launches_per_step": cnt / max(steps, 1), "algorithmic_bytes_per_launch": nbytes / cnt,
@@ -324,6 +337,72 @@ def similarity_bench(model, batch, dev, world, steps, sync, max_over_ranks):
     return out
 
 
+def one_hidden_layer_bench(model, batch, dev, world, steps, sync, max_over_ranks):
+    """OUTPUT_MLP_NUM_LAYERS: 1 (configs/base_config.yaml:34; get_mlp ProtNote.py:337-378) at the headline shape: with the
+    layer-1 factorisation this head has NO pair-grid GEMM - the forward is one fused pair-sum -> ReLU -> row-dot pass, the
+    backward the rank-1 masked reductions (both VALU-bound, reported against the vector unit's issue rate); the step around
+    them is the encoder and the projection MLPs.  Shares the headline model's frozen encoder."""
+    import torch
+
+    from protnote_amd import _lib
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.models.ProtNoteTrainer import train_step
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import get_loss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    torch.manual_seed(4343)
+    m1 = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024, sequence_encoder=model.sequence_encoder,
+                  output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=1, outout_mlp_add_batchnorm=True,
+                  projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3, label_embedding_noising_alpha=20.0,
+                  feature_fusion="concatenation").to(dev).train()
+    loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
+    opt = FusedClipAdam(head_parameters(m1), lr=3e-4, max_norm=1.0)
+    B, NL = batch["label_multihots"].shape
+    for _ in range(2):
+        train_step(m1, loss_fn, opt, batch)
+    sync()
+    _lib.prof_begin()
+    t0 = time.time()
+    for _ in range(steps):
+        loss = train_step(m1, loss_fn, opt, batch)
+    sync()
+    t_train = max_over_ranks(time.time() - t0)
+    tprof = _lib.prof_end()
+    m1.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            m1(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
+               label_embeddings=batch["label_embeddings"])
+        sync()
+        _lib.prof_begin()
+        t0 = time.time()
+        for _ in range(steps):
+            m1(sequence_onehots=batch["sequence_onehots"], sequence_lengths=batch["sequence_lengths"],
+               label_embeddings=batch["label_embeddings"])
+        sync()
+        t_eval = max_over_ranks(time.time() - t0)
+        eprof = _lib.prof_end()
+
+    def head_roof(prof):  # the dominant head kernel of this configuration: the VALU-bound pair passes
+        st = {k: v for k, v in stages_block(prof, steps).items() if v.get("bound") == "valu"}
+        ops = sum(v["lane_instructions_per_launch"] * v["launches_per_step"] for v in st.values())
+        ms = sum(v["ms_per_step"] for v in st.values())
+        ach = ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TOPS, "unit": "T lane-instructions/s",
+                "frac": ach / VALU_PEAK_TOPS, "ms_per_step": ms, "kernel": "k_pairsum_rowdot (+ k_pair_mask_reduce_fused<rank-1> in training)"}
+
+    out = {"workload": f"OUTPUT_MLP_NUM_LAYERS: 1, per-GPU batch {B} x {NL} labels, h = 3072, BCE; train step fwd+bwd+clip+Adam and "
+                       "eval forward (label projection cached); no pair-grid GEMM exists in this configuration",
+           "train": {"value": world * B * NL * steps / t_train, "unit": "pairs/s", "ms_per_step": t_train / steps * 1e3,
+                     "final_loss": float(loss), "dtype": "f32", "roofline": head_roof(tprof), "kernels": kernel_table(tprof),
+                     "stages": stages_block(tprof, steps)},
+           "eval": {"value": world * B * NL * steps / t_eval, "unit": "pairs/s", "ms_per_forward": t_eval / steps * 1e3,
+                    "dtype": "f32", "roofline": head_roof(eprof), "kernels": kernel_table(eprof), "stages": stages_block(eprof, steps)}}
+    del opt, m1
+    return out
+
+
 def zero_shot_batches(seqs_per_rank, batch, rank, world, dev, seed=5):
     """configs[4] workload, weak scaling: `seqs_per_rank` x world sequences, lengths log-uniform in [32, 2048], padded
     to their bucket.  SEQUENCES are dealt to the ranks (not batches): within every length bucket rank r takes rows
@@ -417,6 +496,11 @@ def headline(full):
         modes["similarity_head.train"] = {**_mode_line(sh["train"]), "dtype": "f32"}
     if sh.get("eval"):
         modes["similarity_head.eval"] = {**_mode_line(sh["eval"], "ms_per_forward"), "dtype": "f32"}
+    oh = full.get("one_hidden_layer") or {}
+    if oh.get("train"):
+        modes["one_hidden_layer.train"] = _mode_line(oh["train"])
+    if oh.get("eval"):
+        modes["one_hidden_layer.eval"] = _mode_line(oh["eval"], "ms_per_forward")
     if modes:
         out["modes"] = modes
     if full.get("comm"):
@@ -745,6 +829,7 @@ def main():
         _lib.set_math_mode(args.math)
         model.inference_descriptions_per_label = 1
         extra["similarity_head"] = similarity_bench(model, batch, dev, world, max(2, min(args.steps, 5)), sync, max_over_ranks)
+        extra["one_hidden_layer"] = one_hidden_layer_bench(model, batch, dev, world, max(2, min(args.steps, 5)), sync, max_over_ranks)
 
     if rank == 0:
         pairs = world * B * NL * args.steps

@@ -428,7 +428,9 @@ int pn_dropout_mask(unsigned seed, int stream, float p, long rows, int cols, flo
  * ALGORITHMIC BYTES of the launches (what the pass must read + write once): 2001 conv1 from one-hots (K2),
  * 2002 masked mean-pool (K6), 2003 loss + dlogits + TP/FN/FP (K13/K14), 2004 clip + Adam/SGD (K16),
  * 2005 dz in place, 2006 BatchNorm-backward statistics, 2007 layer-1 masked reduction, 2008 row-dot logits,
- * 2009 convolution operand staging.  Returns the number of kinds written. */
+ * 2009 convolution operand staging.  Kinds >= 3000 are VALU-bound stages; `total_flops` carries their algorithmic vector
+ * instructions per lane-element: 3001 the one-hidden-layer head's forward (3 per pair and hidden column), 3002 its backward
+ * masked reductions (8).  Returns the number of kinds written. */
 int pn_prof_begin(void);
 int pn_prof_end(int max_kinds, int* kinds, long* counts, double* total_ms, double* total_flops);
 

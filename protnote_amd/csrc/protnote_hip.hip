@@ -103,7 +103,11 @@ enum {
   ST_BN_BWD_STATS = 2006, // sum du, sum du*xhat over the stored pre-activations
   ST_PAIR_MASK_REDUCE = 2007,  // layer-1 backward: M0 / M1 tables from one pass over the gradient
   ST_ROWDOT = 2008,       // logits from the stored top pre-activation
-  ST_CONV_STAGE = 2009    // relu(bn(x)) staged once per convolution for the all-DMA conv kernel
+  ST_CONV_STAGE = 2009,   // relu(bn(x)) staged once per convolution for the all-DMA conv kernel
+  // VALU-bound stages (kinds >= 3000): the `flops` field carries the pass's ALGORITHMIC VECTOR INSTRUCTIONS per lane-element
+  // (bench.py puts them next to 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s)
+  ST_PAIR1_FWD = 3001,    // OUTPUT_MLP_NUM_LAYERS: 1 forward: add, max, fma per pair and hidden column
+  ST_PAIR1_BWD = 3002     // ... backward masked reductions on the rank-1 gradient: 8 per pair and hidden column
 };
 
 extern "C" int pn_prof_begin(void) {
@@ -1417,6 +1421,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
   if (hd->nlayers == 1 && !prod) {
     // OUTPUT_MLP_NUM_LAYERS: 1 (get_mlp, ProtNote.py:337-378: one hidden layer + the output neuron).  The hidden layer is
     // the separable one, so there is no pair-grid GEMM at all: logit[i,j] = w_out . relu(A'[i] + B'[j]) + b_out in one pass
+    ProfScope ps(ST_PAIR1_FWD, 3.0 * (double)B * (double)NL * (double)h, st);
     hipLaunchKernelGGL(k_pairsum_rowdot, dim3(nblk(B, 64), nblk(NL, 64)), dim3(256), 0, st, (const float*)w.A1, (long)h,
                        (const float*)w.B1, (long)h, B, NL, h, hd->w_out, hd->b_out, logits_pairs);
     HIP_OK(hipGetLastError());
@@ -2349,6 +2354,7 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
     // OUTPUT_MLP_NUM_LAYERS: 1: the separable layer is the only hidden layer - its BatchNorm statistics came in closed form
     // from the two tables above, and the logits are one fused pair-sum -> ReLU -> row-dot pass (no pair-grid GEMM, nothing
     // stored over the grid)
+    ProfScope ps(ST_PAIR1_FWD, 3.0 * (double)R * (double)h, st);
     hipLaunchKernelGGL(k_pairsum_rowdot, dim3(nblk(B, 64), nblk(NL, 64)), dim3(256), 0, st, (const float*)sv.Ap, (long)h,
                        (const float*)sv.Bp, (long)h, B, NL, h, hd->w_out, hd->b_out, logits_pairs);
     HIP_OK(hipGetLastError());
@@ -2527,8 +2533,11 @@ extern "C" int pn_pairhead_bwd(const pn_pairhead* hd, const float* P_e, const fl
       if (w.m1part != nullptr) {
         const int per = (NL + w.m1_chunks - 1) / w.m1_chunks;
         const int nch = (NL + per - 1) / per;
-        hipLaunchKernelGGL((k_pair_mask_reduce_fused<true>), dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part,
-                           per);
+        {
+          ProfScope ps(ST_PAIR1_BWD, 8.0 * (double)R * (double)h, st);
+          hipLaunchKernelGGL((k_pair_mask_reduce_fused<true>), dim3(nblk(h, 128), nch), dim3(PMR_IG * 32), 0, st, rp, w.m1part,
+                             per);
+        }
         hipLaunchKernelGGL(k_pair_m1_reduce, dim3(nblk((long)B * h / 4, 256)), dim3(256), 0, st, (const float*)w.m1part, nch,
                            (long)B * h, h, w.dA1, (long)h);
         dw_rows = nch;
