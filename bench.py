@@ -77,7 +77,7 @@ HBM_PEAK_TBPS = 8.0  # same guide: HBM3E spec (measured copy rate there: 6.29 TB
 BUCKETS = (128, 256, 512, 1024, 2048)
 
 
-def build_model(device, seed=42, unit_scale_weights=False):
+def build_model(device, seed=42, unit_scale_weights=False, output_mlp_num_layers=3):
     import torch
 
     from protnote_amd.models.ProtNote import ProtNote
@@ -88,8 +88,8 @@ def build_model(device, seed=42, unit_scale_weights=False):
     enc = ProteInfer(num_labels=32102, input_channels=20, output_channels=1100, kernel_size=9,
                      activation=torch.nn.ReLU, dilation_base=3, num_resnet_blocks=5, bottleneck_factor=0.5)
     model = ProtNote(protein_embedding_dim=1100, label_embedding_dim=1024, latent_dim=1024, sequence_encoder=enc,
-                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, outout_mlp_add_batchnorm=True,
-                     projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
+                     output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=output_mlp_num_layers,
+                     outout_mlp_add_batchnorm=True, projection_head_num_layers=4, projection_head_hidden_dim_scale_factor=3,
                      label_embedding_noising_alpha=20.0, feature_fusion="concatenation", temperature=0.07)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():  # random BN statistics/affine so activations and logits are O(1)

@@ -227,3 +227,72 @@ def test_save_embeddings_does_not_change_the_train_step(golden_dir):
                 _, e2 = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, save_embeddings=True)
             np.testing.assert_allclose(outs[1][2]["output_layer_embeddings"].numpy(), e2["output_layer_embeddings"].numpy(),
                                        atol=1e-5, rtol=1e-5)
+
+
+def test_full_size_one_hidden_layer_train_step_vs_chunked_torch():
+    """OUTPUT_MLP_NUM_LAYERS: 1 at BASELINE configs[2]'s REAL size (B = 256, N_L = 32 102, h = 3072): forward and backward against
+    the oracle's label-chunked restatement of the naive algorithm (joint rows -> Linear -> BatchNorm1d over all 8.2 M rows -> ReLU
+    -> Linear(h, 1), BCE, multi-pass BatchNorm backward; O.train_grads_chunked, pinned on CPU to the reference's goldens) in f64
+    (ground truth) and f32 (yardstick) on the device.  Logits 5e-4, loss, the BatchNorm running buffers, every one of the head
+    gradients within 4 x the f32 run's error; a second pass reproduces everything bit for bit."""
+    import protnote_amd
+    from bench import build_model, synthetic_batch
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    dev = torch.device(DEV)
+    model = build_model(dev, unit_scale_weights=True, output_mlp_num_layers=1)
+    model.label_embedding_noising_alpha = 0.0
+    B, NL = 256, 32102
+    batch = synthetic_batch(B, 512, NL, dev, seed=9)
+    y = batch["label_multihots"].float()
+    with torch.no_grad():
+        P_f = model.sequence_encoder.get_embeddings(batch["sequence_onehots"], batch["sequence_lengths"])
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("sequence_encoder.")}
+    model.train()
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(sd0, strict=False)
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model(sequence_embeddings=P_f, label_embeddings=batch["label_embeddings"])
+        loss = BCEWithLogitsLoss()(logits, y)
+        loss.backward()
+        runs.append((logits.detach().clone(), float(loss),
+                     {k: v.detach().clone() for k, v in model.state_dict().items()
+                      if k.endswith(("running_mean", "running_var")) and not k.startswith("sequence_encoder.")},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    del logits, loss
+    lg, ls, bufs, grads = runs[0]
+    assert torch.equal(lg, runs[1][0]) and ls == runs[1][1] and all(torch.equal(grads[n], runs[1][3][n]) for n in grads)
+    protnote_amd.free_workspaces()
+    torch.cuda.empty_cache()
+
+    def reference(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        with torch.backends.cudnn.flags(enabled=False):
+            lg_, loss_, grads_ = O.train_grads_chunked(sd, P_f.to(dtype), batch["label_embeddings"].to(dtype), y.to(dtype),
+                                                       label_chunk=1024)
+        return lg_, float(loss_), grads_, sd
+
+    ref, ref_loss, ref_grads, sd = reference(torch.float64)
+    ref32, _, ref32_grads, _ = reference(torch.float32)
+    assert ref.abs().max().item() > 1.0 and float(ref.std()) > 0.1
+    f32_logit_err = (ref32.double() - ref).abs().max().item()
+    del ref32
+    err = (lg.double() - ref).abs().max().item()
+    assert err < 5e-4, (err, f32_logit_err)
+    assert abs(ls - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    assert len(bufs) == 2 * (3 + 3 + 1)
+    for k, v in bufs.items():
+        np.testing.assert_allclose(v.cpu().numpy(), sd[k].float().cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
+    assert set(grads) == set(ref_grads) and len(grads) == 14 + 14 + 5
+    bad = []
+    for n, gr in grads.items():
+        nrm = max(ref_grads[n].norm().item(), 1e-30)
+        rel = (gr.double() - ref_grads[n]).norm().item() / nrm
+        rel32 = (ref32_grads[n].double() - ref_grads[n]).norm().item() / nrm
+        print(f"full-size 1-layer grad-err {n}: hip {rel:.2e} torch-f32 {rel32:.2e} ratio {rel / max(rel32, 1e-30):.2f}")
+        if not (rel < max(4.0 * rel32, 1e-6) and rel < 2e-2):
+            bad.append((n, rel, rel32))
+    print(f"full-size 1-layer train step: max |logit - f64 reference| = {err:.2e} (torch-f32: {f32_logit_err:.2e}), loss {ls:.7f} vs {ref_loss:.7f}")
+    assert not bad, bad

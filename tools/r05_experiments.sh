@@ -1,6 +1,6 @@
 set -x
 mkdir -p gpurun_out/r05d
-python -m pytest tests/test_hip_train.py -q -m gpu -k "sgd_state_interchange or different_math_modes" 2>&1 | tail -3 > gpurun_out/r05d/tests.txt
+python -m pytest tests/test_hip_train.py tests/test_hip_config_holes.py -q -m gpu -s -k "sgd_state_interchange or different_math_modes or full_size_one_hidden" 2>&1 | grep -E "full-size|passed|failed|Error|assert" > gpurun_out/r05d/tests.txt
 python tools/fp16_weight_probe.py > gpurun_out/r05d/fp16_probe.json 2> gpurun_out/r05d/fp16_probe.err
 python -m protnote_amd.build > /dev/null 2>&1
 PN_STEPS=6 python tools/tn_tasks_ab.py gpurun_out/r05d/tn_tasks_default.json > /dev/null 2> gpurun_out/r05d/ab_a.err
