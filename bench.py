@@ -834,7 +834,7 @@ def main():
     if rank == 0:
         pairs = world * B * NL * args.steps
         traffic, traffic_src, traffic_stale = None, None, None
-        for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        for cand in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if args.math == "f32" and os.path.exists(tpath):
                 try:

@@ -265,10 +265,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
   int* sync_ctr = nullptr;  // this task's four arrival counters (whole-split tasks only: equal work for all 32 workgroups)
   if (p.task_ns > 0) {  // 32-workgroup region tasks (gemm_tn.hpp)
     if (!tn_task_coords(p.task_ns, tile_m, tile_n, split)) return;
-#ifdef PN_TN_TASKS_T
-    // A/B build switch (round 5, PN_EXTRA_HIPCC_FLAGS=-DPN_TN_TASKS_T=1; tools/tn_tasks_ab.py): region tasks taken transposed
-    // for the kind whose two operands both stream from HBM - 8 dz x 4 activation panels instead of 4 x 8 (an f32 activation
-    // panel is twice the bytes of a bf16 dz panel).  The 12 x 12 tile grid is symmetric, so the transpose is a swap.
+#ifndef PN_TN_TASKS_PLAIN
+    // Region tasks are taken TRANSPOSED for the kind whose two operands both stream from HBM: 8 dz x 4 activation panels per
+    // 32-workgroup task instead of 4 x 8 - the dz panel is bf16 here (bwd_bf16_dz.hpp), half the bytes of an f32 activation
+    // panel, so the task fetches 8 x 1 + 4 x 2 = 16 units instead of 4 x 1 + 8 x 2 = 20.  The 12 x 12 tile grid is symmetric, so
+    // the transpose is a swap.  [measured, round 5, A/B on rebuilt binaries whose source hash covers the flag:
+    // 162.6 / 162.0 -> 156.6 ms per launch, profiles/r05_tn_tasks_ab.json; -DPN_TN_TASKS_PLAIN=1 builds the old order.]
     if (TB == TB_AFFINE_RELU) {
       const int t_ = tile_m;
       tile_m = tile_n;

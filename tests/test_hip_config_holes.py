@@ -285,7 +285,7 @@ def test_full_size_one_hidden_layer_train_step_vs_chunked_torch():
     assert len(bufs) == 2 * (3 + 3 + 1)
     for k, v in bufs.items():
         np.testing.assert_allclose(v.cpu().numpy(), sd[k].float().cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
-    assert set(grads) == set(ref_grads) and len(grads) == 14 + 14 + 5
+    assert set(grads) == set(ref_grads) and len(grads) == 10 + 10 + 5  # W_p, W_l (4 Linear + 3 BatchNorm each), head
     bad = []
     for n, gr in grads.items():
         nrm = max(ref_grads[n].norm().item(), 1e-30)
