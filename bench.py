@@ -70,7 +70,10 @@ VALU_STAGE_NAMES = {
     3001: ("one-hidden-layer head forward (k_pairsum_rowdot)", "add + max + fma per pair and hidden column"),
     3002: ("one-hidden-layer head backward reductions (k_pair_mask_reduce_fused<rank-1>)", "8 vector instructions per pair and hidden column"),
 }
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3 T lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
+# 78.6 T lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed f32: v_pk_add_f32 / v_pk_fma_f32 do two per lane and clock -
+# the rate behind the chip's 157.3 TFLOP/s vector-f32 figure, which counts an FMA as 2) at 2.4 GHz.  (Round 5's first run priced the
+# stages against the unpacked 39.3 T and read 1.07: hipcc packs the adds and FMAs of k_pairsum_rowdot.)
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table: Peak BF16 MFMA, dense
 HBM_PEAK_TBPS = 8.0  # same guide: HBM3E spec (measured copy rate there: 6.29 TB/s)
@@ -389,7 +392,7 @@ def one_hidden_layer_bench(model, batch, dev, world, steps, sync, max_over_ranks
         ops = sum(v["lane_instructions_per_launch"] * v["launches_per_step"] for v in st.values())
         ms = sum(v["ms_per_step"] for v in st.values())
         ach = ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TOPS, "unit": "T lane-instructions/s",
+        return {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TOPS, "unit": "T lane-operations/s",
                 "frac": ach / VALU_PEAK_TOPS, "ms_per_step": ms, "kernel": "k_pairsum_rowdot (+ k_pair_mask_reduce_fused<rank-1> in training)"}
 
     out = {"workload": f"OUTPUT_MLP_NUM_LAYERS: 1, per-GPU batch {B} x {NL} labels, h = 3072, BCE; train step fwd+bwd+clip+Adam and "
