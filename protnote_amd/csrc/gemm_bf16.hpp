@@ -19,6 +19,10 @@
 #include "gemm_bf16x3.hpp"
 #include "gemm_tn_fast.hpp"
 
+#ifndef PN_TN_SYNC_SLABS_B16
+#define PN_TN_SYNC_SLABS_B16 PN_TN_SYNC_SLABS  // pacing interval of the single-product dW kernel (a slab here is 16 MFMAs per wave)
+#endif
+
 namespace pn {
 
 // s_waitcnt vmcnt(VM) with the awaited registers as operands: no consumer can be scheduled above it
@@ -452,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
     //  230 registers, no spill, bit-identical; dW = dz^T relu(bn(z)) 172 -> 188 ms per launch, the pair-sum kind 158 -> 160 ms:
     //  with both operands streaming from HBM the extra slab in flight costs more in the caches than the latency it hides.)
     auto checkpoint = [&](int t) {  // (gemm_tn_fast.hpp: epoch e reports into slot e % 4 and waits for epoch e - 1)
-      if (sync_ctr != nullptr && (t & (PN_TN_SYNC_SLABS - 1)) == 0 && wave == 0 && lane == 0) {
-        const int e = t / PN_TN_SYNC_SLABS;
+      if (sync_ctr != nullptr && (t & (PN_TN_SYNC_SLABS_B16 - 1)) == 0 && wave == 0 && lane == 0) {
+        const int e = t / PN_TN_SYNC_SLABS_B16;
         __hip_atomic_fetch_add(sync_ctr + (e & 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e > 1) {
           const int* c = sync_ctr + ((e - 1) & 3);
