@@ -296,3 +296,89 @@ def test_full_size_one_hidden_layer_train_step_vs_chunked_torch():
             bad.append((n, rel, rel32))
     print(f"full-size 1-layer train step: max |logit - f64 reference| = {err:.2e} (torch-f32: {f32_logit_err:.2e}), loss {ls:.7f} vs {ref_loss:.7f}")
     assert not bad, bad
+
+
+ONE_LAYER = ["1layer_concatenation", "1layer_concatenation_diff", "1layer_concatenation_prod", "1layer_concatenation_nobn"]
+
+
+@pytest.mark.parametrize("ndesc", (1, 2))
+@pytest.mark.parametrize("case", ONE_LAYER)
+def test_one_hidden_layer_eval_mode_is_differentiable(golden_dir, case, ndesc):
+    """model.eval() with autograd on (BatchNorm on its running statistics, `bn_use_running`) for the one-hidden-layer head: logits
+    equal the fused inference kernel's, every head gradient equals the oracle's autograd through eval-mode BatchNorm - with and
+    without the description ensembling in the graph - and no buffer moves."""
+    g = _g(golden_dir, case)
+    fusion = str(g["fusion"])
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    lab, y = torch.from_numpy(g["label_embeddings"]), torch.from_numpy(g["multihots"])
+    if ndesc == 1:
+        lab = lab[0::2].contiguous()
+    model, sd = make_protnote(g, DEV)
+    model.inference_descriptions_per_label = ndesc
+    model.eval()
+    _freeze_encoder(model)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    xs, ls, labd = x.to(DEV), lens.to(DEV), lab.to(DEV)
+    with torch.no_grad():
+        fused, _ = model(sequence_onehots=xs, sequence_lengths=ls, label_embeddings=labd)
+    logits, _ = model(sequence_onehots=xs, sequence_lengths=ls, label_embeddings=labd)
+    assert logits.requires_grad
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), fused.cpu().numpy(), atol=2e-5, rtol=2e-5)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y.float().to(DEV))
+    loss.backward()
+    names = O.trainable_names(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    ref = O.protnote_forward(work, x, lens, lab, fusion=fusion, training=False, descriptions_per_label=ndesc)
+    rl = torch.nn.functional.binary_cross_entropy_with_logits(ref, y.float())
+    rgrads = dict(zip(names, torch.autograd.grad(rl, [leaves[k] for k in names], allow_unused=True)))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+    named = dict(model.named_parameters())
+    checked = 0
+    for k, rg in rgrads.items():
+        if rg is None:
+            continue
+        np.testing.assert_allclose(named[k].grad.cpu().numpy(), rg.numpy(), atol=2e-5 + 2e-4 * float(rg.abs().max()), err_msg=k)
+        checked += 1
+    assert checked >= 24
+    after = model.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), k
+
+
+@pytest.mark.parametrize("case", ["1layer_concatenation", "1layer_concatenation_prod"])
+def test_one_hidden_layer_frozen_head_and_bf16x3_mode(golden_dir, case):
+    """TRAIN_PROJECTION_HEAD: False on the one-hidden-layer head (output_layer.* frozen -> NULL gradient destinations: no dw_out
+    column sum, no dgamma / dbeta, no dW_0): logits and the remaining gradients are bit-identical to the unfrozen step.  And the
+    opt-in bf16x3 mode (no pair-grid GEMM exists here; W_p / W_l / the prod GEMM follow the mode's shape rules) stays within the
+    golden tolerances."""
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    g = _g(golden_dir, case)
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
+    y = torch.from_numpy(g["multihots"]).float().to(DEV)
+    res = {}
+    for tag in ("all", "frozen", "bf16x3"):
+        model, _ = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
+        _freeze_encoder(model)
+        if tag == "frozen":
+            for n, p in model.named_parameters():
+                if n.startswith("output_layer"):
+                    p.requires_grad = False
+        if tag == "bf16x3":
+            model.math_mode = "bf16x3"
+        model.train()
+        logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab)
+        BCEWithLogitsLoss()(logits, y).backward()
+        res[tag] = (logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(res["all"][0], res["frozen"][0])
+    assert not any(n.startswith("output_layer") for n in res["frozen"][1])
+    for n, gr in res["frozen"][1].items():
+        assert torch.equal(gr, res["all"][1][n]), n
+    assert len(res["frozen"][1]) == len(res["all"][1]) - (5 if "nobn" not in case else 4)
+    np.testing.assert_allclose(res["bf16x3"][0].cpu().numpy(), res["all"][0].cpu().numpy(), atol=5e-4, rtol=1e-4)
+    for n, gr in res["all"][1].items():
+        ref = gr.cpu().numpy()
+        np.testing.assert_allclose(res["bf16x3"][1][n].cpu().numpy(), ref, atol=2e-5 + 5e-4 * np.abs(ref).max(), err_msg=n)
