@@ -109,7 +109,8 @@ class ProtNote(nn.Module):
 
     @math_mode.setter
     def math_mode(self, mode):
-        L.math_field(mode) if mode is not None else None  # validates
+        if mode is not None:
+            L.math_field(mode)  # raises ValueError on anything but "f32" / "bf16x3"
         self.__dict__["_math_mode"] = mode
         enc = self.__dict__.get("_modules", {}).get("sequence_encoder")
         if enc is not None:
