@@ -425,6 +425,24 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
         raise ValueError("Incompatible sequence parameters passed to forward method.")
     L.require_hip(P_f, L_f)
     L_f = L_f.contiguous()
+    if model.training:
+        # torch's BatchNorm1d refuses to take batch statistics over ONE row (torch/nn/functional.py _verify_batch_size), so the
+        # reference raises ValueError for a single protein / a single label row in training mode (W_p / W_l carry BatchNorm
+        # whenever PROJECTION_HEAD_NUM_LAYERS > 1; the output MLP's BatchNorm sees B * N_L rows).  Same exception here instead
+        # of a silent variance of zero.
+        from .ProtNote import _split_layers
+
+        def _has_bn(seq):
+            return any(bn is not None for _, bn in _split_layers(seq))
+
+        for rows, seq in ((P_f.shape[0], model.W_p), (L_f.shape[0], model.W_l)):
+            if rows == 1 and _has_bn(seq):
+                w = next(lin.out_features for lin, bn in _split_layers(seq) if bn is not None)
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {w}])")
+        if (model.feature_fusion.startswith("concatenation") and P_f.shape[0] * L_f.shape[0] == 1
+                and _has_bn(model.output_layer)):
+            w = next(lin.out_features for lin, bn in _split_layers(model.output_layer) if bn is not None)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {w}])")
     # SEQUENCE_EMBEDDING_DROPOUT / LABEL_EMBEDDING_DROPOUT (ProtNote.py:83-86): Bernoulli masks on the [B, 1100] and
     # [N_L, 1024] input rows (after the label noise, as the wrapped W_l sees them); torch's device RNG, like the noise
     from .ProtNote import input_dropout_p

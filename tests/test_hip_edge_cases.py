@@ -1,0 +1,125 @@
+"""Edge cases of the hot path against the CPU oracle (which is the reference's algorithm in stock torch ops, pinned to its goldens):
+the smallest grids (one protein, one label row, one description pair), length-1 sequences, and the reference's ERROR behaviour
+where torch refuses (train-mode BatchNorm over a single row)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import make_protnote, random_encoder_sd, random_head_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FUSIONS = ("concatenation", "concatenation_diff", "concatenation_prod", "similarity")
+
+
+def _golden(golden_dir, fusion):
+    return np.load(os.path.join(golden_dir, f"protnote_small_{fusion}.npz"))
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+@pytest.mark.parametrize("B,NL,ndesc", [(1, 1, 1), (1, 7, 1), (5, 1, 1), (1, 2, 2), (3, 6, 2), (6, 20, 1)])
+def test_eval_smallest_grids_vs_oracle(golden_dir, fusion, B, NL, ndesc):
+    g = _golden(golden_dir, fusion)
+    model, sd = make_protnote(g, DEV)
+    model.eval()
+    model.inference_descriptions_per_label = ndesc
+    x, lens = torch.from_numpy(g["x"])[:B], torch.from_numpy(g["lens"])[:B]
+    lab = torch.from_numpy(g["label_embeddings"])[:NL].contiguous()
+    with torch.no_grad():
+        got, emb = model(sequence_onehots=x.to(DEV), sequence_lengths=lens.to(DEV), label_embeddings=lab.to(DEV))
+    ref = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=float(g["head_cfg_temperature"]),
+                             descriptions_per_label=ndesc)
+    assert tuple(got.shape) == (B, NL // ndesc) == tuple(ref.shape)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
+    assert emb == {"output_layer_embeddings": [], "joint_embeddings": []}
+
+
+@pytest.mark.parametrize("fusion", ("concatenation", "similarity"))
+def test_length_one_sequences(golden_dir, fusion):
+    """Every sequence has ONE residue and the batch is padded to L = 1 (collator: pad to the batch maximum): the dilated
+    convolutions see nothing but their own zero padding."""
+    g = _golden(golden_dir, fusion)
+    model, sd = make_protnote(g, DEV)
+    model.eval()
+    model.inference_descriptions_per_label = 1
+    gen = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 20, (4, 1), generator=gen)
+    x = torch.nn.functional.one_hot(ids, 20).permute(0, 2, 1).float().contiguous()
+    lens = torch.ones(4, dtype=torch.int64)
+    lab = torch.from_numpy(g["label_embeddings"])
+    with torch.no_grad():
+        got, _ = model(sequence_onehots=x.to(DEV), sequence_lengths=lens.to(DEV), label_embeddings=lab.to(DEV))
+    ref = O.protnote_forward(sd, x, lens, lab, fusion=fusion, temperature=float(g["head_cfg_temperature"]))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fusion", ("concatenation", "similarity"))
+@pytest.mark.parametrize("B,NL", [(1, 5), (4, 1)])
+def test_train_mode_single_row_raises_like_torch(golden_dir, fusion, B, NL):
+    """torch's BatchNorm1d refuses batch statistics over one row, so the REFERENCE raises ValueError for a single protein (W_p) or
+    a single label row (W_l) in training mode.  The oracle (stock torch ops) raises; so must the HIP path - not a silent zero
+    variance."""
+    g = _golden(golden_dir, fusion)
+    model, sd = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
+    model.train()
+    x, lens = torch.from_numpy(g["x"])[:B], torch.from_numpy(g["lens"])[:B]
+    lab = torch.from_numpy(g["label_embeddings"])[:NL].contiguous()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        O.protnote_forward(dict(sd), x, lens, lab, fusion=fusion, training=True, sequence_embeddings=torch.randn(B, 28))
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        model(sequence_embeddings=torch.randn(B, 28).to(DEV), label_embeddings=lab.to(DEV))
+
+
+@pytest.mark.parametrize("fusion", FUSIONS)
+def test_train_step_on_a_two_by_two_grid(golden_dir, fusion):
+    """The smallest grid torch accepts in training mode (2 proteins x 2 label rows: BatchNorm statistics over 2, 2 and 4 rows):
+    logits, loss and every head gradient against the oracle's autograd."""
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    g = _golden(golden_dir, fusion)
+    model, sd = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
+    for n, p in model.named_parameters():
+        if n.startswith("sequence_encoder"):
+            p.requires_grad = False
+    model.train()
+    gen = torch.Generator().manual_seed(5)
+    P_f = torch.randn(2, 28, generator=gen)
+    lab = torch.from_numpy(g["label_embeddings"])[:2].contiguous()
+    y = torch.tensor([[1.0, 0.0], [0.0, 1.0]])
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+    loss.backward()
+    names = O.trainable_names(sd)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(leaves)
+    ref = O.protnote_forward(work, None, None, lab, fusion=fusion, training=True, sequence_embeddings=P_f,
+                             temperature=float(g["head_cfg_temperature"]))
+    rl = O.bce_loss(ref, y)
+    rg = dict(zip(names, torch.autograd.grad(rl, [leaves[k] for k in names], allow_unused=True)))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), rl.item(), rtol=1e-4)
+    named = dict(model.named_parameters())
+    # (a BatchNorm over 2 rows maps them to +-1 up to eps: gradients through it are O(eps)-sensitive, hence the looser bound)
+    for k, r in rg.items():
+        if r is not None:
+            np.testing.assert_allclose(named[k].grad.cpu().numpy(), r.numpy(), atol=5e-5 + 2e-3 * float(r.abs().max()), err_msg=k)
+
+
+def test_real_width_single_protein_eval():
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(8)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    P_f, lab = torch.randn(1, 1100, generator=gen), torch.randn(3, 1024, generator=gen)
+    with torch.no_grad():
+        got, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    ref = O.protnote_forward(sd, None, None, lab, sequence_embeddings=P_f)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
