@@ -74,39 +74,47 @@ def test_train_mode_single_row_raises_like_torch(golden_dir, fusion, B, NL):
 
 
 @pytest.mark.parametrize("fusion", FUSIONS)
-def test_train_step_on_a_two_by_two_grid(golden_dir, fusion):
-    """The smallest grid torch accepts in training mode (2 proteins x 2 label rows: BatchNorm statistics over 2, 2 and 4 rows):
-    logits, loss and every head gradient against the oracle's autograd."""
+def test_train_step_on_tiny_grids(golden_dir, fusion):
+    """Training mode on the smallest grids torch accepts.  2 x 2: BatchNorm statistics over 2, 2 and 4 rows - logits and loss
+    against the oracle (the GRADIENT through a 2-row BatchNorm is (du1 - du2)/2 * eps/(var + eps): pure cancellation, any two f32
+    implementations disagree in the leading digit, so it is not compared).  3 x 4: logits, loss and every head gradient against
+    the oracle's autograd evaluated in float64."""
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 
     g = _golden(golden_dir, fusion)
-    model, sd = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
-    for n, p in model.named_parameters():
-        if n.startswith("sequence_encoder"):
-            p.requires_grad = False
-    model.train()
-    gen = torch.Generator().manual_seed(5)
-    P_f = torch.randn(2, 28, generator=gen)
-    lab = torch.from_numpy(g["label_embeddings"])[:2].contiguous()
-    y = torch.tensor([[1.0, 0.0], [0.0, 1.0]])
-    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
-    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
-    loss.backward()
-    names = O.trainable_names(sd)
-    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
-    work = dict(sd)
-    work.update(leaves)
-    ref = O.protnote_forward(work, None, None, lab, fusion=fusion, training=True, sequence_embeddings=P_f,
-                             temperature=float(g["head_cfg_temperature"]))
-    rl = O.bce_loss(ref, y)
-    rg = dict(zip(names, torch.autograd.grad(rl, [leaves[k] for k in names], allow_unused=True)))
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-4, rtol=1e-4)
-    np.testing.assert_allclose(loss.item(), rl.item(), rtol=1e-4)
-    named = dict(model.named_parameters())
-    # (a BatchNorm over 2 rows maps them to +-1 up to eps: gradients through it are O(eps)-sensitive, hence the looser bound)
-    for k, r in rg.items():
-        if r is not None:
-            np.testing.assert_allclose(named[k].grad.cpu().numpy(), r.numpy(), atol=5e-5 + 2e-3 * float(r.abs().max()), err_msg=k)
+    T = float(g["head_cfg_temperature"])
+    for B, NL, check_grads in ((2, 2, False), (3, 4, True)):
+        model, sd = make_protnote(g, DEV, label_embedding_noising_alpha=0.0)
+        for n, p in model.named_parameters():
+            if n.startswith("sequence_encoder"):
+                p.requires_grad = False
+        model.train()
+        gen = torch.Generator().manual_seed(5)
+        P_f = torch.randn(B, 28, generator=gen)
+        lab = torch.from_numpy(g["label_embeddings"])[:NL].contiguous()
+        y = (torch.rand(B, NL, generator=gen) < 0.4).float()
+        logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+        loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+        loss.backward()
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        names = O.trainable_names(sd64)
+        leaves = {k: sd64[k].clone().requires_grad_(True) for k in names}
+        work = dict(sd64)
+        work.update(leaves)
+        ref = O.protnote_forward(work, None, None, lab.double(), fusion=fusion, training=True, sequence_embeddings=P_f.double(),
+                                 temperature=T)
+        rl = O.bce_loss(ref, y.double())
+        rg = dict(zip(names, torch.autograd.grad(rl, [leaves[k] for k in names], allow_unused=True)))
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+        np.testing.assert_allclose(loss.item(), rl.item(), rtol=1e-4)
+        if not check_grads:
+            continue
+        named = dict(model.named_parameters())
+        for k, r in rg.items():
+            if r is None:
+                continue
+            rel = (named[k].grad.cpu().double() - r).norm().item() / max(r.norm().item(), 1e-30)
+            assert rel < 5e-3, (fusion, k, rel)  # 3-row BatchNorm backward: still cancellation-heavy, f32 class ~1e-4..1e-3
 
 
 def test_real_width_single_protein_eval():
