@@ -1,0 +1,94 @@
+"""Seeded sweep over the head's configuration surface at small widths: random (FEATURE_FUSION, OUTPUT_MLP_NUM_LAYERS 1..4,
+OUTPUT_MLP_BATCHNORM, PROJECTION_HEAD_NUM_LAYERS 1..4, widths, B, N_L, descriptions per label) - eval logits (ensembled) and a
+train-mode step (logits, loss, every gradient) of the HIP path against the CPU oracle evaluated in float64 on the twin's own
+state dict.  The goldens pin a handful of configurations to the reference; this holds the combinations in between."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cases(n=28, seed=2024):
+    rng = np.random.RandomState(seed)
+    out = []
+    for k in range(n):
+        fusion = ["concatenation", "concatenation_diff", "concatenation_prod", "similarity"][rng.randint(4)]
+        out.append(dict(id=k, fusion=fusion, nl=int(rng.randint(1, 5)), bn=bool(rng.rand() < 0.75), nproj=int(rng.randint(1, 5)),
+                        pdim=int(4 * rng.randint(3, 12)), ldim=int(4 * rng.randint(3, 12)), d=int(4 * rng.randint(2, 10)),
+                        oscale=int(rng.randint(1, 4)), pscale=int(rng.randint(1, 4)), B=int(rng.randint(2, 40)),
+                        NLab=int(rng.randint(2, 70)), ndesc=int(rng.randint(1, 3))))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['id']}-{c['fusion']}-L{c['nl']}-bn{int(c['bn'])}-p{c['nproj']}-{c['B']}x{c['NLab']}x{c['ndesc']}")
+def test_random_head_configuration_vs_oracle(c):
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(100 + c["id"])
+    torch.manual_seed(c["id"])
+    model = ProtNote(protein_embedding_dim=c["pdim"], label_embedding_dim=c["ldim"], latent_dim=c["d"],
+                     output_mlp_hidden_dim_scale_factor=c["oscale"], output_mlp_num_layers=c["nl"],
+                     outout_mlp_add_batchnorm=c["bn"], projection_head_num_layers=c["nproj"],
+                     projection_head_hidden_dim_scale_factor=c["pscale"], feature_fusion=c["fusion"],
+                     inference_descriptions_per_label=c["ndesc"], label_embedding_noising_alpha=0.0)
+    with torch.no_grad():  # O(1) activations and logits: random BatchNorm state, weights ~ 1.6 / sqrt(fan_in)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.3)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) * 1.5 + 0.5)
+            elif isinstance(m, torch.nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (1.6 / m.weight.shape[1] ** 0.5))
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    model = model.to(DEV)
+    B, NL, nd = c["B"], c["NLab"], c["ndesc"]
+    P_f = torch.randn(B, c["pdim"], generator=gen)
+    lab = torch.randn(NL * nd, c["ldim"], generator=gen)
+    y = (torch.rand(B, NL * nd, generator=gen) < 0.3).float()
+
+    # ---- eval (ensembled when nd == 2)
+    model.eval()
+    with torch.no_grad():
+        got, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    ref = O.protnote_forward(sd64, None, None, lab.double(), fusion=c["fusion"], sequence_embeddings=P_f.double(),
+                             descriptions_per_label=nd)
+    assert tuple(got.shape) == (B, NL)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() < 5e-4 * scale, c
+
+    # ---- train step (training ignores the ensembling: one logit per row, ProtNote.py:308-309)
+    model.train()
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+    loss.backward()
+    names = O.trainable_names(sd64)
+    leaves = {k: sd64[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd64)
+    work.update(leaves)
+    rl_ = O.protnote_forward(work, None, None, lab.double(), fusion=c["fusion"], training=True, sequence_embeddings=P_f.double())
+    rloss = O.bce_loss(rl_, y.double())
+    rg = dict(zip(names, torch.autograd.grad(rloss, [leaves[k] for k in names], allow_unused=True)))
+    scale = max(1.0, rl_.abs().max().item())
+    assert (logits.detach().cpu().double() - rl_.detach()).abs().max().item() < 5e-4 * scale, c
+    assert abs(loss.item() - rloss.item()) < 1e-4 * max(1.0, abs(rloss.item()))
+    named = dict(model.named_parameters())
+    for k, r in rg.items():
+        if r is None:
+            continue
+        assert named[k].grad is not None, k
+        rel = (named[k].grad.cpu().double() - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert rel < 3e-3 or (named[k].grad.cpu().double() - r).abs().max().item() < 1e-7, (c, k, rel)
+    # BatchNorm buffers after the train-mode forward (the oracle's functional batch_norm advanced sd64's buffers in place)
+    after = model.state_dict()
+    for k, v in work.items():
+        if k.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(after[k].cpu().numpy(), v.detach().float().numpy(), atol=2e-5, rtol=2e-4, err_msg=k)
