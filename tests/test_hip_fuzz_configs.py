@@ -148,3 +148,46 @@ def test_random_encoder_configuration_vs_oracle(c):
         for k, v in work.items():
             if k.endswith(("running_mean", "running_var")):
                 np.testing.assert_allclose(after[k].cpu().numpy(), v.float().numpy(), atol=2e-5, rtol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 33), (7, 1), (3, 257), (64, 1000), (33, 4099), (256, 64)])
+def test_losses_and_counts_on_ragged_shapes_vs_oracle(B, N):
+    """Every LOSS_FN (losses.py:58-294) and the fused TP/FN/FP counts (ProtNoteTrainer.py:61-83) on shapes that leave the
+    kernel's tiles ragged - single row, single label, N = 4099 - and with extreme logits (+-40: softplus saturation): loss and
+    dL/dlogits against the oracle in float64, counts bit-exact."""
+    from protnote_amd.utils import losses as LS
+
+    gen = torch.Generator().manual_seed(B * 7919 + N)
+    logits = torch.randn(B, N, generator=gen) * 3
+    logits.view(-1)[:: max(1, (B * N) // 7)] = 40.0
+    logits.view(-1)[1:: max(1, (B * N) // 5)] = -40.0
+    y = (torch.rand(B, N, generator=gen) < 0.2).float()
+    lw = torch.rand(N, generator=gen) * 4 + 0.1
+    counts_src = torch.randint(0, 300, (N,), generator=gen).float()
+    cases = [
+        ("BCE", LS.BCEWithLogitsLoss(pos_weight=torch.tensor(1.0)), lambda x, t: O.bce_loss(x, t)),
+        ("BCE_pw", LS.BCEWithLogitsLoss(pos_weight=torch.tensor(3.5)), lambda x, t: O.bce_loss(x, t, pos_weight=3.5)),
+        ("Focal", LS.FocalLoss(alpha=-1, gamma=2), lambda x, t: O.focal_loss(x, t, 2.0, -1.0)),
+        ("Focal_a_ls", LS.FocalLoss(alpha=0.25, gamma=1.5, label_smoothing=0.1), lambda x, t: O.focal_loss(x, t, 1.5, 0.25, 0.1)),
+        ("RGDBCE", LS.RGDBCE(temperature=0.12), lambda x, t: O.rgd_bce_loss(x, t, 0.12)),
+        ("BatchWeightedBCE", LS.BatchWeightedBCE(), lambda x, t: O.batch_weighted_bce_loss(x, t)),
+        ("WeightedBCE", LS.WeightedBCE(label_weights=lw.to(DEV)), lambda x, t: O.weighted_bce_loss(x, t, lw.double())),
+        ("CBLoss", LS.CBLoss(label_weights=counts_src.to(DEV)), lambda x, t: O.cb_loss(x, t, counts_src)),
+    ]
+    for name, fn, ref_fn in cases:
+        lg = logits.clone().to(DEV).requires_grad_(True)
+        if hasattr(fn, "metric_counts"):
+            fn.metric_counts = torch.zeros(3, N, device=DEV)
+            fn.decision_threshold = 0.3
+        l = fn(lg, y.to(DEV))
+        l.backward()
+        x64 = logits.double().requires_grad_(True)
+        rl = ref_fn(x64, y.double())
+        (rg,) = torch.autograd.grad(rl, x64)
+        assert abs(l.item() - rl.item()) <= 2e-6 * max(1.0, abs(rl.item())), (name, l.item(), rl.item())
+        err = (lg.grad.cpu().double() - rg).abs().max().item()
+        assert err <= 1e-9 + 2e-5 * rg.abs().max().item(), (name, err, rg.abs().max().item())
+        if getattr(fn, "metric_counts", None) is not None:
+            tp, fn_, fp = O.tp_fn_fp(torch.sigmoid(logits), y, 0.3)
+            got = fn.metric_counts.cpu()
+            assert torch.equal(got[0], tp.float()) and torch.equal(got[1], fn_.float()) and torch.equal(got[2], fp.float()), name
