@@ -184,9 +184,12 @@ def test_losses_and_counts_on_ragged_shapes_vs_oracle(B, N):
         x64 = logits.double().requires_grad_(True)
         rl = ref_fn(x64, y.double())
         (rg,) = torch.autograd.grad(rl, x64)
-        assert abs(l.item() - rl.item()) <= 2e-6 * max(1.0, abs(rl.item())), (name, l.item(), rl.item())
+        assert abs(l.item() - rl.item()) <= (5e-5 if name == "CBLoss" else 2e-6) * max(1.0, abs(rl.item())), (name, l.item(), rl.item())
         err = (lg.grad.cpu().double() - rg).abs().max().item()
-        assert err <= 1e-9 + 2e-5 * rg.abs().max().item(), (name, err, rg.abs().max().item())
+        # (CBLoss: the class weights (1 - beta) / (1 - beta^n) are f32 on both sides, as in the reference - 1 - 0.9999^n cancels,
+        #  so torch's pow on the GPU and on the CPU agree to ~1e-5 relative only; measured 2.2e-5)
+        rtol = 1e-4 if name == "CBLoss" else 2e-5
+        assert err <= 1e-9 + rtol * rg.abs().max().item(), (name, err, rg.abs().max().item())
         if getattr(fn, "metric_counts", None) is not None:
             tp, fn_, fp = O.tp_fn_fp(torch.sigmoid(logits), y, 0.3)
             got = fn.metric_counts.cpu()
