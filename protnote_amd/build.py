@@ -101,6 +101,21 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not hipcc:
         raise RuntimeError("hipcc not found (set HIPCC)")
     os.makedirs(OBJ, exist_ok=True)
+    # one builder at a time: the N ranks of `bench.py --gpus N` (or pytest-xdist workers) may all find the binary stale at once
+    import fcntl
+
+    lock = open(os.path.join(OBJ, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not stale():  # another process built it while this one waited
+            return LIB
+        return _build_locked(hipcc, force, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc, force, verbose):
 
     def compile_unit(unit):
         if not force and not _unit_stale(unit):
@@ -115,10 +130,12 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
         list(ex.map(compile_unit, UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(u) for u in UNITS]
+    tmp = LIB + f".tmp{os.getpid()}"  # link beside the target, then rename: a reader never sees a half-written library
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [_obj(u) for u in UNITS]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     if embedded_hash() != csrc_hash():
         raise RuntimeError(f"built {LIB} carries hash {embedded_hash()} but the sources hash to {csrc_hash()} "
                            "(a source changed during the build?)")
