@@ -122,6 +122,11 @@ class ProteInfer(torch.nn.Module):
         updates its running buffers exactly like the reference's "frozen" encoder does.
         With gradients enabled and trainable parameters (TRAIN_SEQUENCE_ENCODER: True) the call is differentiable:
         pn_encoder_fwd_train keeps the activations, pn_encoder_bwd returns every parameter gradient."""
+        if self.training and x.dim() == 3 and x.shape[0] * x.shape[2] == 1 and len(self.resnet_blocks) > 0:
+            # torch's BatchNorm1d refuses batch statistics over one value per channel (a single residue in the whole batch):
+            # the reference raises here, so does the twin
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([1, {self._dims['C']}, 1])")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.trunk_parameters()):
             # (eval mode: BatchNorm normalises with its running statistics, which the backward treats as constants -
             #  pn_encoder.bn_use_running)

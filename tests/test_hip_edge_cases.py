@@ -135,3 +135,24 @@ def test_real_width_single_protein_eval():
         got, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
     ref = O.protnote_forward(sd, None, None, lab, sequence_embeddings=P_f)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
+
+
+def test_encoder_train_mode_single_residue_raises_like_torch(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder_small.npz"))
+    from tests.helpers import make_encoder, npz_cfg
+
+    sd = O.as_torch_sd(g, "sd/")
+    enc = make_encoder({"e." + k: v for k, v in sd.items()}, "e.", npz_cfg(g, "cfg_"), DEV)
+    enc.train()
+    x = torch.zeros(1, 20, 1)
+    x[0, 3, 0] = 1.0
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        O.proteinfer_get_embeddings(dict(sd), x, torch.tensor([1]), True)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        with torch.no_grad():
+            enc.get_embeddings(x.to(DEV), torch.tensor([1]).to(DEV))
+    enc.eval()
+    with torch.no_grad():
+        got = enc.get_embeddings(x.to(DEV), torch.tensor([1]).to(DEV))
+    ref = O.proteinfer_get_embeddings(sd, x, torch.tensor([1]), False)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=1e-4)
