@@ -8,7 +8,7 @@ from contextlib import redirect_stdout
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORDS = ["r04_bench_20steps.json", "r03_bench_20steps.json"]
+RECORDS = ["r05_bench_20steps.json", "r04_bench_20steps.json", "r03_bench_20steps.json"]
 
 
 @pytest.mark.parametrize("record", RECORDS)
@@ -36,10 +36,22 @@ def test_headline_is_compact_and_complete(record):
         assert set(m) <= {"value", "ms_per_step", "dtype", "roofline_frac"}, (name, m)
 
 
+def test_r05_record_carries_the_round5_blocks():
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_20steps.json")))
+    h = json.loads(bench.headline(full))
+    assert len(h["build_hash"]) == 16 and h["roofline"]["traffic_stale"] is False
+    for k in ("fast_mode", "amp_backward.forward_bf16x3", "forward_only.f32", "zero_shot.f32.GO-2019", "one_hidden_layer.train"):
+        assert k in h["modes"], k
+    valu = [v for v in full["one_hidden_layer"]["train"]["stages"].values() if v["bound"] == "valu"]
+    assert len(valu) == 2 and all(0.0 < v["frac"] < 1.0 for v in valu)  # priced against the packed-f32 vector rate
+
+
 def test_headline_sheds_modes_rather_than_overflow():
     import bench
 
-    full = json.load(open(os.path.join(ROOT, "profiles", RECORDS[0])))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_20steps.json")))
     full["zero_shot"]["f32"] = {f"table{i} (x)": dict(next(iter(full["zero_shot"]["f32"].values()))) for i in range(80)}
     line = bench.headline(full)
     assert len(line) <= bench.HEADLINE_MAX_BYTES and "modes" not in json.loads(line)
