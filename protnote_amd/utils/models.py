@@ -28,12 +28,27 @@ def strip_ddp_prefix(state_dict):
     return state_dict
 
 
+def _load_checkpoint_file(path: str, map_location):
+    """A checkpoint written by the reference's save_checkpoint (utils/models.py:304-321) holds tensors, ints and floats only, so
+    it loads under torch's restricted unpickler (weights_only=True: no code execution).  Anything that does not (a checkpoint with
+    pickled custom objects) falls back to the reference's own full unpickling (torch.load, :347) with a warning - only load such
+    files from sources you trust."""
+    import pickle
+    import warnings
+
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError) as exc:
+        warnings.warn(f"{path}: not loadable with weights_only=True ({str(exc)[:120]}); falling back to full unpickling - "
+                      "this executes whatever the file contains", stacklevel=3)
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
 def load_checkpoint_into(model, checkpoint_path: str, map_location="cpu", strict: bool = True):
     """Load `model_state_dict` of a reference-format checkpoint into a protnote_amd (or reference) model.
     Returns the rest of the checkpoint (epoch, optimizer_state_dict, best_val_metric).
-    Checkpoints are unpickled in full (weights_only=False, as the reference's torch.load does, utils/models.py:347):
-    only load files you trust."""
-    ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+    Loaded with torch's restricted unpickler first (_load_checkpoint_file)."""
+    ckpt = _load_checkpoint_file(checkpoint_path, map_location)
     model.load_state_dict(strip_ddp_prefix(ckpt["model_state_dict"]), strict=strict)
     return {k: v for k, v in ckpt.items() if k != "model_state_dict"}
 
@@ -45,7 +60,7 @@ def load_model(trainer, checkpoint_path: str, rank: int = 0, from_checkpoint: bo
     (as `starting_epoch` and `epoch`) and `best_val_metric` are restored too.  Tensors saved on cuda:0 land on this
     rank's device (:347)."""
     map_location = {"cuda:0": f"cuda:{rank}"} if torch.cuda.is_available() else "cpu"
-    ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+    ckpt = _load_checkpoint_file(checkpoint_path, map_location)
     model = trainer._get_model() if hasattr(trainer, "_get_model") else getattr(trainer.model, "module", trainer.model)
     model.load_state_dict(strip_ddp_prefix(ckpt["model_state_dict"]))
     opt = getattr(trainer, "optimizer", None)
