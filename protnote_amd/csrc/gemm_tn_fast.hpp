@@ -1,10 +1,7 @@
 // f32 weight-gradient (TN) kernel of the pair head, specialised for the shapes that carry the train step:
 //     dW[m][n] = sum_r dz[r][m] * h[r][n],   h = relu(s * z + t)  (TB_AFFINE_RELU)  or  relu(A'[r % B] + B'[r / B])  (TB_PAIRSUM_RELU)
 // M, N multiples of 256, every row split a whole number of 32-row slabs, for the pair-sum kind B % 32 == 0 (a slab then
-// lies inside one label: B'[j] is ONE row per slab and the A' rows are consecutive) or - PB != 0, round 5 - B in {2, 4, 8, 16} (a
-// slab then covers 32 / B whole labels; the reference ships a per-GPU batch of 8, configs/base_config.yaml:7-9): a thread stages
-// the slab rows wave + 8 q, whose protein (wave + 8 q) % B never changes from slab to slab, so its A' row(s) are LOOP-INVARIANT
-// registers and what it fetches per slab are its (at most four) B' rows - the same four 16-byte loads and the same adds.  Same tiles, LDS images, product
+// lies inside one label: B'[j] is ONE row per slab and the A' rows are consecutive).  Same tiles, LDS images, product
 // order and split-K partials as gemm_tn_kernel<TA_PLAIN, TB, BIG, ADMA> - results are bit-identical - but written, like
 // gemm_nt_dma_kernel, so that the slab loop spends vector instructions on nothing but the operand transform: the generic
 // kernel's row clamps, masks, 64-bit per-lane addresses and pair decode cost ~125-160 VALU instructions per slab and wave,
@@ -53,10 +50,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // SYNC: the region task's workgroups pace each other (checkpoint below); compiled in only where it is used - the code in the
 // slab loop costs 1-3 % even when it does nothing.
-template <int TB, bool SYNC = false, int PB = 0>
+template <int TB, bool SYNC = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) {
   static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the fast TN kernel");
-  static_assert(PB == 0 || (TB == TB_PAIRSUM_RELU && (PB == 2 || PB == 4 || PB == 8 || PB == 16)), "PB: small pair batches");
   constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
   constexpr unsigned ROWB = 1024u;    // bytes of one tile row (256 floats)
   constexpr unsigned TILEB = 32768u;  // bytes of one operand buffer (32 rows)
@@ -108,12 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
   const unsigned b_lane = (unsigned)((long)wave * p.ldb + 4 * lane) * 4u;
   const unsigned b2_lane = 16u * lane;
   f32x4 rb[NQ], rb2 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 rb2b = rb2;  // PB == 16: the A' row of the odd q (protein wave + 8)
   f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bt = bs;
-  if constexpr (PB != 0) {  // the thread's protein(s) never change: A'[(wave + 8 q) % PB] once, for the whole split
-    rb2 = bload4(p.B + (long)(wave % PB) * p.ldb + n0, b2_lane);
-    if constexpr (PB == 16) rb2b = bload4(p.B + (long)(wave + 8) * p.ldb + n0, b2_lane);
-  }
   if constexpr (TB == TB_AFFINE_RELU) {
     const float4 s4 = ld4(p.b_s + n0 + 4 * lane), t4 = ld4(p.b_t + n0 + 4 * lane);
     bs = f32x4{s4.x, s4.y, s4.z, s4.w};
@@ -127,14 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
   }
   int pf_t = 0;  // slab the carried pair decode stands at
   auto fetch_b = [&](int t) {  // t = the previous call's t or that + 1 (the end of the split re-fetches the last slab)
-    if constexpr (PB != 0) {
-      // rows wave + 8 q of slab t: label (slab base + wave + 8 q) / PB = j0 + wave / PB + q * (8 / PB)   (PB <= 8)
-      //                                                                    j0 + q / 2                       (PB == 16)
-      const long j0 = (r_begin + (long)t * BK) / PB + (PB <= 8 ? wave / PB : 0);
-      const float* src = p.B2 + j0 * p.ldb2 + n0;  // uniform
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) rb[q] = bload4(src + (long)(PB == 16 ? q / 2 : q * (8 / PB)) * p.ldb2, b2_lane);
-    } else if constexpr (TB == TB_PAIRSUM_RELU) {
+    if constexpr (TB == TB_PAIRSUM_RELU) {
       const bool adv = t != pf_t;
       pf_t = t;
       const int ni = pf_i + (adv ? BK : 0);
@@ -154,8 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
   // make the fetched registers opaque at this point of the program: their consumers (and the s_waitcnt vmcnt that goes
   // with them) cannot be hoisted above it (gemm_engine.hpp pin4)
   auto pin_b = [&]() {
-    if constexpr (PB != 0) asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));  // (rb2 / rb2b are loop-invariant)
-    else asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb2));
+    asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb2));
   };
   // B image: inside a tile row the two 64-column groups of a wave's 128-column strip are interleaved pair-wise, so that
   // the four values a lane feeds to its four MFMA tiles (columns 2 l', 2 l' + 1 of group 0 and of group 1) are ONE 16-byte
@@ -172,12 +155,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
       if constexpr (TB == TB_AFFINE_RELU) {
         lo = pk_fma(rb[q].xy, bs.xy, bt.xy);
         hi = pk_fma(rb[q].zw, bs.zw, bt.zw);
-      } else if (PB == 16 && (q & 1)) {
-        lo = pk_add(rb2b.xy, rb[q].xy);  // (A' + B' in the generic kernel's operand order: the sum is bit-identical)
-        hi = pk_add(rb2b.zw, rb[q].zw);
-      } else if constexpr (PB != 0) {
-        lo = pk_add(rb2.xy, rb[q].xy);
-        hi = pk_add(rb2.zw, rb[q].zw);
       } else {
         lo = pk_add(rb[q].xy, rb2.xy);
         hi = pk_add(rb[q].zw, rb2.zw);

@@ -1660,11 +1660,11 @@ static const int TN_SYNC_INTS = 4096;  // arrival counters of the paced TN kerne
 // (Tried in round 4 and removed: the pair-sum operand for batch sizes that are not multiples of 32 with a scalar per-row
 //  pair decode - 4 more B' row registers per thread push the slab loop into scratch spills, 129 instead of the generic
 //  kernel's 133 TFLOP/s at B = 100 / 250; profiles/r04_shape_sweep.json.)
-template <int TB, int PB = 0>
+template <int TB>
 static int launch_tn_fast(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   // pacing only for the kind whose second operand streams from HBM too (the pair-sum kind's tables are L2-resident: 0.22 TB)
   constexpr bool SYNC = TB == TB_AFFINE_RELU;
-  auto kern = gemm_tn_fast_kernel<TB, SYNC, PB>;
+  auto kern = gemm_tn_fast_kernel<TB, SYNC>;
   static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
@@ -1828,16 +1828,6 @@ static int launch_tn(TnParams p, float* dst, long ldd, float* part, size_t part_
         const bool tail_ok = p.R % 32 == 0 || (part != nullptr && part_cap_floats >= 3 * (size_t)p.M * p.N);
         const bool pair_ok = TB != TB_PAIRSUM_RELU || (p.pairB % 32 == 0 && p.ldb2 % 4 == 0);
         if (fits && tail_ok && pair_ok) return launch_tn_fast<TB>(p, dst, ldd, part, part_cap_floats, st);
-        if constexpr (TB == TB_PAIRSUM_RELU) {
-          // small batches that divide a slab (the reference ships a per-GPU batch of 8): a slab covers 32 / B whole labels and
-          // the thread's A' rows are loop-invariant (gemm_tn_fast.hpp, PB)
-          if (fits && tail_ok && p.ldb2 % 4 == 0 && (long)8 * p.ldb2 * 4 < (1L << 31)) {
-            if (p.pairB == 8) return launch_tn_fast<TB, 8>(p, dst, ldd, part, part_cap_floats, st);
-            if (p.pairB == 16) return launch_tn_fast<TB, 16>(p, dst, ldd, part, part_cap_floats, st);
-            if (p.pairB == 4) return launch_tn_fast<TB, 4>(p, dst, ldd, part, part_cap_floats, st);
-            if (p.pairB == 2) return launch_tn_fast<TB, 2>(p, dst, ldd, part, part_cap_floats, st);
-          }
-        }
       }
       if (p.R % 32 == 0) return launch_tn_cfg<TA, TB, true, true>(p, dst, ldd, part, part_cap_floats, st);
     }
