@@ -139,6 +139,10 @@ typedef struct pn_pairhead {
   /* pn_pairhead_bwd: arithmetic of the hidden layers' backward pair-grid GEMMs: 0 = the library default
    * (pn_set_backward_math), 1 = as the forward, 2 = one bf16 product with f32 accumulation (AMP class) */
   int backward_math;
+  /* pn_pairhead_fwd_*: arithmetic of the hidden layers' FORWARD pair-grid GEMMs (z_l = h_{l-1} W_l^T, l >= 1): 0 = the library
+   * default (pn_set_forward_math), 1 = as math_mode, 2 = one bf16 product with f32 accumulation (AMP class, see
+   * pn_set_forward_math).  pn_pairhead_bwd ignores it (the backward regenerates h from the stored f32 z). */
+  int forward_math;
 } pn_pairhead;
 
 size_t pn_pairhead_eval_ws_bytes(const pn_pairhead* hd, int B, int NL, int label_chunk);
@@ -387,6 +391,19 @@ int pn_get_math_mode(void);
  * affected; layers with OUTPUT_MLP_DROPOUT > 0 keep the f32 kernels. */
 int pn_set_backward_math(int mode);
 int pn_get_backward_math(void);
+
+/* Arithmetic of the FORWARD pair-grid GEMMs of the output MLP's hidden layers (z_l = h_{l-1} W_l^T, l >= 1; the separable first
+ * layer has no pair-grid GEMM): 0 (default) = whatever math_mode selects; 1 = one product of the bf16-rounded operands with f32
+ * accumulation (v_mfma_f32_32x32x16_bf16) - the arithmetic class of the reference's own GPU run, whose forward executes under
+ * torch.autocast as well (ProtNoteTrainer.py:287 eval, :728-729 train).  What stays as math_mode says: the layer-1 tables, the
+ * extra pair GEMM of concatenation_prod, W_p / W_l, the encoder; what stays f32 in every mode: BatchNorm statistics (f64
+ * partials), the STORED pre-activations z_l (so the backward is untouched), the row-dot of the output neuron, the loss.  Opt-in:
+ * rounding the h x h weights to bf16 alone moves O(1) logits by ~1e-2 (profiles/r05_fp16_weight_probe.json), so this mode
+ * cannot meet the 1e-3 logit bound the f32 / bf16x3 modes are held to; it is held to torch's own autocast(bfloat16) run of
+ * the oracle instead (tests/test_hip_fwd_bf16.py).  Layers with OUTPUT_MLP_DROPOUT > 0 keep the math_mode kernels (they carry
+ * the mask code); shapes the single-product kernel does not cover (hidden width not a multiple of 256) fall back likewise. */
+int pn_set_forward_math(int mode);
+int pn_get_forward_math(void);
 /* Kernels of mode 1, a bit mask (default 7).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
  * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel.  Bit 1: dW = dz^T h
  * on the transpose-read kernel (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16) instead of the single-product

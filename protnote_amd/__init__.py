@@ -40,3 +40,17 @@ def get_backward_math() -> str:
     from . import _lib
 
     return _lib.get_backward_math()
+
+
+def set_forward_math(mode) -> None:
+    """"same" (default) or "bf16" for the forward pair-grid GEMMs of the output MLP's hidden layers (opt-in AMP class); see
+    include/protnote_hip.h pn_set_forward_math."""
+    from . import _lib
+
+    _lib.set_forward_math(mode)
+
+
+def get_forward_math() -> str:
+    from . import _lib
+
+    return _lib.get_forward_math()

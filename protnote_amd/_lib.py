@@ -45,7 +45,8 @@ class pn_pairhead(C.Structure):
                 ("w", C.c_void_p * PN_MAX_LAYERS), ("bias", C.c_void_p * PN_MAX_LAYERS),
                 ("bn", pn_bn * PN_MAX_LAYERS), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint),
-                ("bn_use_running", C.c_int), ("math_mode", C.c_int), ("backward_math", C.c_int)]
+                ("bn_use_running", C.c_int), ("math_mode", C.c_int), ("backward_math", C.c_int),
+                ("forward_math", C.c_int)]
 
 
 class pn_res_block_grads(C.Structure):
@@ -162,6 +163,8 @@ _SIGS = {
     "pn_get_math_mode": (C.c_int, []),
     "pn_set_backward_math": (C.c_int, [C.c_int]),
     "pn_get_backward_math": (C.c_int, []),
+    "pn_set_forward_math": (C.c_int, [C.c_int]),
+    "pn_get_forward_math": (C.c_int, []),
     "pn_set_bwd_deep": (C.c_int, [C.c_int]),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
     "pn_set_encoder_f64": (C.c_int, [C.c_int]),
@@ -227,6 +230,9 @@ def lib():
         mode = os.environ.get("PN_BACKWARD_MATH")
         if mode:
             set_backward_math(mode)
+        mode = os.environ.get("PN_FORWARD_MATH")
+        if mode:
+            set_forward_math(mode)
     return _lib
 
 
@@ -283,6 +289,32 @@ def backward_math_field(mode=None) -> int:
     key = str(mode).lower()
     if key not in _BWD_MODES:
         raise ValueError(f"backward math must be 'same' or 'bf16', got {mode!r}")
+    return 1 + _BWD_MODES[key]
+
+
+def set_forward_math(mode) -> None:
+    """Arithmetic of the FORWARD pair-grid GEMMs of the output MLP's hidden layers: "same" (default: math_mode's kernels)
+    or "bf16" (one bf16 product, f32 accumulation - the class of the reference's autocast forward,
+    ProtNoteTrainer.py:287,728-729).  Opt-in: logits move by ~1e-2 at O(1) scale (weight rounding), so this mode is held
+    to torch's own autocast(bfloat16) run of the oracle, not to the 1e-3 bound of "f32" / "bf16x3".  Stored activations,
+    BatchNorm statistics and the loss stay f32.  Also settable with PN_FORWARD_MATH."""
+    key = str(mode).lower()
+    if key not in _BWD_MODES:
+        raise ValueError(f"forward math must be 'same' or 'bf16', got {mode!r}")
+    check(lib().pn_set_forward_math(_BWD_MODES[key]))
+
+
+def get_forward_math() -> str:
+    return "bf16" if lib().pn_get_forward_math() == 1 else "same"
+
+
+def forward_math_field(mode=None) -> int:
+    """Value of pn_pairhead.forward_math (1 = as math_mode, 2 = bf16); None = the process default, read now."""
+    if mode is None:
+        return 1 + int(lib().pn_get_forward_math())
+    key = str(mode).lower()
+    if key not in _BWD_MODES:
+        raise ValueError(f"forward math must be 'same' or 'bf16', got {mode!r}")
     return 1 + _BWD_MODES[key]
 
 

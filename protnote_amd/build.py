@@ -42,14 +42,24 @@ def _obj(unit):
     return os.path.join(OBJ, os.path.splitext(unit)[0] + ".o")
 
 
+def _unit_stamp(unit) -> str:
+    """What an object file was made from: the compile flags and a sha256 over the unit, every csrc/*.hpp and the API header.
+    Written beside the object (`<obj>.flags`) and compared by CONTENT: file times do not survive the snapshot that travels
+    to the GPU box, so an object that merely looks newer than an edited source must not be relinked."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, unit), API] + headers():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return " ".join(_unit_flags(unit)) + "\nsrc=" + h.hexdigest()[:16]
+
+
 def _unit_stale(unit) -> bool:
     o = _obj(unit)
-    if not os.path.exists(o) or not os.path.exists(o + ".flags") or open(o + ".flags").read() != " ".join(_unit_flags(unit)):
+    if not os.path.exists(o) or not os.path.exists(o + ".flags"):
         return True
-    if unit == "build_hash.cpp":
-        return os.path.getmtime(os.path.join(CSRC, unit)) > os.path.getmtime(o)
-    t = os.path.getmtime(o)
-    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, unit), API] + headers())
+    return open(o + ".flags").read() != _unit_stamp(unit)
 
 
 def csrc_hash() -> str:
@@ -124,9 +134,10 @@ def _build_locked(hipcc, force, verbose):
         cmd = [hipcc] + _unit_flags(unit) + lang + ["-c", os.path.join(CSRC, unit), "-o", _obj(unit)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        stamp = _unit_stamp(unit)  # taken BEFORE the compile: an edit during it leaves a stamp that no longer matches
         subprocess.check_call(cmd)
         with open(_obj(unit) + ".flags", "w") as f:
-            f.write(" ".join(_unit_flags(unit)))
+            f.write(stamp)
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
         list(ex.map(compile_unit, UNITS))

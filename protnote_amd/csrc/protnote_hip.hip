@@ -399,6 +399,32 @@ struct BwdBf16Scope {
   }
 };
 
+// Arithmetic of the FORWARD pair-grid GEMMs of the hidden layers (z_l = h_{l-1} W_l^T, l >= 1): 0 = math_mode's kernels
+// (default), 1 = ONE product of the bf16-rounded operands with f32 accumulation - the class of the reference's autocast forward
+// (ProtNoteTrainer.py:287,728-729).  Per call through pn_pairhead.forward_math (0 = this process default, 1 = as math_mode,
+// 2 = bf16).  The stored pre-activations, the BatchNorm statistics and the row-dot stay f32: the backward does not change.
+static std::atomic<int> g_fwd_math{0};
+extern "C" int pn_set_forward_math(int mode) {
+  if (mode != 0 && mode != 1) return fail("pn_set_forward_math: 0 (as math_mode) or 1 (bf16, one product)");
+  g_fwd_math = mode;
+  return 0;
+}
+extern "C" int pn_get_forward_math(void) { return g_fwd_math; }
+// set by the pn_pairhead_fwd_* entry points around the hidden layers' GEMMs only; read by launch_gemm
+static thread_local bool tl_fwd_bf16 = false;
+struct FwdBf16Scope {
+  bool prev;
+  explicit FwdBf16Scope(bool on) : prev(tl_fwd_bf16) { tl_fwd_bf16 = on; }
+  ~FwdBf16Scope() { tl_fwd_bf16 = prev; }
+};
+static int fwd_math_of(const pn_pairhead* hd, bool* bf16) {
+  if (hd->forward_math < 0 || hd->forward_math > 2)
+    return fail("pairhead: forward_math %d (0 = library default, 1 = as math_mode, 2 = bf16)", hd->forward_math);
+  const int m = hd->forward_math == 0 ? g_fwd_math.load(std::memory_order_relaxed) : hd->forward_math - 1;
+  *bf16 = (m == 1) && hd->dropout_p == 0.f;
+  return 0;
+}
+
 // bf16x3 pair-grid GEMMs with the weight operand pre-split and staged by LDS-DMA; pn_set_b3_dma(0) keeps the register
 // path (the bit-identity test compares the two)
 static std::atomic<int> g_b3_dma{1};
@@ -650,6 +676,13 @@ static int launch_gemm(const GemmParams& p, int variant, hipStream_t st) {
       return launch_gemm_cfg<AK, EK, 2, 2, 2, 2, PN_BK, true>(p, st);
     } else {
       return fail("gemm: dropout is not defined for operand kind %d / epilogue %d", AK, EK);
+    }
+  }
+  if (tl_fwd_bf16 && PN_BIG) {  // forward_math = bf16: z_l = h_{l-1} W_l^T on one bf16 product (weight plane by LDS-DMA)
+    if constexpr ((AK == A_PLAIN || AK == A_AFFINE_RELU || AK == A_PAIRSUM_RELU) && (EK == E_STORE || EK == E_ROWDOT)) {
+      if (variant == 0 && p.nseg == 1 && p.Kseg % 32 == 0 && p.N % 256 == 0 && p.Nstore == p.N && p.wsplit != nullptr &&
+          p.lda % 4 == 0 && (AK != A_PAIRSUM_RELU || p.lda2 % 4 == 0))
+        return launch_gemm_bf16x3<AK, EK, 2, 4, false, true, 1>(p, st);
     }
   }
   if (tl_bwd_bf16 && PN_BIG) {  // pn_set_backward_math(1): dh = dz W on one bf16 product (weight plane by LDS-DMA)
@@ -1373,6 +1406,8 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
                                     void* stream) {
   PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_eval"));
   MathScope math_scope(hd->math_mode);
+  bool fwd_bf16 = false;
+  PN_OK(fwd_math_of(hd, &fwd_bf16));
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h, d = hd->d;
   if (hd->nlayers < 1 || hd->nlayers > PN_MAX_LAYERS) return fail("pairhead: nlayers=%d unsupported (need 1..%d)", hd->nlayers, PN_MAX_LAYERS);
@@ -1445,6 +1480,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
       in = w.z[zsel];
       zsel ^= 1;
     }
+    FwdBf16Scope fwd_scope(fwd_bf16);  // the hidden layers' pair-grid GEMMs below (the layer-1 GEMM of _prod above is not one)
     for (int li = 1; li < hd->nlayers; ++li) {
       const bool last = (li + 1 == hd->nlayers);
       const bool from_pairs = (li == 1) && !prod;
@@ -2252,6 +2288,8 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
                                      size_t ws_bytes, void* stream) {
   PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_train"));
   MathScope math_scope(hd->math_mode);
+  bool fwd_bf16 = false;
+  PN_OK(fwd_math_of(hd, &fwd_bf16));
   hipStream_t st = (hipStream_t)stream;
   PN_OK(pair_check(hd, B, NL));
   BnMode bn_mode(hd->bn_use_running != 0);
@@ -2336,12 +2374,15 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
       const DropSpec ds = drop_spec(hd->dropout_p, hd->dropout_seed, DROP_STREAM_PAIR + (l - 1));
       p.drop_seed = ds.seed; p.drop_thresh = ds.thresh; p.drop_scale = ds.scale;
     }
-    if (l == 1 && !prod) {
-      p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
-      PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
-    } else {
-      p.A = sv.zbuf[l - 1] + (size_t)S * h; p.lda = h; p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
-      PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+    {
+      FwdBf16Scope fwd_scope(fwd_bf16);
+      if (l == 1 && !prod) {
+        p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
+        PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));
+      } else {
+        p.A = sv.zbuf[l - 1] + (size_t)S * h; p.lda = h; p.a_scale = sv.s[l - 1]; p.a_shift = sv.t[l - 1];
+        PN_OK((launch_gemm<A_AFFINE_RELU, E_STORE>(p, 0, st)));
+      }
     }
     if (hd->bn[l].weight == nullptr) fold_nobn(l);
     else
@@ -2947,6 +2988,8 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
                                            void* stream) {
   PN_OK(math_field_check(hd->math_mode, "pn_pairhead_fwd_eval_hidden"));
   MathScope math_scope(hd->math_mode);
+  bool fwd_bf16 = false;
+  PN_OK(fwd_math_of(hd, &fwd_bf16));
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h;
   const long R = (long)B * NL;
@@ -2985,6 +3028,8 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
   GemmParams p = gp_zero();
   p.M = (int)R; p.N = h; p.Nstore = h; p.Kseg = h;
   p.W = hd->w[li]; p.ldw = h; p.C = zlast; p.ldc = h;
+  FwdBf16Scope fwd_scope(fwd_bf16);  // the same arithmetic as the logits of step 1
+  if (fwd_bf16) p.wsplit = w.wsplit;
   if (li == 1 && !prod) {
     p.A = w.A1; p.lda = h; p.A2 = w.B1; p.lda2 = h; p.pairB = B;
     PN_OK((launch_gemm<A_PAIRSUM_RELU, E_STORE>(p, 0, st)));

@@ -98,10 +98,13 @@ def input_dropout_p(seq) -> float:
 class ProtNote(nn.Module):
     _warned_eval_stored = False  # the eval-mode + autograd path warns once per process (see forward)
     # Arithmetic of THIS model's big GEMMs: None = the process default at call time (protnote_amd.set_math_mode /
-    # set_backward_math), or "f32" | "bf16x3" and "same" | "bf16".  Carried in every descriptor this model builds
-    # (pn_*.math_mode / pn_pairhead.backward_math), so models driven from different host threads can differ.
+    # set_backward_math / set_forward_math), or "f32" | "bf16x3" and "same" | "bf16".  Carried in every descriptor this model
+    # builds (pn_*.math_mode / pn_pairhead.backward_math / .forward_math), so models driven from different host threads can
+    # differ.  forward_math = "bf16" + backward_math = "bf16" is the reference's autocast arithmetic class
+    # (ProtNoteTrainer.py:287,728-738) for the pair-grid GEMMs of the output MLP; everything else follows math_mode.
     _math_mode = None
     backward_math = None
+    forward_math = None
 
     @property
     def math_mode(self):
@@ -217,6 +220,7 @@ class ProtNote(nn.Module):
         hd.bn_eps, hd.bn_momentum = eps, mom
         hd.math_mode = L.math_field(self.math_mode)
         hd.backward_math = L.backward_math_field(self.backward_math)
+        hd.forward_math = L.forward_math_field(self.forward_math)
         if drop_seed is not None and self.mlp_dropout > 0:
             hd.dropout_p, hd.dropout_seed = self.mlp_dropout, int(drop_seed)
         return hd, layers

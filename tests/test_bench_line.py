@@ -71,3 +71,59 @@ def test_emit_prints_detail_first_and_headline_last(tmp_path, monkeypatch):
     detail = json.loads(lines[0])["bench_detail"]
     assert detail["kernels"] == full["kernels"] and detail["stages"] == full["stages"]
     assert json.load(open(tmp_path / "bench_detail.json"))["kernels"] == full["kernels"]
+
+
+def test_headline_survives_broken_optional_blocks():
+    """an optional block that lacks a key (an empty forward_only entry, a zero_shot table without `roofline` or
+    `seconds`, a cpu_baseline in which no leg finished) must cost that block, never the contract keys."""
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", RECORDS[0])))
+    full["forward_only"]["bf16"] = {}
+    go = next(iter(full["zero_shot"]["f32"]))
+    full["zero_shot"]["f32"][go].pop("roofline")
+    full["zero_shot"]["bf16x3"][go].pop("seconds")
+    full["fast_mode"] = {"value": "n/a"}
+    full["amp_full"] = {"value": 7.5e6, "ms_per_step": 1100.0, "dtype": "x" * 30, "roofline": {"frac": 0.4}}
+    full["cpu_baseline"] = {"value": None, "unit": "protein-label pairs/s", "cores": None, "kind": "port", "legs": {},
+                            "sample": "no leg finished"}
+    h = json.loads(bench.headline(full))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "cpu_baseline", "config"):
+        assert k in h, k
+    assert h["modes"]["amp_full"]["roofline_frac"] == 0.4 and "forward_only.bf16" not in h["modes"]
+
+
+def test_cpu_baseline_legs_and_budget(monkeypatch):
+    """cpu_baseline starts its legs together (32 / 64 / half the host's threads, deduplicated on small hosts) under ONE budget;
+    a leg reports its largest finished sample; the best finished leg is the value.  The oracle step is stubbed: the real one
+    takes ~20 s per leg."""
+    import bench
+
+    assert bench.cpu_leg_threads(256) == [32, 64, 128] and bench.cpu_leg_threads(8) == [4, 8]
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            self.t = int(cmd[-1].rsplit("(", 1)[1].rstrip(")"))
+
+        def communicate(self, timeout=None):
+            import subprocess
+
+            if self.t == 128:  # never finishes B = 4: only the B = 2 line is on record
+                if timeout is not None and not getattr(self, "killed", False):
+                    self.partial = json.dumps({"B": 2, "pairs": 64204, "seconds": 9.0}) + "\n"
+                    raise subprocess.TimeoutExpired("x", timeout)
+                return self.partial, None
+            secs = {32: 21.0, 64: 16.0}[self.t]
+            return (json.dumps({"B": 2, "pairs": 64204, "seconds": secs / 1.8}) + "\n" +
+                    json.dumps({"B": 4, "pairs": 128408, "seconds": secs}) + "\n"), None
+
+        def kill(self):
+            self.killed = True
+
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    out = bench.cpu_baseline(budget=1.0)
+    assert set(out["legs"]) == {"32", "64", "128"} and all(v["value"] for v in out["legs"].values())
+    assert out["cores"] == 64 and out["value"] == pytest.approx(128408 / 16.0) and out["kind"] == "port"
+    assert out["legs"]["128"]["B"] == 2 and "not finished" in out["legs"]["128"]["note"]
+    assert "B=4" in out["sample"] and "64 threads" in out["sample"]

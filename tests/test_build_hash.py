@@ -119,3 +119,45 @@ def test_extra_compile_flags_are_part_of_the_hash(scratch, monkeypatch):
     assert build.csrc_hash() != h0 and build.stale()
     monkeypatch.delenv("PN_EXTRA_HIPCC_FLAGS")
     assert build.csrc_hash() == h0 and not build.stale()
+
+
+def test_objects_newer_than_an_edited_source_are_recompiled(scratch, monkeypatch):
+    """file times do not survive the snapshot to the GPU box, so objects can ARRIVE newer than an edited source.
+    Each unit's staleness is keyed on content (flags + sha256 of the unit, every header and the API header, kept in
+    <obj>.flags): the edited unit is recompiled, not relinked under a fresh build_hash.o.  The compile itself is stubbed."""
+    import subprocess
+    import time
+
+    os.makedirs(build.OBJ, exist_ok=True)
+    for u in build.UNITS:  # a finished build: objects + content stamps
+        open(build._obj(u), "wb").write(b"obj")
+        open(build._obj(u) + ".flags", "w").write(build._unit_stamp(u))
+    assert not any(build._unit_stale(u) for u in build.UNITS)
+    with open(scratch / "csrc" / "gemm_bf16.hpp", "a") as fh:
+        fh.write("\n// edited after the objects were made\n")
+    future = time.time() + 3600
+    for u in build.UNITS:  # ... and the objects look NEWER than every source, as after the snapshot
+        os.utime(build._obj(u), (future, future))
+        os.utime(build._obj(u) + ".flags", (future, future))
+    assert all(build._unit_stale(u) for u in build.UNITS)
+
+    compiled = []
+
+    def fake_call(cmd):
+        if "-c" in cmd:
+            compiled.append(os.path.basename(cmd[cmd.index("-c") + 1]))
+            open(cmd[cmd.index("-o") + 1], "wb").write(b"obj")
+        else:  # the link: a "binary" that carries the hash the sources have now
+            open(cmd[cmd.index("-o") + 1], "wb").write(build.HASH_MARKER + build.csrc_hash().encode())
+
+    monkeypatch.setattr(subprocess, "check_call", fake_call)
+    monkeypatch.setattr(build, "have_hipcc", lambda: "/bin/true")
+    build.build_lib(verbose=False)
+    assert sorted(compiled) == sorted(build.UNITS)
+    assert not build.stale() and not any(build._unit_stale(u) for u in build.UNITS)
+    # an edit of ONE translation unit recompiles that unit (and the hash carrier), nothing else
+    compiled.clear()
+    with open(scratch / "csrc" / "metrics.hip", "a") as fh:
+        fh.write("\n// edited\n")
+    build.build_lib(verbose=False)
+    assert sorted(compiled) == ["build_hash.cpp", "metrics.hip"]

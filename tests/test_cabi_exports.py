@@ -76,6 +76,14 @@ def test_error_convention(built_lib):
     assert rc != 0 and b"divisible" in lib.pn_last_error()
     with pytest.raises(RuntimeError, match="libprotnote_hip"):
         _lib.check(rc)
+    # descriptor fields are validated before anything is launched: an unknown forward_math / math_mode is an error
+    hd = _lib.pn_pairhead()
+    hd.nlayers, hd.h, hd.d, hd.math_mode, hd.forward_math = 3, 256, 64, 1, 7
+    rc = lib.pn_pairhead_fwd_eval(ctypes.byref(hd), None, None, 4, 4, None, 0, None, 0, None)
+    assert rc != 0 and b"forward_math" in lib.pn_last_error()
+    hd.forward_math, hd.math_mode = 2, 9
+    rc = lib.pn_pairhead_fwd_eval(ctypes.byref(hd), None, None, 4, 4, None, 0, None, 0, None)
+    assert rc != 0 and b"math_mode" in lib.pn_last_error()
 
 
 def test_grad_struct_sizes_match_c(built_lib, tmp_path):

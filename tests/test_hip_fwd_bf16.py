@@ -1,0 +1,346 @@
+"""forward_math = "bf16" (pn_set_forward_math / pn_pairhead.forward_math / model.forward_math): the hidden layers' FORWARD
+pair-grid GEMMs (z_l = h_{l-1} W_l^T, l >= 1) on ONE bf16 product with f32 accumulation - the arithmetic class of the
+reference's own GPU run, whose forward executes under torch.autocast (ProtNoteTrainer.py:287 eval, :728-729 train).  Together
+with backward_math = "bf16" (tests/test_hip_bwd_bf16.py) this completes the reference's mixed-precision class for the output
+MLP.  Opt-in and never the headline: rounding the h x h weights to bf16 alone moves O(1) logits by ~1e-2, so the yardstick
+here is torch's own autocast(bfloat16) run of the oracle's formulation against the float64 oracle, not the 1e-3 bound."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import protnote_oracle as O
+from tests.helpers import random_head_sd
+from tests.test_hip_bwd_bf16 import _full_width_model, _oracle_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle_eval(sd, P_f, lab, dtype, autocast=False, fusion="concatenation", ndesc=1):
+    """Eval-mode logits of the oracle's naive formulation run by stock torch on the device."""
+    ref_sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()).to(DEV) for k, v in sd.items()}
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if autocast else torch.autocast("cuda", enabled=False)
+    with torch.no_grad(), ctx:
+        lg = O.protnote_forward(ref_sd, None, None, lab.to(dtype).to(DEV), training=False, fusion=fusion,
+                                sequence_embeddings=P_f.to(dtype).to(DEV), descriptions_per_label=ndesc)
+    return lg.double().cpu()
+
+
+def _rel(a, ref):
+    return (a - ref).norm().item() / max(ref.norm().item(), 1e-30)
+
+
+@pytest.mark.parametrize("math_mode,bwd", [("f32", "same"), ("bf16x3", "same"), ("bf16x3", "bf16"), ("f32", "bf16")])
+def test_forward_bf16_step_vs_f64_with_autocast_yardstick(math_mode, bwd):
+    """Full-width head, 256 x 300 pairs, train mode (batch-statistics BatchNorm over the grid).  Against the float64 oracle:
+    (i) the logits of forward_math = "bf16" are within 2 x the error torch's own autocast(bfloat16) run of the oracle shows
+    (max and rms), and NOT equal to forward_math = "same" (the single-product kernels really ran); (ii) the loss agrees to
+    2e-3 relative; (iii) every gradient is within 2 x torch-autocast's error (the AMP criterion of the bf16 backward),
+    absolute cap 5e-2 - with the default backward behind it as well as with the bf16 backward."""
+    import protnote_amd
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(33)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 256, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64)
+    torch.cuda.empty_cache()
+    lg_amp, ls_amp, g_amp = _oracle_grads(sd, P_f, lab, y, torch.float32, autocast=True)
+    torch.cuda.empty_cache()
+    amp_max = (lg_amp - lg64).abs().max().item()
+    amp_rms = (lg_amp - lg64).pow(2).mean().sqrt().item()
+
+    model = _full_width_model(sd)
+
+    def run(fwd):
+        model.math_mode, model.forward_math, model.backward_math = math_mode, fwd, bwd
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+        loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+        loss.backward()
+        return logits.detach().double().cpu(), loss.item(), {n: p.grad.detach().double().cpu() for n, p in model.named_parameters()}
+
+    lg0, l0, g0 = run("same")
+    lg1, l1, g1 = run("bf16")
+    lg2, l2, g2 = run("bf16")
+    assert torch.equal(lg1, lg2) and l1 == l2 and all(torch.equal(g1[n], g2[n]) for n in g1)   # bit-reproducible
+    moved = (lg1 - lg0).abs().max().item()
+    assert moved > 1e-4, moved                                    # the single-product kernels ran
+    assert (lg0 - lg64).abs().max().item() < 1e-3                 # (the default forward stays inside the north-star bound)
+    e_max = (lg1 - lg64).abs().max().item()
+    e_rms = (lg1 - lg64).pow(2).mean().sqrt().item()
+    assert e_max <= 2.0 * amp_max and e_rms <= 2.0 * amp_rms, (e_max, amp_max, e_rms, amp_rms)   # (i)
+    assert abs(l1 - ls64) <= 2e-3 * abs(ls64), (l1, ls64, ls_amp)                               # (ii)
+    report = []
+    for name, ref in g64.items():
+        e_same, e_bf16, e_amp = _rel(g0[name], ref), _rel(g1[name], ref), _rel(g_amp[name], ref)
+        report.append((name, e_same, e_bf16, e_amp))
+        assert e_bf16 <= 2.0 * e_amp + 1e-6, (name, e_bf16, e_amp)                              # (iii)
+        assert e_bf16 < 5e-2, (name, e_bf16)
+    worst = max(report, key=lambda r: r[2])
+    print(f"[{math_mode}, forward bf16, backward {bwd}] logits vs f64: max {e_max:.2e} rms {e_rms:.2e} (torch autocast(bf16): max "
+          f"{amp_max:.2e} rms {amp_rms:.2e}; forward 'same': max {(lg0 - lg64).abs().max().item():.2e}); loss {l1:.6f} vs f64 "
+          f"{ls64:.6f} (autocast {ls_amp:.6f}); worst gradient {worst[0]}: {worst[2]:.2e} (forward 'same' {worst[1]:.2e}, "
+          f"autocast {worst[3]:.2e}); median ratio to autocast {float(np.median([r[2] / max(r[3], 1e-30) for r in report])):.3f}")
+
+
+@pytest.mark.parametrize("ndesc", [1, 2])
+def test_forward_bf16_eval_vs_f64_with_autocast_yardstick(ndesc):
+    """Eval mode (running-statistics BatchNorm, the fused inference kernels under no_grad, description ensembling): logits of
+    forward_math = "bf16" within 2 x torch-autocast's error against the float64 oracle, on the f32 and the bf16x3 base mode."""
+    gen = torch.Generator().manual_seed(35)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 256, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = _oracle_eval(sd, P_f, lab, torch.float64, ndesc=ndesc)
+    amp = _oracle_eval(sd, P_f, lab, torch.float32, autocast=True, ndesc=ndesc)
+    amp_max, amp_rms = (amp - ref).abs().max().item(), (amp - ref).pow(2).mean().sqrt().item()
+    model = _full_width_model(sd).eval()
+    model.inference_descriptions_per_label = ndesc
+    for math_mode in ("f32", "bf16x3"):
+        model.math_mode = math_mode
+        out = {}
+        for fwd in ("same", "bf16"):
+            model.forward_math = fwd
+            with torch.no_grad():
+                lg, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+            out[fwd] = lg.double().cpu()
+        assert out["bf16"].shape == (B, NL // ndesc)
+        assert (out["same"] - ref).abs().max().item() < 1e-3
+        e_max = (out["bf16"] - ref).abs().max().item()
+        e_rms = (out["bf16"] - ref).pow(2).mean().sqrt().item()
+        assert (out["bf16"] - out["same"]).abs().max().item() > 1e-4
+        assert e_max <= 2.0 * amp_max and e_rms <= 2.0 * amp_rms, (math_mode, e_max, amp_max, e_rms, amp_rms)
+        print(f"[eval, {math_mode}, ndesc {ndesc}] forward bf16 logits vs f64: max {e_max:.2e} rms {e_rms:.2e} "
+              f"(torch autocast(bf16): max {amp_max:.2e} rms {amp_rms:.2e})")
+
+
+def test_forward_bf16_map_parity():
+    """BASELINE metric 'mAP parity vs reference' with the AMP-class forward: micro / macro AP of the device metrics over
+    the HIP logits (full-width head, 256 x 300 pairs) against the AP of the CPU oracle's f32 logits and against the f32 HIP
+    path.  The reference's own seed-to-seed spread is mAP-micro +- 0.0013: |delta mAP| must stay below it."""
+    from oracle import metrics_oracle as MO
+    from protnote_amd.utils.evaluation import DeviceAveragePrecision
+
+    gen = torch.Generator().manual_seed(31)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 256, 300
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    ref = O.protnote_forward({k: v.clone() for k, v in sd.items()}, None, None, lab, sequence_embeddings=P_f)
+    y = (torch.rand(B, NL, generator=gen) < torch.sigmoid(2 * ref - 2)).numpy()
+    model = _full_width_model(sd).eval()
+    got = {}
+    for fwd in ("same", "bf16"):
+        model.forward_math = fwd
+        with torch.no_grad():
+            out, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+        acc = DeviceAveragePrecision(NL, B, DEV)
+        acc.update(torch.sigmoid(out), torch.from_numpy(y).to(DEV))
+        got[fwd] = acc.compute()
+    pr = torch.sigmoid(ref).numpy()
+    mi_ref = MO.average_precision_fast(pr.ravel(), y.ravel())
+    ma_ref = MO.macro_mean([MO.average_precision_fast(pr[:, j], y[:, j]) for j in range(NL)])
+    assert 0.2 < mi_ref < 0.99
+    d_mi = abs(got["bf16"]["map_micro"] - mi_ref)
+    d_ma = abs(got["bf16"]["map_macro"] - ma_ref)
+    print(f"mAP parity, forward bf16: micro {got['bf16']['map_micro']:.6f} (oracle {mi_ref:.6f}, f32 path "
+          f"{got['same']['map_micro']:.6f}; |delta| {d_mi:.2e}), macro {got['bf16']['map_macro']:.6f} (oracle {ma_ref:.6f}; "
+          f"|delta| {d_ma:.2e}); reference seed spread 1.3e-3")
+    assert d_mi < 1.3e-3 and d_ma < 2.6e-3, (got, mi_ref, ma_ref)
+
+
+def test_forward_bf16_training_tracks_f32():
+    """200 optimisation steps (fwd + bwd + clip + Adam) of the full-width head on a 64 x 1100 pair grid from the same
+    initial state: default arithmetic vs the full AMP class (forward bf16 + backward bf16).  Both learn; the loss
+    trajectories stay together."""
+    from protnote_amd.models.train_path import head_parameters
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+    from protnote_amd.utils.optim import FusedClipAdam
+
+    gen = torch.Generator().manual_seed(6)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 64, 1100
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    U = torch.randn(1100, 1024, generator=gen).to(DEV) / 1100 ** 0.5
+    y = ((P_f @ U @ lab.T) > 32.0).float()
+    assert 0.02 < y.mean().item() < 0.4
+
+    def run(fwd, bwd):
+        model = _full_width_model(sd)
+        model.forward_math, model.backward_math = fwd, bwd
+        opt = FusedClipAdam(head_parameters(model), lr=1e-4, max_norm=1.0)
+        losses = []
+        for _ in range(200):
+            logits, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            l = BCEWithLogitsLoss()(logits, y)
+            l.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(l.item())
+        return np.array(losses)
+
+    l32, lamp = run("same", "same"), run("bf16", "bf16")
+    assert l32[-1] < 0.5 * l32[0] and lamp[-1] < 0.5 * lamp[0], (l32[[0, -1]], lamp[[0, -1]])
+    dev = np.abs(lamp - l32) / np.maximum(l32, 1e-3)
+    print(f"200 steps: loss {l32[0]:.4f} -> {l32[-1]:.4f} (default), {lamp[0]:.4f} -> {lamp[-1]:.4f} (forward + backward bf16); "
+          f"max relative gap {dev.max():.3f}, first step {dev[0]:.2e}, at step 50 {dev[50]:.4f}")
+    assert dev[0] < 5e-3
+    assert dev[:50].max() < 0.05 and dev.max() < 0.25, (dev[:50].max(), dev.max())
+
+
+@pytest.mark.parametrize("B,NL,latent,scale,nl,fusion", [
+    (64, 1100, 512, 2, 2, "concatenation"),        # h = 1024, two hidden layers: ONE pair-grid GEMM, 4 column tiles
+    (96, 700, 256, 3, 3, "concatenation"),         # h = 768: 3 column tiles (no XCD regions)
+    (8, 333, 1024, 3, 3, "concatenation"),         # the reference's per-GPU batch: 2 664 pair rows = 10.4 row tiles
+    (64, 1100, 1024, 3, 3, "concatenation_diff"),  # effective first-layer weights
+    (64, 1100, 1024, 3, 3, "concatenation_prod"),  # z1 is a stored pair-grid GEMM (stays math_mode); layers 2, 3 take relu(bn(z))
+    (66, 1000, 1024, 3, 5, "concatenation"),       # five hidden layers: four single-product GEMMs in a row
+])
+def test_forward_bf16_other_shapes_vs_oracle(B, NL, latent, scale, nl, fusion):
+    """Other widths (any hidden width that is a multiple of 256), depths, fusions and grids: train step with the full AMP
+    class against the f64 oracle - logits 5e-2 (O(1) logits through up to four bf16 GEMMs), loss 5e-3, gradients 5e-2
+    (Frobenius) - plus eval logits; and every case is checked to have really left the f32 path."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(17)
+    h = latent * scale
+    in_mult = 2 if fusion == "concatenation" else 3
+    sd = random_head_sd(gen, 1100, 1024, latent, h, 2, h, nl, in_mult=in_mult)
+    P_f = torch.randn(B, 1100, generator=gen)
+    lab = torch.randn(NL, 1024, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64, fusion=fusion)
+    ev64 = _oracle_eval(sd, P_f, lab, torch.float64, fusion=fusion)
+    torch.cuda.empty_cache()
+    model = ProtNote(latent_dim=latent, output_mlp_hidden_dim_scale_factor=scale, output_mlp_num_layers=nl,
+                     projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=scale, feature_fusion=fusion)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    model.forward_math, model.backward_math = "bf16", "bf16"
+    logits, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(logits, y.to(DEV))
+    loss.backward()
+    err = (logits.detach().double().cpu() - lg64).abs().max().item()
+    assert 1e-5 < err < 5e-2, err
+    np.testing.assert_allclose(loss.item(), ls64, rtol=5e-3)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        rel = _rel(p.grad.double().cpu(), g64[name])
+        worst = max(worst, rel)
+        assert rel < 5e-2, (name, rel)
+    model.load_state_dict(sd)  # (the train-mode forward advanced the BatchNorm buffers)
+    model.eval()
+    with torch.no_grad():
+        ev, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    e_ev = (ev.double().cpu() - ev64).abs().max().item()
+    assert 1e-5 < e_ev < 5e-2, e_ev
+    print(f"[{fusion}, {B} x {NL}, h = {h}, {nl} hidden layers] forward + backward bf16: train logits {err:.2e}, eval logits "
+          f"{e_ev:.2e}, worst gradient {worst:.2e} vs f64")
+
+
+def test_forward_bf16_falls_back_where_the_kernel_does_not_apply():
+    """Hidden width not a multiple of 256 (h = 600): the single-product kernel does not cover the shape, the layer keeps
+    math_mode's kernels - logits bit-identical to forward_math = "same".  Likewise with OUTPUT_MLP_DROPOUT > 0 (the dropped
+    layers stay on the kernels that carry the mask code): same seed, same logits."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    gen = torch.Generator().manual_seed(3)
+    sd = random_head_sd(gen, 1100, 1024, 200, 600, 2, 600, 3)
+    P_f = torch.randn(40, 1100, generator=gen).to(DEV)
+    lab = torch.randn(90, 1024, generator=gen).to(DEV)
+    model = ProtNote(latent_dim=200, output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                     projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    outs = {}
+    for fwd in ("same", "bf16"):
+        model.forward_math = fwd
+        with torch.no_grad():
+            outs[fwd], _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+    assert torch.equal(outs["same"], outs["bf16"])
+
+    sd = random_head_sd(gen, 1100, 1024, 256, 768, 2, 768, 3)
+    model = ProtNote(latent_dim=256, output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=3,
+                     projection_head_num_layers=2, projection_head_hidden_dim_scale_factor=3, dropout=0.1)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    outs = {}
+    for fwd in ("same", "bf16"):
+        model.load_state_dict(sd)
+        model.forward_math = fwd
+        torch.manual_seed(123)
+        with torch.no_grad():
+            outs[fwd], _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+    assert torch.equal(outs["same"], outs["bf16"])
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_forward_bf16_saved_embeddings_belong_to_the_logits(training):
+    """save_embeddings=True (ProtNote.py:292-302) under forward_math = "bf16": the penultimate activations that come back are
+    the ones the logits were computed from (logit = hidden . w_out + b_out to f32 rounding), in eval mode (fused kernels +
+    pn_pairhead_fwd_eval_hidden) and in train mode (activation store)."""
+    gen = torch.Generator().manual_seed(12)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    B, NL = 24, 40
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    model = _full_width_model(sd)
+    model.train(training)
+    res = {}
+    for fwd in ("same", "bf16"):
+        model.load_state_dict(sd)
+        model.forward_math = fwd
+        with torch.no_grad():
+            lg, emb = model(sequence_embeddings=P_f, label_embeddings=lab, save_embeddings=True)
+        hid = emb["output_layer_embeddings"].double()
+        assert hid.shape == (B * NL, 3072)
+        w = sd["output_layer.11.weight"].double().reshape(-1)
+        b = sd["output_layer.11.bias"].double().item()
+        res[fwd] = (lg.double().cpu().reshape(-1), hid @ w + b, hid)
+        assert (res[fwd][0] - res[fwd][1]).abs().max().item() < 1e-4, fwd
+    assert (res["bf16"][2] - res["same"][2]).abs().max().item() > 1e-4  # and they are the bf16 forward's activations
+
+
+def test_forward_math_switches():
+    """The three ways to select the mode - process default (set_forward_math / PN_FORWARD_MATH), per model
+    (model.forward_math), per call (descriptor field) - and their error behaviour."""
+    import protnote_amd
+    from protnote_amd import _lib as L
+
+    assert protnote_amd.get_forward_math() == "same"
+    with pytest.raises(ValueError):
+        protnote_amd.set_forward_math("fp8")
+    assert L.lib().pn_set_forward_math(2) != 0 and b"pn_set_forward_math" in L.lib().pn_last_error()
+    gen = torch.Generator().manual_seed(5)
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    P_f = torch.randn(16, 1100, generator=gen).to(DEV)
+    lab = torch.randn(50, 1024, generator=gen).to(DEV)
+    model = _full_width_model(sd).eval()
+
+    def fwd():
+        with torch.no_grad():
+            return model(sequence_embeddings=P_f, label_embeddings=lab)[0]
+
+    base = fwd()
+    model.forward_math = "bf16"
+    per_model = fwd()
+    model.forward_math = None
+    protnote_amd.set_forward_math("bf16")
+    try:
+        assert protnote_amd.get_forward_math() == "bf16"
+        by_default = fwd()
+        model.forward_math = "same"   # an explicit per-model choice beats the process default
+        explicit_same = fwd()
+    finally:
+        protnote_amd.set_forward_math("same")
+        model.forward_math = None
+    assert torch.equal(per_model, by_default) and not torch.equal(per_model, base)
+    assert torch.equal(explicit_same, base)

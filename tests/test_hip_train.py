@@ -403,9 +403,10 @@ def test_full_size_train_step_vs_chunked_torch():
     run of the reference itself - the criterion of test_train_real_width_vs_oracle); the opt-in bf16x3 arithmetic is held
     to the same reference (logits 1e-3, gradients 4x as well), and so is the AMP-class bf16 BACKWARD behind either forward
     (pn_set_backward_math: logits bit-identical to the same forward mode; every gradient within max(4 x torch-f32, 2 x the
-    error of torch's own autocast(bfloat16) run of the oracle on a 256 x 300 sub-grid), cap 2e-2).  The encoder is not part of
-    this check (its
-    own full-size parity: test_full_size_eval_properties); both sides start from the same [256, 1100] embeddings."""
+    error of torch's own autocast(bfloat16) run of the oracle on a 256 x 300 sub-grid), cap 2e-2), and - round 6 - the
+    AMP-class bf16 FORWARD (pn_set_forward_math) with either backward behind it: all 8.2 M logits within 2 x the error of that
+    same autocast run (max and rms), gradients by the AMP criterion, cap 5e-2.  The encoder is not part of this check (its own
+    full-size parity: test_full_size_eval_properties); both sides start from the same [256, 1100] embeddings."""
     import protnote_amd
     from bench import build_model, synthetic_batch
     from protnote_amd.utils.losses import BCEWithLogitsLoss
@@ -421,13 +422,16 @@ def test_full_size_train_step_vs_chunked_torch():
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("sequence_encoder.")}
     model.train()
     got = {}
-    # (forward arithmetic, backward arithmetic): the two default-backward modes, then the AMP-class bf16 backward
-    # (pn_set_backward_math) behind each forward - round 4 only ever compared that one with the default backward
-    MODES = (("f32", "same"), ("bf16x3", "same"), ("bf16x3", "bf16"), ("f32", "bf16"))
-    for mode, bwd in MODES:
+    # (math_mode, backward arithmetic, forward arithmetic of the hidden pair-grid GEMMs): the two default modes, the AMP-class
+    # bf16 backward (pn_set_backward_math) behind each forward, and - round 6 - the AMP-class bf16 FORWARD (pn_set_forward_math)
+    # with the bf16 and with the default backward behind it
+    MODES = (("f32", "same", "same"), ("bf16x3", "same", "same"), ("bf16x3", "bf16", "same"), ("f32", "bf16", "same"),
+             ("bf16x3", "bf16", "bf16"), ("bf16x3", "same", "bf16"))
+    for mode, bwd, fwd in MODES:
         model.load_state_dict(sd0, strict=False)
         protnote_amd.set_math_mode(mode)
         protnote_amd.set_backward_math(bwd)
+        protnote_amd.set_forward_math(fwd)
         try:
             for p in model.parameters():
                 p.grad = None
@@ -435,16 +439,20 @@ def test_full_size_train_step_vs_chunked_torch():
             loss = BCEWithLogitsLoss()(logits, y)
             loss.backward()
             # (bf16-backward entries keep their logits only long enough for the bit-identity check below: 33 MB each)
-            got[(mode, bwd)] = (logits.detach().clone(), float(loss),
-                                {k: v.detach().clone() for k, v in model.state_dict().items()
-                                 if k.endswith(("running_mean", "running_var")) and not k.startswith("sequence_encoder.")},
-                                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            got[(mode, bwd, fwd)] = (logits.detach().clone(), float(loss),
+                                     {k: v.detach().clone() for k, v in model.state_dict().items()
+                                      if k.endswith(("running_mean", "running_var")) and not k.startswith("sequence_encoder.")},
+                                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
         finally:
+            protnote_amd.set_forward_math("same")
             protnote_amd.set_backward_math("same")
             protnote_amd.set_math_mode("f32")
     del logits, loss
     for mode in ("f32", "bf16x3"):  # the backward arithmetic does not touch the forward: logits and loss bit-identical
-        assert torch.equal(got[(mode, "bf16")][0], got[(mode, "same")][0]) and got[(mode, "bf16")][1] == got[(mode, "same")][1]
+        assert torch.equal(got[(mode, "bf16", "same")][0], got[(mode, "same", "same")][0])
+        assert got[(mode, "bf16", "same")][1] == got[(mode, "same", "same")][1]
+    assert torch.equal(got[("bf16x3", "bf16", "bf16")][0], got[("bf16x3", "same", "bf16")][0])
+    assert not torch.equal(got[("bf16x3", "bf16", "bf16")][0], got[("bf16x3", "bf16", "same")][0])
     for p in model.parameters():
         p.grad = None
     model.__dict__.pop("_pn_train_save", None)  # 2 x 101 GB of stored pre-activations: not needed beside the reference
@@ -474,44 +482,58 @@ def test_full_size_train_step_vs_chunked_torch():
 
     sd_cpu = {k: v.detach().cpu() for k, v in sd0.items()}
     sub = (P_f.cpu(), batch["label_embeddings"][:300].cpu(), y[:, :300].cpu())
-    _, _, g64_sub = _oracle_grads(sd_cpu, *sub, torch.float64)
+    lg64_sub, _, g64_sub = _oracle_grads(sd_cpu, *sub, torch.float64)
     torch.cuda.empty_cache()
-    _, _, gamp_sub = _oracle_grads(sd_cpu, *sub, torch.float32, autocast=True)
+    lgamp_sub, _, gamp_sub = _oracle_grads(sd_cpu, *sub, torch.float32, autocast=True)
     torch.cuda.empty_cache()
     amp_err = {n: (gamp_sub[n] - g64_sub[n]).norm().item() / max(g64_sub[n].norm().item(), 1e-30) for n in g64_sub}
-    del g64_sub, gamp_sub
+    amp_logit_err = (lgamp_sub - lg64_sub).abs().max().item()   # the yardstick of the AMP-class FORWARD
+    amp_logit_rms = (lgamp_sub - lg64_sub).pow(2).mean().sqrt().item()
+    del g64_sub, gamp_sub, lg64_sub, lgamp_sub
     bad = []
     # measured (round 3): logits 2.2e-4 (f32) / 2.4e-4 (bf16x3) against 1.05e-4 for torch's own f32 run; every gradient
     # 0.2x..1.9x the torch-f32 run's error in BOTH modes (W_p.* ~1e-2 for HIP and torch alike: with 32 102 labels per protein
     # the protein-side gradient is all common mode, see test_train_real_width_vs_oracle)
-    for (mode, bwd), tol, factor, cap in ((("f32", "same"), 5e-4, 4.0, 2e-2), (("bf16x3", "same"), 1e-3, 4.0, 2e-2),
-                                          (("bf16x3", "bf16"), 1e-3, 4.0, 2e-2), (("f32", "bf16"), 5e-4, 4.0, 2e-2)):
-        lg, loss, bufs, grads = got[(mode, bwd)]
+    for (mode, bwd, fwd), tol, factor, cap in ((("f32", "same", "same"), 5e-4, 4.0, 2e-2), (("bf16x3", "same", "same"), 1e-3, 4.0, 2e-2),
+                                               (("bf16x3", "bf16", "same"), 1e-3, 4.0, 2e-2), (("f32", "bf16", "same"), 5e-4, 4.0, 2e-2),
+                                               (("bf16x3", "bf16", "bf16"), None, 4.0, 5e-2), (("bf16x3", "same", "bf16"), None, 4.0, 5e-2)):
+        lg, loss, bufs, grads = got[(mode, bwd, fwd)]
         err = (lg.double() - ref).abs().max().item()
-        assert err < tol, (mode, err, f32_logit_err)
-        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (mode, loss, ref_loss)
+        rms = (lg.double() - ref).pow(2).mean().sqrt().item()
+        if fwd == "bf16":
+            # AMP-class forward: all 8.2 M logits within 2 x the error torch's own autocast(bfloat16) run of the oracle shows
+            # on the 256 x 300 sub-grid (max over 107 x fewer pairs - the rms is the like-for-like figure and is held as well)
+            assert err <= 2.0 * amp_logit_err and rms <= 2.0 * amp_logit_rms, (mode, fwd, err, amp_logit_err, rms, amp_logit_rms)
+            assert abs(loss - ref_loss) < 2e-3 * max(1.0, abs(ref_loss)), (mode, loss, ref_loss)
+        else:
+            assert err < tol, (mode, err, f32_logit_err)
+            assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (mode, loss, ref_loss)
         assert len(bufs) == 2 * (3 + 3 + 3)
         for k, v in bufs.items():
-            np.testing.assert_allclose(v.cpu().numpy(), sd[k].float().cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=f"{mode} {k}")
+            # (bf16 forward: the statistics of z_2, z_3 are f32 sums of values that carry the operands' bf16 rounding)
+            loose = fwd == "bf16" and k.startswith("output_layer.")
+            np.testing.assert_allclose(v.cpu().numpy(), sd[k].float().cpu().numpy(), atol=2e-3 if loose else 1e-5,
+                                       rtol=5e-3 if loose else 1e-4, err_msg=f"{mode} {k}")
         assert set(grads) == set(ref_grads)
         worst = ("", 0.0, 0.0)
         for n, gr in grads.items():
             rel = (gr.double() - ref_grads[n]).norm().item() / scale[n]
-            print(f"full-size grad-err [{mode}, backward {bwd}] {n}: hip {rel:.2e} torch-f32 {f32_err[n]:.2e} ratio {rel / max(f32_err[n], 1e-30):.2f}")
+            print(f"full-size grad-err [{mode}, forward {fwd}, backward {bwd}] {n}: hip {rel:.2e} torch-f32 {f32_err[n]:.2e} ratio {rel / max(f32_err[n], 1e-30):.2f}")
             if rel / max(f32_err[n], 1e-30) > worst[2]:
                 worst = (n, rel, rel / max(f32_err[n], 1e-30))
             # same criterion as the small-grid tests: within `factor` x the error of an f32 run of the reference algorithm
-            # itself against float64, and an absolute cap.  bf16 backward: the AMP criterion - within 2 x torch-autocast's
-            # error (sub-grid yardstick above) where that is the larger allowance (tensors whose f32 error at this size is
-            # already common-mode dominated, W_p.*, keep the f32 allowance), same absolute cap
+            # itself against float64, and an absolute cap.  bf16 backward / forward: the AMP criterion - within 2 x
+            # torch-autocast's error (sub-grid yardstick above) where that is the larger allowance (tensors whose f32 error at
+            # this size is already common-mode dominated, W_p.*, keep the f32 allowance), same absolute cap
             allow = max(factor * f32_err[n], 1e-6)
-            if bwd == "bf16":
+            if bwd == "bf16" or fwd == "bf16":
                 allow = max(allow, 2.0 * amp_err[n] + 1e-6)
-                print(f"full-size grad-err [{mode}+bf16 backward] {n}: torch-autocast(bf16) yardstick (256 x 300) {amp_err[n]:.2e}")
+                print(f"full-size grad-err [{mode}, forward {fwd}, backward {bwd}] {n}: torch-autocast(bf16) yardstick (256 x 300) {amp_err[n]:.2e}")
             if not (rel < allow and rel < cap):
-                bad.append((mode, bwd, n, rel, f32_err[n], amp_err[n]))
-        mode = f"{mode}, backward {bwd}"
-        print(f"full-size train step [{mode}]: max |logit - f64 reference| = {err:.2e} (torch-f32 reference: {f32_logit_err:.2e}), "
+                bad.append((mode, bwd, fwd, n, rel, f32_err[n], amp_err[n]))
+        mode = f"{mode}, forward {fwd}, backward {bwd}"
+        print(f"full-size train step [{mode}]: max |logit - f64 reference| = {err:.2e}, rms {rms:.2e} (torch-f32 reference: {f32_logit_err:.2e}; "
+              f"torch-autocast(bf16) on 256 x 300: max {amp_logit_err:.2e} rms {amp_logit_rms:.2e}), "
               f"loss {loss:.7f} vs {ref_loss:.7f}, worst gradient ratio {worst[0]}: {worst[1]:.2e} = {worst[2]:.2f} x torch-f32")
     assert not bad, bad
 
