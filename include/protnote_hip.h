@@ -38,6 +38,10 @@ extern "C" {
 
 #define PN_MAX_BLOCKS 16
 #define PN_MAX_LAYERS 8
+/* element types of a multihot label / target array (pn_loss_fwd_bwd_t, pn_tp_fn_fp_t, the metrics entry points) */
+#define PN_LABEL_F32 0
+#define PN_LABEL_I64 1
+#define PN_LABEL_U8 2
 
 const char* pn_last_error(void);
 int pn_version(void);
@@ -87,6 +91,26 @@ size_t pn_encoder_ws_bytes(const pn_encoder* enc, int B, int L);
  * "frozen" encoder behaves under model.train() (ProtNoteTrainer.py:844). */
 int pn_encoder_fwd(const pn_encoder* enc, const float* onehots, const int64_t* lens, int B, int L,
                    float* emb, int ld_emb, int training, void* ws, size_t ws_bytes, void* stream);
+
+/* MaskedConv1D.forward (protein_encoders.py:8-17) called stand-alone: x [B][Cin][L] f32, lens [B] i64 -> out [B][Cout][L];
+ * input and output zeroed at positions >= len.  w_packed from pn_pack_conv_weight.  (ProteInfer never calls this: pn_encoder_fwd
+ * runs the convolutions fused and channels-last.) */
+size_t pn_masked_conv1d_ws_bytes(int B, int L, int Cin, int Cout);
+int pn_masked_conv1d_fwd(const float* x, const int64_t* lens, const float* w_packed, const float* bias, int B, int Cin, int Cout,
+                         int L, int ksize, int dilation, float* out, void* ws, size_t ws_bytes, void* stream);
+/* Residual.forward (protein_encoders.py:61-67) called stand-alone: x [B][C][L] -> out [B][C][L] =
+ * masked_conv2(relu(bn2(masked_conv1(relu(bn1(x)))))) + x.  As in the reference bn1 sees the RAW input (train-mode statistics
+ * run over all B*L positions, pads included) and the residual adds it back unmasked: positions >= len of `out` hold x.
+ * training != 0: batch statistics, running statistics updated (momentum 0.01, eps 1e-3). */
+size_t pn_residual_ws_bytes(int B, int L, int C, int Cb);
+int pn_residual_fwd(const pn_res_block* blk, int C, int Cb, int ksize, int dilation, const float* x, const int64_t* lens, int B,
+                    int L, float* out, int training, void* ws, size_t ws_bytes, void* stream);
+
+/* ProteInfer.get_embeddings from residue IDS: ids = the batch's residue indices back to back (uint8), offsets [B+1] i64 (the
+ * input of pn_onehot_batch - what the device-side collator holds).  Bit-identical to pn_onehot_batch + pn_encoder_fwd without
+ * the [B][Cin][L] one-hot tensor; needs the gather form of conv1 (kernel_size 9, Cin <= 27) and a frozen encoder. */
+int pn_encoder_fwd_ids(const pn_encoder* enc, const uint8_t* ids, const int64_t* offsets, int B, int L, float* emb, int ld_emb,
+                       int training, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- row MLPs W_p / W_l: torchvision.ops.MLP built at protnote/models/ProtNote.py:63-81 ---- */
 typedef struct pn_mlp {
@@ -185,6 +209,10 @@ int pn_ensemble_logit_bwd(const float* logits, const float* dout, int B, int NL,
 
 /* ProtNote.py:219-240: out = L_f + (2u - 1) * scale, scale = alpha / sqrt(d); u ~ U[0,1) from the caller. */
 int pn_label_noise(const float* L_f, const float* u, float scale, float* out, long n, void* stream);
+/* ... with u drawn inside the kernel from a counter hash of (seed, row, column) - no tensor of uniforms exists - and the hook
+ * that hands a test (or the oracle) the very same u [rows][cols] (24-bit uniforms in [0, 1), like torch's float uniform). */
+int pn_label_noise_seeded(const float* L_f, unsigned seed, float scale, float* out, long rows, int cols, void* stream);
+int pn_uniform(unsigned seed, long rows, int cols, float* out, void* stream);
 
 /* ---- similarity head, ProtNote.py:281-284 ---- */
 size_t pn_similarity_ws_bytes(int B, int NL);
@@ -279,6 +307,15 @@ int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t
                     float* loss_out, float* dlogits, float* tp, float* fn, float* fp, int weight_mode,
                     const float* label_weights, float rgd_temperature, void* ws, size_t ws_bytes, void* stream);
 
+/* The same pass with the targets as ONE typed pointer: target_kind = PN_LABEL_F32 | PN_LABEL_I64 | PN_LABEL_U8 (defined with the
+ * metrics below).  A multihot is 1 B of information per pair; the reference's collator hands int64 (collators.py:136-137, row
+ * (a)14 - still the default of the Python twin), PN_LABEL_U8 lets a caller that keeps its multihots as bytes
+ * (collate_to_device(multihot_dtype=torch.uint8)) pay the algorithmic 1 B instead of 8.  Same arithmetic, bit for bit. */
+int pn_loss_fwd_bwd_t(const float* logits, const void* targets, int target_kind, int B, int N, int kind, float pos_weight,
+                      float gamma, float alpha, float smoothing, float threshold, float* loss_out, float* dlogits, float* tp,
+                      float* fn, float* fp, int weight_mode, const float* label_weights, float rgd_temperature, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* LOSS_FN: SupCon (utils/losses.py:7-56, one_way_supcon over the label axis; the reference marks it unused and never
  * reads its temperature): loss = -mean_i [ sum_j y_ij log_softmax_j(x_i) / n_i ], rows without positives count 0 in the
  * loss and - as in the reference's autograd - NaN in the gradient.  ws >= pn_supcon_ws_bytes(B). */
@@ -289,6 +326,10 @@ int pn_supcon_fwd_bwd(const float* logits, const float* targets_f32, const int64
 /* calculate_tp_fn_fp (ProtNoteTrainer.py:61-83) on probabilities; outputs are overwritten. */
 int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
                 float threshold, float* tp, float* fn, float* fp, void* stream);
+
+/* ... with typed targets (see pn_loss_fwd_bwd_t) */
+int pn_tp_fn_fp_t(const float* probs, const void* targets, int target_kind, int B, int N, float threshold, float* tp, float* fn,
+                  float* fp, void* stream);
 
 /* clip_grad_norm_(max_norm) + Adam / AdamW step on flat f32 buffers (ProtNoteTrainer.py:745-755);
  * max_norm <= 0 disables clipping; norm_out (optional, [1]) receives the total gradient norm.
@@ -322,9 +363,6 @@ int pn_onehot_batch(const uint8_t* ids, const int64_t* offsets, int B, int A, in
  * Replaces the per-batch D2H + CPU torcheval BinaryAUPRC / MultilabelAUPRC of ProtNoteTrainer.py:477-485,540-543
  * (ESTIMATE_MAP False: exact) and the on-device Binary/MultilabelBinnedAUPRC(threshold=50) (ESTIMATE_MAP True),
  * and torchmetrics AveragePrecision of utils/evaluation.py:148-169.  Label element types: */
-#define PN_LABEL_F32 0
-#define PN_LABEL_I64 1
-#define PN_LABEL_U8 2
 
 /* Exact AP.  The accumulator is label-major and stays in HBM for the whole evaluation: keys [N_L][cap] u32
  * (order-preserving image of the f32 score), hits [N_L][cap] u8.  pn_ap_append transposes one batch

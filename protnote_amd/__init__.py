@@ -54,3 +54,48 @@ def get_forward_math() -> str:
     from . import _lib
 
     return _lib.get_forward_math()
+
+
+# reference module path -> twin module; a reference module without an entry here is outside the
+# hot path and is NOT aliased
+_PROTNOTE_ALIASES = {
+    "protnote": "protnote_amd",
+    "protnote.models": "protnote_amd.models",
+    "protnote.models.ProtNote": "protnote_amd.models.ProtNote",
+    "protnote.models.protein_encoders": "protnote_amd.models.protein_encoders",
+    "protnote.models.ProtNoteTrainer": "protnote_amd.models.ProtNoteTrainer",
+    "protnote.utils": "protnote_amd.utils",
+    "protnote.utils.losses": "protnote_amd.utils.losses",
+    "protnote.utils.models": "protnote_amd.utils.models",
+    "protnote.utils.configs": "protnote_amd.utils.configs",
+    "protnote.utils.proteinfer": "protnote_amd.utils.proteinfer",
+    "protnote.utils.evaluation": "protnote_amd.utils.evaluation",
+    "protnote.data": "protnote_amd.data",
+    "protnote.data.collators": "protnote_amd.data.collators",
+    "protnote.data.samplers": "protnote_amd.data.samplers",
+}
+
+
+def install_as_protnote(force: bool = False):
+    """Make `from protnote.models.ProtNote import ProtNote`, `from protnote.models.protein_encoders import ProteInfer`,
+    `from protnote.utils.losses import get_loss` (the imports of reference bin/main.py:9-11) and the other hot-path module
+    paths resolve to the protnote_amd twins: the `sys.modules` aliasing of INTEGRATION.md section 1, as one call made before
+    the caller's own imports.  Refuses to shadow a real `protnote` package that is already imported (or importable) unless
+    `force=True`.  Returns the list of aliased module names."""
+    import importlib
+    import importlib.util
+    import sys
+
+    if not force:
+        mod = sys.modules.get("protnote")
+        if mod is not None and getattr(mod, "__name__", "") != "protnote_amd":
+            raise RuntimeError("a different `protnote` package is already imported; call install_as_protnote(force=True) "
+                               "before importing it, or remove it from the path")
+        if mod is None and importlib.util.find_spec("protnote") is not None:
+            raise RuntimeError("a real `protnote` package is importable from sys.path; install_as_protnote(force=True) "
+                               "shadows it for this process")
+    done = []
+    for ref, twin in _PROTNOTE_ALIASES.items():
+        sys.modules[ref] = importlib.import_module(twin)
+        done.append(ref)
+    return done

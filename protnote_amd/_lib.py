@@ -78,6 +78,12 @@ _SIGS = {
     "pn_encoder_ws_bytes": (C.c_size_t, [C.POINTER(pn_encoder), C.c_int, C.c_int]),
     "pn_encoder_fwd": (C.c_int, [C.POINTER(pn_encoder), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_masked_conv1d_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pn_masked_conv1d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pn_residual_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pn_residual_fwd": (C.c_int, [C.POINTER(pn_res_block), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_mlp_rows_ws_bytes": (C.c_size_t, [C.POINTER(pn_mlp), C.c_int]),
     "pn_mlp_rows_fwd_eval": (C.c_int, [C.POINTER(pn_mlp), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]),
@@ -95,6 +101,10 @@ _SIGS = {
     "pn_ensemble_logit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_ensemble_logit_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pn_label_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
+    "pn_label_noise_seeded": (C.c_int, [C.c_void_p, C.c_uint, C.c_float, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
+    "pn_uniform": (C.c_int, [C.c_uint, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "pn_encoder_fwd_ids": (C.c_int, [C.POINTER(pn_encoder), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pn_similarity_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pn_similarity_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -129,6 +139,12 @@ _SIGS = {
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "pn_loss_fwd_bwd_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "pn_tp_fn_fp_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "pn_supcon_ws_bytes": (C.c_size_t, [C.c_int]),
     "pn_supcon_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -316,6 +332,20 @@ def forward_math_field(mode=None) -> int:
     if key not in _BWD_MODES:
         raise ValueError(f"forward math must be 'same' or 'bf16', got {mode!r}")
     return 1 + _BWD_MODES[key]
+
+
+PN_LABEL_F32, PN_LABEL_I64, PN_LABEL_U8 = 0, 1, 2
+
+
+def typed_targets(target):
+    """(tensor to keep alive, PN_LABEL_* kind) for a multihot target tensor: int64 (the reference collator's dtype) and uint8 /
+    bool (1 B per pair) go to the kernels as they are, anything else as float32."""
+    if target.dtype == torch.int64:
+        return target.contiguous(), PN_LABEL_I64
+    if target.dtype in (torch.uint8, torch.bool):
+        t = target.contiguous()
+        return (t.view(torch.uint8) if t.dtype == torch.bool else t), PN_LABEL_U8
+    return target.detach().float().contiguous(), PN_LABEL_F32
 
 
 def check(rc: int):

@@ -1101,8 +1101,28 @@ extern "C" size_t pn_encoder_train_save_bytes(const pn_encoder* enc, int B, int 
   return bp.off + 256;
 }
 
+// ragged residue ids (back to back, uint8) + offsets [B+1] -> padded ids [B*L] int8 (-1 = pad, or a residue outside the
+// alphabet: an all-zero one-hot column) and int32 lengths: what k_onehot_ids derives from one-hots, without the one-hots
+__global__ void k_ids_pad(const uint8_t* __restrict__ flat, const int64_t* __restrict__ offsets, int B, int L, int Cin,
+                          signed char* __restrict__ ids, int* __restrict__ lens32) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)B * L) return;
+  const int b = (int)(p / L), t = (int)(p - (long)b * L);
+  const int64_t off = offsets[b];
+  long len = (long)(offsets[b + 1] - off);
+  if (len > L) len = L;
+  int id = -1;
+  if (t < len) {
+    const int v = (int)flat[off + t];
+    id = v < Cin ? v : -1;
+  }
+  ids[p] = (signed char)id;
+  if (t == 0) lens32[b] = (int)len;
+}
+
 static int encoder_forward(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L, float* emb,
-                           int ld_emb, int training, EncWs& w, EncSave* sv, hipStream_t st) {
+                           int ld_emb, int training, EncWs& w, EncSave* sv, hipStream_t st,
+                           const uint8_t* flat_ids = nullptr, const int64_t* id_offsets = nullptr) {
   const long P = (long)B * L;
   if (P > 0x7fffffffL) return fail("encoder: B*L too large");
   const int ldc = ld4(e->C), ldb = ld4(e->Cb), ldi = ld4(e->Cin);
@@ -1110,7 +1130,15 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
   int* lens32 = sv ? sv->lens32 : w.lens32;
   float* x0 = sv ? sv->x0 : w.x0;
 
-  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, lens32, B);
+  const bool from_ids = flat_ids != nullptr;  // pn_encoder_fwd_ids: conv1 is the gather-sum, no one-hot tensor exists
+  if (from_ids) {
+    if (sv != nullptr || !g_conv1_gather || w.ids == nullptr || !conv1_gather_shape(e))
+      return fail("encoder (ids): needs the gather form of conv1 (kernel_size 9, alphabet <= 27, pn_set_conv1_gather on, "
+                  "frozen encoder); pass one-hots to pn_encoder_fwd otherwise");
+    hipLaunchKernelGGL(k_ids_pad, dim3(nblk(P, 256)), dim3(256), 0, st, flat_ids, id_offsets, B, L, e->Cin, w.ids, lens32);
+  } else {
+    hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, lens32, B);
+  }
   HIP_OK(hipGetLastError());
 
   const int* conv_run_if = nullptr;  // set around conv1: the general kernel is a no-op while the flag is 0
@@ -1193,8 +1221,9 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
         attr_done[dev] = true;
       }
       HIP_OK(hipMemsetAsync(w.oh_flag, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_onehot_ids, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, w.ids, w.oh_flag, B,
-                         e->Cin, L);
+      if (!from_ids)
+        hipLaunchKernelGGL(k_onehot_ids, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, w.ids, w.oh_flag, B,
+                           e->Cin, L);
       hipLaunchKernelGGL(k_conv1_relay, dim3(nblk((long)e->ksize * e->Cin * ldc, 256)), dim3(256), 0, st, e->conv1_w, e->C,
                          e->ksize, e->Cin, ldi, w.W1t, ldc);
       hipLaunchKernelGGL(k_conv1_gather<9>, dim3(nblk(ldc, CONV1_GATHER_CS), nblk(nblk(P, BM), tiles)), dim3(512), lds, st,
@@ -1203,12 +1232,19 @@ static int encoder_forward(const pn_encoder* e, const float* onehots, const int6
       HIP_OK(hipGetLastError());
       conv_run_if = w.oh_flag;
     }
-    // channels-last copy of the input: operand of the general kernel, and of the conv1 weight gradient (sv)
-    hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
-                       L, ldi, (gather && sv == nullptr) ? (const int*)w.oh_flag : (const int*)nullptr);
-    HIP_OK(hipGetLastError());
-    PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
-               training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+    if (!from_ids) {  // (from ids the input IS one-hot by construction: the general kernel has nothing to do)
+      // channels-last copy of the input: operand of the general kernel, and of the conv1 weight gradient (sv)
+      hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, onehots, (const int*)lens32, x0, B, e->Cin,
+                         L, ldi, (gather && sv == nullptr) ? (const int*)w.oh_flag : (const int*)nullptr);
+      HIP_OK(hipGetLastError());
+      PN_OK(conv(x0, ldi, e->conv1_w, e->conv1_b, e->C, ldc, x, e->ksize, 1, nullptr, nullptr, nullptr,
+                 training ? w.sum_x : nullptr, training ? w.sq_x : nullptr));
+    } else if (training) {  // column statistics of conv1's output from the gather kernel's per-tile partials (as conv() does)
+      GemmParams p = gp_zero();
+      p.M = (int)P; p.N = e->C; p.col_sum = w.sum_x; p.col_sumsq = w.sq_x; p.col_part = w.cs.part; p.col_red = w.cs.red;
+      const bool big = PN_BIG && ldc >= 512 && P >= 4096;
+      PN_OK(finish_col_stats(p, (P + (big ? 256 : 128) - 1) / (big ? 256 : 128), st));
+    }
     conv_run_if = nullptr;
   }
 
@@ -1273,6 +1309,23 @@ extern "C" int pn_encoder_fwd(const pn_encoder* e, const float* onehots, const i
   return encoder_forward(e, onehots, lens, B, L, emb, ld_emb, training, w, nullptr, (hipStream_t)stream);
 }
 
+// The same forward from residue ids: `ids` = the batch's residue indices back to back (uint8), `offsets` [B+1] i64 - the input
+// of pn_onehot_batch, i.e. what collate_to_device already holds on the device.  Equivalent to pn_onehot_batch followed by
+// pn_encoder_fwd (sequences longer than L are cut to L; an id >= Cin is an all-zero column), bit for bit, without the
+// [B][Cin][L] f32 one-hot tensor and the two passes that re-derive the ids from it.
+extern "C" int pn_encoder_fwd_ids(const pn_encoder* e, const uint8_t* ids, const int64_t* offsets, int B, int L, float* emb,
+                                  int ld_emb, int training, void* ws, size_t ws_bytes, void* stream) {
+  PN_OK(math_field_check(e->math_mode, "pn_encoder_fwd_ids"));
+  MathScope math_scope(e->math_mode);
+  if (e->nblocks > PN_MAX_BLOCKS) return fail("encoder: too many blocks (%d)", e->nblocks);
+  if (B <= 0 || L <= 0) return fail("encoder: empty batch");
+  if (ids == nullptr || offsets == nullptr) return fail("encoder (ids): ids / offsets are NULL");
+  Bump bp(ws, ws_bytes);
+  EncWs w;
+  if (!enc_carve(e, B, L, bp, w)) return fail("encoder: workspace too small (%zu given)", ws_bytes);
+  return encoder_forward(e, nullptr, nullptr, B, L, emb, ld_emb, training, w, nullptr, (hipStream_t)stream, ids, offsets);
+}
+
 // training forward that keeps what the backward needs (block inputs, conv_a outputs, BN batch statistics)
 extern "C" int pn_encoder_fwd_train(const pn_encoder* e, const float* onehots, const int64_t* lens, int B, int L,
                                     float* emb, int ld_emb, void* save, size_t save_bytes, void* ws, size_t ws_bytes,
@@ -1288,6 +1341,155 @@ extern "C" int pn_encoder_fwd_train(const pn_encoder* e, const float* onehots, c
   if (!enc_save_carve(e, B, L, bs, sv)) return fail("encoder: save buffer too small (%zu given)", save_bytes);
   BnMode bn_mode(e->bn_use_running != 0);
   return encoder_forward(e, onehots, lens, B, L, emb, ld_emb, 1, w, &sv, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaskedConv1D / Residual called stand-alone (protein_encoders.py:8-17, :23-67): the public classes under ProteInfer.
+// ProteInfer itself never takes this route (pn_encoder_fwd fuses them and stays channels-last); these entry points keep the
+// reference's [B][C][L] layout on both sides and its stand-alone semantics, which differ from the fused pipeline exactly
+// where the input's PAD positions hold something: Residual normalises the RAW input (train-mode statistics include the pads)
+// and adds it back unmasked, so its output carries the input's pad values.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_int(int* out, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+// channels-last [B*L][ld] -> [B][C][L]; positions t >= len[b] take pad_src[b][c][t] (the raw input) or 0
+__global__ void k_nlc_to_ncl(const float* __restrict__ y, int ld, const int* __restrict__ lens, const float* __restrict__ pad_src,
+                             float* __restrict__ out, int B, int C, int L) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * L) return;
+  const int t = (int)(i % L);
+  const int c = (int)((i / L) % C);
+  const int b = (int)(i / ((long)L * C));
+  out[i] = t < lens[b] ? y[((long)b * L + t) * ld + c] : (pad_src != nullptr ? pad_src[i] : 0.f);
+}
+
+struct PieceWs {
+  int *lens32, *lens_full;
+  float *xin, *z, *y, *s1, *t1, *s2, *t2;
+  double *sum_a, *sq_a, *sum_b, *sq_b;
+  ColScr cs;
+  StatScr st;
+};
+static const long PIECE_STAT_ROWS = 256;
+static bool piece_carve(int B, int L, int Ca, int Cb, Bump& bp, PieceWs& w) {
+  const long P = (long)B * L;
+  const int lda = ld4(Ca), ldb = ld4(Cb), ldm = lda > ldb ? lda : ldb;
+  w.lens32 = bp.take<int>(B);
+  w.lens_full = bp.take<int>(B);
+  w.xin = bp.take<float>((size_t)P * lda);
+  w.z = bp.take<float>((size_t)P * ldb);
+  w.y = bp.take<float>((size_t)P * lda);
+  w.s1 = bp.take<float>(lda); w.t1 = bp.take<float>(lda);
+  w.s2 = bp.take<float>(ldb); w.t2 = bp.take<float>(ldb);
+  w.sum_a = bp.take<double>(lda); w.sq_a = bp.take<double>(lda);
+  w.sum_b = bp.take<double>(ldb); w.sq_b = bp.take<double>(ldb);
+  colscr_carve(bp, P, ldm, w.cs);
+  statscr_carve(bp, P, PIECE_STAT_ROWS, ldm, w.st);
+  return bp.ok;
+}
+static int piece_conv(const float* in, int ld_in, const float* wpk, const float* bias, int Cout, int ld_out, float* out, int ntap,
+                      int dil, const float* s, const float* t, const float* resid, double* csum, double* csq, const int* lens32,
+                      int B, int L, PieceWs& w, hipStream_t st) {
+  const long P = (long)B * L;
+  GemmParams p = gp_zero();
+  p.M = (int)P; p.N = Cout; p.Nstore = ld_out; p.nseg = ntap; p.Kseg = ld_in;
+  p.A = in; p.lda = ld_in; p.a_scale = s; p.a_shift = t; p.lens = lens32; p.L = L; p.dil = dil;
+  p.W = wpk; p.ldw = (long)ntap * ld_in; p.C = out; p.ldc = ld_out; p.bias = bias; p.resid = resid; p.ldr = ld_out;
+  p.col_sum = csum; p.col_sumsq = csq;
+  if (csum) { p.col_part = w.cs.part; p.col_red = w.cs.red; }
+  const bool big = PN_BIG && ld_out >= 512 && P >= 4096;
+  return launch_gemm<A_CONV, E_CONV>(p, big ? 3 : pick_variant(ld_out), st);
+}
+
+extern "C" size_t pn_masked_conv1d_ws_bytes(int B, int L, int Cin, int Cout) {
+  Bump bp(nullptr, (size_t)-1);
+  PieceWs w;
+  piece_carve(B, L, Cin, Cout, bp, w);
+  return bp.off;
+}
+
+extern "C" int pn_masked_conv1d_fwd(const float* x, const int64_t* lens, const float* w_packed, const float* bias, int B, int Cin,
+                                    int Cout, int L, int ksize, int dilation, float* out, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B <= 0 || L <= 0 || Cin <= 0 || Cout <= 0) return fail("masked_conv1d: empty input");
+  if (ksize < 1 || ksize % 2 != 1) return fail("masked_conv1d: kernel_size %d must be odd (padding='same')", ksize);
+  if (dilation < 1) return fail("masked_conv1d: dilation %d", dilation);
+  if ((long)B * L > 0x7fffffffL) return fail("masked_conv1d: B*L too large");
+  Bump bp(ws, ws_bytes);
+  PieceWs w;
+  if (!piece_carve(B, L, Cin, Cout, bp, w)) return fail("masked_conv1d: workspace too small (%zu given)", ws_bytes);
+  const long P = (long)B * L;
+  const int ldi = ld4(Cin), ldo = ld4(Cout);
+  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, w.lens32, B);
+  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, x, (const int*)w.lens32, w.xin, B, Cin, L, ldi,
+                     (const int*)nullptr);  // masks the input (protein_encoders.py:14)
+  HIP_OK(hipGetLastError());
+  PN_OK(piece_conv(w.xin, ldi, w_packed, bias, Cout, ldo, w.z, ksize, dilation, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   w.lens32, B, L, w, st));
+  hipLaunchKernelGGL(k_nlc_to_ncl, dim3(nblk((long)B * Cout * L, 256)), dim3(256), 0, st, (const float*)w.z, ldo,
+                     (const int*)w.lens32, (const float*)nullptr, out, B, Cout, L);  // ... and the output (:16)
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t pn_residual_ws_bytes(int B, int L, int C, int Cb) {
+  Bump bp(nullptr, (size_t)-1);
+  PieceWs w;
+  piece_carve(B, L, C, Cb, bp, w);
+  return bp.off;
+}
+
+extern "C" int pn_residual_fwd(const pn_res_block* blk, int C, int Cb, int ksize, int dilation, const float* x,
+                               const int64_t* lens, int B, int L, float* out, int training, void* ws, size_t ws_bytes,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B <= 0 || L <= 0 || C <= 0 || Cb <= 0) return fail("residual: empty input");
+  if (ksize < 1 || ksize % 2 != 1) return fail("residual: kernel_size %d must be odd (padding='same')", ksize);
+  if (dilation < 1) return fail("residual: dilation %d", dilation);
+  if ((long)B * L > 0x7fffffffL) return fail("residual: B*L too large");
+  Bump bp(ws, ws_bytes);
+  PieceWs w;
+  if (!piece_carve(B, L, C, Cb, bp, w)) return fail("residual: workspace too small (%zu given)", ws_bytes);
+  const long P = (long)B * L;
+  const int ldc = ld4(C), ldb = ld4(Cb);
+  const float bn_eps = 1e-3f, bn_mom = 0.01f;  // protein_encoders.py:36,48
+  hipLaunchKernelGGL(k_lens32, dim3(nblk(B, 256)), dim3(256), 0, st, lens, w.lens32, B);
+  hipLaunchKernelGGL(k_fill_int, dim3(nblk(B, 256)), dim3(256), 0, st, w.lens_full, B, L);
+  // the RAW input, channels-last: bn_activation_1 sees it unmasked (:62), pads included
+  hipLaunchKernelGGL(k_ncl_to_nlc, dim3(nblk(P, 256)), dim3(256), 0, st, x, (const int*)w.lens_full, w.xin, B, C, L, ldc,
+                     (const int*)nullptr);
+  HIP_OK(hipGetLastError());
+  if (training) {
+    const unsigned nrb = nblk(P, PIECE_STAT_ROWS);
+    hipLaunchKernelGGL(k_col_stats, dim3(nblk(C, 256), nrb), dim3(256), 0, st, (const float*)w.xin, (long)ldc, P, C,
+                       PIECE_STAT_ROWS, w.st.part);
+    PN_OK(reduce_parts<double>(w.st.part, nrb, 2 * C, C, w.sum_a, w.sq_a, nullptr, w.st.red, st));
+    PN_OK(fold_train(st, blk->bn1, (const double*)w.sum_a, (const double*)w.sq_a, (double)P, bn_eps, bn_mom, C, ldc, w.s1, w.t1,
+                     nullptr, nullptr));
+  } else {
+    hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldc, 256)), dim3(256), 0, st, blk->bn1, (const float*)nullptr, bn_eps, C, ldc,
+                       w.s1, w.t1);
+  }
+  // masked_conv1 on relu(bn1(x)): the tap gather masks it (positions >= len read as 0, output rows >= len are 0)
+  PN_OK(piece_conv(w.xin, ldc, blk->conv_a_w, blk->conv_a_b, Cb, ldb, w.z, ksize, dilation, w.s1, w.t1, nullptr,
+                   training ? w.sum_b : nullptr, training ? w.sq_b : nullptr, w.lens32, B, L, w, st));
+  if (training) {
+    PN_OK(fold_train(st, blk->bn2, (const double*)w.sum_b, (const double*)w.sq_b, (double)P, bn_eps, bn_mom, Cb, ldb, w.s2, w.t2,
+                     nullptr, nullptr));
+  } else {
+    hipLaunchKernelGGL(k_bn_fold_eval, dim3(nblk(ldb, 256)), dim3(256), 0, st, blk->bn2, (const float*)nullptr, bn_eps, Cb, ldb,
+                       w.s2, w.t2);
+  }
+  // masked_conv2 (1 x 1) + x on the live rows; the pad rows of `out + x` (:66) are x itself
+  PN_OK(piece_conv(w.z, ldb, blk->conv_b_w, blk->conv_b_b, C, ldc, w.y, 1, 1, w.s2, w.t2, w.xin, nullptr, nullptr, w.lens32, B, L,
+                   w, st));
+  hipLaunchKernelGGL(k_nlc_to_ncl, dim3(nblk((long)B * C * L, 256)), dim3(256), 0, st, (const float*)w.y, ldc,
+                     (const int*)w.lens32, x, out, B, C, L);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1536,6 +1738,44 @@ __global__ void k_label_noise(const float* __restrict__ x, const float* __restri
 
 extern "C" int pn_label_noise(const float* L_f, const float* u, float scale, float* out, long n, void* stream) {
   hipLaunchKernelGGL(k_label_noise, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, L_f, u, scale, out, n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// The same noise with u drawn INSIDE the kernel: a counter hash of (seed, row, column) like the dropout masks
+// (gemm_engine.hpp: drop_rowkey / pn_lowbias32), top 24 bits -> u in [0, 1) on the float grid torch's own uniform uses.  No
+// [rows][cols] tensor of uniforms is written and read back (131 MB each way at the bench size); pn_uniform hands a test the
+// very same draw.  LABEL_NOISE_STREAM keeps the sequence apart from the dropout streams of the same seed.
+enum { LABEL_NOISE_STREAM = 400 };
+__device__ __forceinline__ float noise_uniform(uint32_t rowkey, uint32_t col) {
+  return (float)(pn_lowbias32(rowkey + col * 0x9E3779B1U) >> 8) * (1.f / 16777216.f);
+}
+__global__ void k_label_noise_seeded(const float* __restrict__ x, uint32_t seed, float scale, float* __restrict__ out, long rows,
+                                     int cols, int just_u) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const uint32_t c = (uint32_t)(i - r * cols);
+  const float u = noise_uniform(drop_rowkey(seed, (uint32_t)r), c);
+  out[i] = just_u ? u : x[i] + (2.f * u - 1.f) * scale;
+}
+static uint32_t noise_seed(unsigned seed) { return seed ^ ((uint32_t)LABEL_NOISE_STREAM * 0x9E3779B9u); }
+
+extern "C" int pn_label_noise_seeded(const float* L_f, unsigned seed, float scale, float* out, long rows, int cols,
+                                     void* stream) {
+  if (rows < 0 || cols <= 0 || rows > 0xffffffffL) return fail("label_noise: bad shape %ld x %d", rows, cols);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_label_noise_seeded, dim3(nblk(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, L_f, noise_seed(seed),
+                     scale, out, rows, cols, 0);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pn_uniform(unsigned seed, long rows, int cols, float* out, void* stream) {
+  if (rows < 0 || cols <= 0 || rows > 0xffffffffL) return fail("uniform: bad shape %ld x %d", rows, cols);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(k_label_noise_seeded, dim3(nblk(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                     noise_seed(seed), 0.f, out, rows, cols, 1);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -2737,14 +2977,32 @@ extern "C" size_t pn_loss_ws_bytes(int B, int N) {
   return al256(512 + (size_t)B * sizeof(float)) + al256((size_t)nblk(N, 256) * nblk(B, 32) * sizeof(double));
 }
 
-extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B,
-                               int N, int kind, float pos_weight, float gamma, float alpha, float smoothing,
-                               float threshold, float* loss_out, float* dlogits, float* tp, float* fn, float* fp,
-                               int weight_mode, const float* label_weights, float rgd_temperature, void* ws,
-                               size_t ws_bytes, void* stream) {
+// targets as one typed pointer -> the three typed pointers of the kernels (exactly one non-null)
+struct TargetPtrs {
+  const float* f;
+  const int64_t* i;
+  const uint8_t* u;
+};
+static int typed_targets(const void* targets, int kind, const char* who, TargetPtrs* t) {
+  t->f = nullptr; t->i = nullptr; t->u = nullptr;
+  if (targets == nullptr) return fail("%s: targets are NULL", who);
+  if (kind == PN_LABEL_F32) t->f = (const float*)targets;
+  else if (kind == PN_LABEL_I64) t->i = (const int64_t*)targets;
+  else if (kind == PN_LABEL_U8) t->u = (const uint8_t*)targets;
+  else return fail("%s: target_kind %d (PN_LABEL_F32 = 0, PN_LABEL_I64 = 1, PN_LABEL_U8 = 2)", who, kind);
+  return 0;
+}
+
+extern "C" int pn_loss_fwd_bwd_t(const float* logits, const void* targets, int target_kind, int B, int N, int kind,
+                                 float pos_weight, float gamma, float alpha, float smoothing, float threshold, float* loss_out,
+                                 float* dlogits, float* tp, float* fn, float* fp, int weight_mode, const float* label_weights,
+                                 float rgd_temperature, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  TargetPtrs tg;
+  PN_OK(typed_targets(targets, target_kind, "loss", &tg));
+  const float* targets_f32 = tg.f;
+  const int64_t* targets_i64 = tg.i;
   if (ws_bytes < pn_loss_ws_bytes(B, N)) return fail("loss: workspace too small (need pn_loss_ws_bytes(B, N))");
-  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("loss: pass exactly one target array");
   if (weight_mode < 0 || weight_mode > 2) return fail("loss: weight_mode must be 0, 1 (batch) or 2 (label weights)");
   if (weight_mode == 2 && label_weights == nullptr) return fail("loss: weight_mode 2 needs label_weights");
   double* acc = (double*)ws;               // [0] loss sum, [1] number of positives (integer-valued: order-free)
@@ -2755,13 +3013,13 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
   HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
   LossParams p;
   memset(&p, 0, sizeof(p));
-  p.logits = logits; p.tf = targets_f32; p.ti = targets_i64; p.B = B; p.N = N; p.kind = kind;
+  p.logits = logits; p.tf = targets_f32; p.ti = targets_i64; p.tu = tg.u; p.B = B; p.N = N; p.kind = kind;
   p.pos_weight = pos_weight; p.gamma = gamma; p.alpha = alpha; p.smoothing = smoothing; p.threshold = threshold;
   p.grad_scale = 1.f / ((float)B * (float)N);
   p.dlogits = dlogits; p.loss_part = lpart; p.tp = tp; p.fn = fn; p.fp = fp;
   p.rows_per_block = 32;
   if (weight_mode != 0) {
-    hipLaunchKernelGGL(k_target_weights, dim3(nblk(B, 4)), dim3(256), 0, st, targets_f32, targets_i64, B, N,
+    hipLaunchKernelGGL(k_target_weights, dim3(nblk(B, 4)), dim3(256), 0, st, targets_f32, targets_i64, tg.u, B, N,
                        weight_mode == 2 ? label_weights : (const float*)nullptr,
                        weight_mode == 2 ? row_w : (float*)nullptr, acc + 1);
     if (weight_mode == 1) {
@@ -2772,7 +3030,7 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
       p.row_w = row_w;
     }
   }
-  {  // K13/K14: 4 B logit + target (1 B algorithmically; this ABI takes f32 or i64) read, 4 B gradient written
+  {  // K13/K14: 4 B logit + 1 B target (algorithmic: a multihot; PN_LABEL_U8 reads exactly that) read, 4 B gradient written
     ProfScope ps(ST_LOSS, (double)B * (double)N * (dlogits ? 9.0 : 5.0), st);
     hipLaunchKernelGGL(k_loss, lgrid, dim3(256), 0, st, p);
   }
@@ -2785,6 +3043,18 @@ extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, co
                        1.f / ((float)B * (float)N));
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// the two-pointer form (exactly one of targets_f32 / targets_i64 non-NULL)
+extern "C" int pn_loss_fwd_bwd(const float* logits, const float* targets_f32, const int64_t* targets_i64, int B,
+                               int N, int kind, float pos_weight, float gamma, float alpha, float smoothing,
+                               float threshold, float* loss_out, float* dlogits, float* tp, float* fn, float* fp,
+                               int weight_mode, const float* label_weights, float rgd_temperature, void* ws,
+                               size_t ws_bytes, void* stream) {
+  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("loss: pass exactly one target array");
+  return pn_loss_fwd_bwd_t(logits, targets_f32 ? (const void*)targets_f32 : (const void*)targets_i64,
+                           targets_f32 ? PN_LABEL_F32 : PN_LABEL_I64, B, N, kind, pos_weight, gamma, alpha, smoothing, threshold,
+                           loss_out, dlogits, tp, fn, fp, weight_mode, label_weights, rgd_temperature, ws, ws_bytes, stream);
 }
 
 extern "C" size_t pn_supcon_ws_bytes(int B) { return al256((size_t)B * sizeof(double)) + 256; }
@@ -2804,17 +3074,25 @@ extern "C" int pn_supcon_fwd_bwd(const float* logits, const float* targets_f32, 
   return 0;
 }
 
-extern "C" int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
-                           float threshold, float* tp, float* fn, float* fp, void* stream) {
+extern "C" int pn_tp_fn_fp_t(const float* probs, const void* targets, int target_kind, int B, int N, float threshold,
+                             float* tp, float* fn, float* fp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("tp_fn_fp: pass exactly one target array");
+  TargetPtrs tg;
+  PN_OK(typed_targets(targets, target_kind, "tp_fn_fp", &tg));
   HIP_OK(hipMemsetAsync(tp, 0, N * sizeof(float), st));
   HIP_OK(hipMemsetAsync(fn, 0, N * sizeof(float), st));
   HIP_OK(hipMemsetAsync(fp, 0, N * sizeof(float), st));
-  hipLaunchKernelGGL(k_tp_fn_fp, dim3(nblk(N, 256), nblk(B, 64)), dim3(256), 0, st, probs, targets_f32, targets_i64,
-                     B, N, threshold, tp, fn, fp, 64);
+  hipLaunchKernelGGL(k_tp_fn_fp, dim3(nblk(N, 256), nblk(B, 64)), dim3(256), 0, st, probs, tg.f, tg.i, tg.u, B, N, threshold, tp,
+                     fn, fp, 64);
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" int pn_tp_fn_fp(const float* probs, const float* targets_f32, const int64_t* targets_i64, int B, int N,
+                           float threshold, float* tp, float* fn, float* fp, void* stream) {
+  if ((targets_f32 == nullptr) == (targets_i64 == nullptr)) return fail("tp_fn_fp: pass exactly one target array");
+  return pn_tp_fn_fp_t(probs, targets_f32 ? (const void*)targets_f32 : (const void*)targets_i64,
+                       targets_f32 ? PN_LABEL_F32 : PN_LABEL_I64, B, N, threshold, tp, fn, fp, stream);
 }
 
 extern "C" int pn_clip_adam_step(float* w, const float* g, float* m, float* v, long n, float max_norm, float lr,

@@ -917,6 +917,7 @@ struct LossParams {
   const float* logits;
   const float* tf;     // float targets or null
   const int64_t* ti;   // int64 targets or null
+  const uint8_t* tu;   // uint8 targets or null (1 B per pair: the algorithmic size of a multihot)
   int B, N;
   int kind;
   float pos_weight, gamma, alpha, smoothing;
@@ -930,6 +931,11 @@ struct LossParams {
   const float* posneg;  // [2] = (weight of positives, weight of negatives) (BatchWeightedBCE) or null
 };
 
+// one multihot target as float from whichever array the caller passed (exactly one is non-null)
+__device__ __forceinline__ float load_target(const float* tf, const int64_t* ti, const uint8_t* tu, long idx) {
+  return tf ? tf[idx] : (ti ? (float)ti[idx] : (float)tu[idx]);
+}
+
 // number of positive targets -> (w_pos, w_neg) of BatchWeightedBCE (losses.py:131-139)
 __global__ void k_posneg_weights(const double* npos_in, double numel, double eps, float* out) {
   const double num_pos = npos_in[0] + eps;
@@ -940,14 +946,14 @@ __global__ void k_posneg_weights(const double* npos_in, double numel, double eps
 }
 
 // row_w[i] = sum_j label_weights[j] * target[i][j];  npos += sum of targets  (one wave per row)
-__global__ __launch_bounds__(256) void k_target_weights(const float* tf, const int64_t* ti, int B, int N,
+__global__ __launch_bounds__(256) void k_target_weights(const float* tf, const int64_t* ti, const uint8_t* tu, int B, int N,
                                                         const float* label_weights, float* row_w, double* npos) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= B) return;
   float w = 0.f, c = 0.f;
   for (int j = lane; j < N; j += 64) {
-    const float y = tf ? tf[(long)i * N + j] : (float)ti[(long)i * N + j];
+    const float y = load_target(tf, ti, tu, (long)i * N + j);
     c += y;
     if (label_weights) w += label_weights[j] * y;
   }
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(256) void k_loss(const LossParams p) {
         const int iu = ib + u < i1 ? ib + u : i1 - 1;
         const long idx = (long)iu * p.N + j;
         xs[u] = p.logits[idx];
-        ys[u] = p.tf ? p.tf[idx] : (float)p.ti[idx];
+        ys[u] = load_target(p.tf, p.ti, p.tu, idx);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1117,8 +1123,8 @@ __global__ __launch_bounds__(256) void k_supcon(const float* __restrict__ logits
 
 // calculate_tp_fn_fp on probabilities (ProtNoteTrainer.py:61-83): counts are integers held in f32
 __global__ __launch_bounds__(256) void k_tp_fn_fp(const float* __restrict__ probs, const float* tf, const int64_t* ti,
-                                                   int B, int N, float threshold, float* tp, float* fn, float* fp,
-                                                   int rows_per_block) {
+                                                   const uint8_t* tu, int B, int N, float threshold, float* tp, float* fn,
+                                                   float* fp, int rows_per_block) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   const int i0 = blockIdx.y * rows_per_block;
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_tp_fn_fp(const float* __restrict__ prob
   float a = 0.f, b = 0.f, c = 0.f;
   for (int i = i0; i < i1; ++i) {
     const long idx = (long)i * N + j;
-    const float y = tf ? tf[idx] : (float)ti[idx];
+    const float y = load_target(tf, ti, tu, idx);
     const float pred = probs[idx] >= threshold ? 1.f : 0.f;
     a += pred * y;
     b += (1.f - pred) * y;

@@ -61,7 +61,8 @@ def collate_variable_sequence_length(batch: List[Dict], label_sample_size=None, 
 
 
 def collate_to_device(batch: List[Dict], device, label_sample_size=None, distribute_labels=False, shuffle_labels=False,
-                      in_batch_sampling=False, grid_sampler=False, return_label_multihots=True, world_size=1, rank=0):
+                      in_batch_sampling=False, grid_sampler=False, return_label_multihots=True, world_size=1, rank=0,
+                      multihot_dtype=None, residue_ids=False):
     """Same batch dict as collate_variable_sequence_length, assembled ON THE DEVICE: the host ships the ragged
     residue indices as uint8 (B*L bytes, one copy) plus offsets, and pn_onehot_batch writes the zero-padded f32
     one-hots [B, A, Lmax] and the lengths in HBM.  Examples may carry `sequence_ints` (residue indices) or the
@@ -82,15 +83,27 @@ def collate_to_device(batch: List[Dict], device, label_sample_size=None, distrib
     B, Lmax = len(batch), int(max(lens))
     flat_d = flat.to(device, non_blocking=True)
     off_d = offsets.to(device, non_blocking=True)
-    onehots = torch.empty(B, A, Lmax, dtype=torch.float32, device=device)
-    lengths = torch.empty(B, dtype=torch.int64, device=device)
-    L.check(L.lib().pn_onehot_batch(L.ptr(flat_d), L.ptr(off_d), B, A, Lmax, L.ptr(onehots), L.ptr(lengths),
-                                    L.stream_ptr()))
+    if residue_ids:
+        # opt-in: hand the encoder the ids themselves (ResidueIds; pn_encoder_fwd_ids) - no [B, A, Lmax] f32 tensor is written.
+        # The default below is the reference collator's dict (row (a)14): f32 one-hots
+        from ..models.protein_encoders import ResidueIds
+
+        onehots = ResidueIds(flat_d, off_d, A, Lmax)
+        lengths = torch.tensor(lens, dtype=torch.int64).to(device, non_blocking=True)
+    else:
+        onehots = torch.empty(B, A, Lmax, dtype=torch.float32, device=device)
+        lengths = torch.empty(B, dtype=torch.int64, device=device)
+        L.check(L.lib().pn_onehot_batch(L.ptr(flat_d), L.ptr(off_d), B, A, Lmax, L.ptr(onehots), L.ptr(lengths),
+                                        L.stream_ptr()))
     emb = first["label_embeddings"] if idx is None else first["label_embeddings"][idx]
     out = {"sequence_onehots": onehots, "sequence_ids": [r["sequence_id"] for r in batch],
            "sequence_lengths": lengths, "label_embeddings": emb.to(device, non_blocking=True),
            "label_token_counts": first["label_token_counts"].to(device, non_blocking=True)}
     if return_label_multihots:
         mh = torch.stack([r["label_multihots"] if idx is None else r["label_multihots"][idx] for r in batch])
+        # multihot_dtype=torch.uint8: 1 B per pair over PCIe and in the loss / metric kernels (pn_loss_fwd_bwd_t, PN_LABEL_U8)
+        # instead of the reference collator's int64 (collators.py:136-137), which stays the default (row (a)14's contract)
+        if multihot_dtype is not None:
+            mh = mh.to(multihot_dtype)
         out["label_multihots"] = mh.to(device, non_blocking=True)
     return out

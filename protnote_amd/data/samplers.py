@@ -46,16 +46,33 @@ class LengthBucketBatchSampler:
         return len(self._batches())
 
 
+def _resolve_world(world_size, rank):
+    """`None` defaults of the reference's samplers (samplers.py:15-37 via torch's DistributedSampler, :66-74): the process
+    group's world size / this process's rank; RuntimeError when torch.distributed is not available, and whatever
+    torch.distributed raises when no process group has been initialised."""
+    if world_size is None or rank is None:
+        import torch.distributed as dist
+
+        if not dist.is_available():
+            raise RuntimeError("Requires distributed package to be available")
+        if world_size is None:
+            world_size = dist.get_world_size()
+        if rank is None:
+            rank = dist.get_rank()
+    return int(world_size), int(rank)
+
+
 class DistributedWeightedSampler:
     """Index stream of the reference's DistributedWeightedSampler (protnote/data/samplers.py:66-124): every epoch
     draws floor(N / world) * world indices from torch.multinomial(weights) on a CPU generator seeded with the
     epoch, keeps the rank-strided slice and shuffles it with the same generator - bit-identical streams."""
 
-    def __init__(self, weights, world_size: int = 1, rank: int = 0, replacement: bool = True):
+    def __init__(self, weights, world_size=None, rank=None, replacement=True):
         import math
 
         import torch
 
+        world_size, rank = _resolve_world(world_size, rank)  # None -> torch.distributed, as the reference (:69-74)
         self.weights = weights if isinstance(weights, torch.Tensor) else torch.tensor(weights, dtype=torch.double)
         self.world_size, self.rank, self.replacement, self.epoch = world_size, rank, replacement, 0
         self.num_samples = int(math.floor(len(self.weights) * 1.0 / world_size))
@@ -85,9 +102,13 @@ class GeneralDistributedSampler:
     shuffle=False over `list(sampler)`): the stream is padded by repeating its head to a multiple of the world size
     (or cut to one with drop_last) and rank r keeps indices r, r + world, ..."""
 
-    def __init__(self, sampler, num_replicas: int, rank: int, seed: int = 0, drop_last: bool = False):
+    def __init__(self, sampler, num_replicas=None, rank=None, seed: int = 0, drop_last: bool = False):
         import math
 
+        # None -> torch.distributed's world, as torch's DistributedSampler (the reference's base class, :15-37) resolves it
+        num_replicas, rank = _resolve_world(num_replicas, rank)
+        if rank >= num_replicas or rank < 0:
+            raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}]")
         n = len(sampler)
         assert n > num_replicas, "Total samples must be > num replicas"
         self.sampler, self.num_replicas, self.rank, self.seed, self.drop_last = sampler, num_replicas, rank, seed, drop_last

@@ -179,7 +179,7 @@ class ProtNote(nn.Module):
         with that seed; eval descriptors leave it off."""
         layers = _split_layers(seq)
         if len(layers) > L.PN_MAX_LAYERS:
-            raise ValueError("too many projection layers")
+            raise ValueError(f"PROJECTION_HEAD_NUM_LAYERS: at most {L.PN_MAX_LAYERS} projection layers are supported, got {len(layers)}")
         m = L.pn_mlp()
         m.nlayers = len(layers)
         m.dims[0] = layers[0][0].in_features
@@ -200,6 +200,8 @@ class ProtNote(nn.Module):
     def _pair_desc(self, drop_seed=None):
         layers = _split_layers(self.output_layer)
         hidden, out = layers[:-1], layers[-1][0]
+        if len(hidden) > L.PN_MAX_LAYERS:
+            raise ValueError(f"OUTPUT_MLP_NUM_LAYERS: at most {L.PN_MAX_LAYERS} hidden layers are supported, got {len(hidden)}")
         hd = L.pn_pairhead()
         hd.d = self.latent_dim
         hd.in_dim = hidden[0][0].in_features
@@ -348,19 +350,24 @@ class ProtNote(nn.Module):
         out_emb = hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu()
         return pairs, {"output_layer_embeddings": out_emb, "joint_embeddings": self._joint_embeddings_cpu(P_e, L_e)}
 
-    def _joint_embeddings_cpu(self, P_e, L_e):
-        """The reference's joint tensor (_get_joint_embeddings, ProtNote.py:112-152) as save_embeddings returns it
-        (:326-328: detached, on the CPU), protein-major rows i * N_L + j.  Only ever built for save_embeddings - the kernels
-        never materialise it."""
-        pe, le = P_e.detach().cpu(), L_e.detach().cpu()
-        B, NL, d = pe.shape[0], le.shape[0], pe.shape[1]
-        joint = torch.cat([pe[:, None, :].expand(B, NL, -1), le[None, :, :].expand(B, NL, -1)], dim=2)
-        joint = joint.reshape(B * NL, -1)
+    def _get_joint_embeddings(self, P_e, L_e, num_sequences, num_labels):
+        """Reference ProtNote._get_joint_embeddings (ProtNote.py:112-152), same signature: the [num_sequences * num_labels,
+        2d | 3d] joint tensor, protein-major rows i * num_labels + j, on the inputs' device.  The kernels never build it
+        (layer 1 is separable) - this is the layout contract for callers that ask for the tensor itself
+        (`save_embeddings`, ProtNote.py:324-332); data movement only, no arithmetic beyond the reference's own diff / product."""
+        d = P_e.shape[1]
+        joint = torch.cat([P_e.unsqueeze(1).expand(-1, num_labels, -1), L_e.unsqueeze(0).expand(num_sequences, -1, -1)], dim=2)
+        joint = joint.reshape(-1, joint.shape[-1])
         if self.feature_fusion == "concatenation_diff":
             joint = torch.cat([joint, joint[:, :d] - joint[:, d:]], dim=-1)
-        if self.feature_fusion == "concatenation_prod":
+        elif self.feature_fusion == "concatenation_prod":
             joint = torch.cat([joint, joint[:, :d] * joint[:, d:]], dim=-1)
         return joint
+
+    def _joint_embeddings_cpu(self, P_e, L_e):
+        """The reference's joint tensor as save_embeddings returns it (ProtNote.py:326-328: detached, on the CPU)."""
+        pe, le = P_e.detach().cpu(), L_e.detach().cpu()
+        return self._get_joint_embeddings(pe, le, pe.shape[0], le.shape[0])
 
     def additive_attention(self, hidden_states, attention_mask):
         """Reference ProtNote.additive_attention (ProtNote.py:154-166), inference: masked-softmax attention pooling of
@@ -391,12 +398,29 @@ class ProtNote(nn.Module):
                                           L.stream_ptr()))
         return out
 
-    def _noised(self, L_f, u):
-        """Reference :219-240: L_f + (2u - 1) * alpha / sqrt(d), u ~ U[0,1) supplied by torch's Philox stream."""
+    # Where the uniforms of the label-embedding noise (ProtNote.py:219-240) come from: "kernel" (default) = a counter hash of
+    # (seed, row, column) evaluated inside pn_label_noise_seeded - the seed is one draw from torch's host generator per forward,
+    # so torch.manual_seed governs it, and no [N_L, d] tensor of uniforms is written and read back; "torch" = torch.rand_like
+    # on the device, the reference's own call (what tests that replay a reference run's noise hook into).
+    label_noise_rng = "kernel"
+
+    def _noised(self, L_f, u=None):
+        """Reference :219-240: L_f + (2u - 1) * alpha / sqrt(L_f.shape[1]), u ~ U[0,1).  `u` given: that draw; else by
+        `label_noise_rng`.  The seed of the last in-kernel draw is kept in `_pn_last_noise_seed` (pn_uniform reproduces it)."""
         out = torch.empty_like(L_f)
         scale = float(self.label_embedding_noising_alpha) / math.sqrt(L_f.shape[1])
-        L.check(L.lib().pn_label_noise(L.ptr(L_f), L.ptr(u.contiguous()), scale, L.ptr(out), L_f.numel(),
-                                       L.stream_ptr()))
+        if u is None and self.label_noise_rng == "torch":
+            u = torch.rand_like(L_f)
+        if u is not None:
+            L.check(L.lib().pn_label_noise(L.ptr(L_f), L.ptr(u.contiguous()), scale, L.ptr(out), L_f.numel(),
+                                           L.stream_ptr()))
+            return out
+        if self.label_noise_rng != "kernel":
+            raise ValueError(f"label_noise_rng must be 'kernel' or 'torch', got {self.label_noise_rng!r}")
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())  # host generator: no device sync
+        self.__dict__["_pn_last_noise_seed"] = seed
+        cols = int(L_f.shape[-1])
+        L.check(L.lib().pn_label_noise_seeded(L.ptr(L_f), seed, scale, L.ptr(out), L_f.numel() // cols, cols, L.stream_ptr()))
         return out
 
     # ------------------------------------------------------------------ forward
@@ -470,7 +494,7 @@ class ProtNote(nn.Module):
                 L_f = L_f.detach().float().contiguous()
                 if self.training and label_token_counts is not None and self.label_embedding_noising_alpha > 0:
                     # reference :219-240
-                    L_f = self._noised(L_f, torch.rand_like(L_f))
+                    L_f = self._noised(L_f)
                 # ---- sequence branch (:243-264) ----
                 if sequence_embeddings is not None and (not self.train_sequence_encoder or not self.training):
                     P_f = sequence_embeddings.detach().float().contiguous()

@@ -11,16 +11,12 @@ def calculate_tp_fn_fp(probs, labels, threshold=0.5):
     L.require_hip(probs, labels)
     B, N = probs.shape
     p = probs.detach().float().contiguous()
-    tf = ti = None
-    if labels.dtype == torch.int64:
-        ti = labels.contiguous()
-    else:
-        tf = labels.detach().float().contiguous()
+    tgt, tkind = L.typed_targets(labels)
     tp = torch.empty(N, dtype=torch.float32, device=p.device)
     fn = torch.empty_like(tp)
     fp = torch.empty_like(tp)
-    L.check(L.lib().pn_tp_fn_fp(L.ptr(p), L.ptr(tf), L.ptr(ti), B, N, float(threshold), L.ptr(tp), L.ptr(fn),
-                                L.ptr(fp), L.stream_ptr()))
+    L.check(L.lib().pn_tp_fn_fp_t(L.ptr(p), L.ptr(tgt), tkind, B, N, float(threshold), L.ptr(tp), L.ptr(fn),
+                                  L.ptr(fp), L.stream_ptr()))
     return tp, fn, fp
 
 

@@ -403,7 +403,7 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
         if model.training and label_token_counts is not None and model.label_embedding_noising_alpha > 0:
             # (for [N, T, d] token embeddings the reference's scale is alpha / sqrt(L_f.shape[1]) = alpha / sqrt(T),
             #  ProtNote.py:227-230 - _noised reads shape[1] the same way)
-            L_f = model._noised(L_f, torch.rand_like(L_f))
+            L_f = model._noised(L_f)
     if L_src.requires_grad and torch.is_grad_enabled():
         # the reference uses the caller's tensor as is (ProtNote.py:192-196; the noise is additive): gradients reach it
         L_f = _PassGradFn.apply(L_src, L_f)

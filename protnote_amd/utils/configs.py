@@ -2,14 +2,38 @@
 `--override KEY VALUE ...` rule (python-literal values, null/true/false spelled the YAML way), the mapping
 from config keys to the model constructors that bin/main.py:383-446 performs, and the naming rule of the cached
 label-embedding files.  No path prefixing or loggers (I/O side, out of scope)."""
+import os
 from ast import literal_eval
+from pathlib import Path
 
 import yaml
 
 
-def load_config(path: str) -> dict:
-    with open(path) as f:
-        return yaml.safe_load(f)
+def get_project_root():
+    """Reference configs.py:268-270: the directory that holds `configs/`, `data/` and `outputs/` - there the checkout the
+    package lives in.  Here: $PROTNOTE_PROJECT_ROOT when set (point it at the ProtNote checkout whose configs / data this
+    drop-in should serve), else the directory above the package."""
+    env = os.environ.get("PROTNOTE_PROJECT_ROOT")
+    return Path(env).resolve() if env else Path(__file__).resolve().parent.parent.parent
+
+
+def update_config_paths(config, project_root):
+    """Reference configs.py:272-280: data paths -> <root>/data/<value>, output paths -> <root>/outputs/<value>."""
+    for key, value in config["paths"].get("data_paths", {}).items():
+        config["paths"]["data_paths"][key] = project_root / "data" / value
+    for key, value in config["paths"].get("output_paths", {}).items():
+        config["paths"]["output_paths"][key] = project_root / "outputs" / value
+    return config
+
+
+def load_config(config_file: str = "base_config.yaml"):
+    """Reference configs.py:282-290, as every script calls it (`config, project_root = load_config()`): reads
+    <project_root>/configs/<config_file> (an absolute `config_file` wins, as pathlib joins it there too), prefixes the data /
+    output paths and returns (config, project_root)."""
+    project_root = get_project_root()
+    with open(project_root / "configs" / config_file) as f:
+        config = yaml.safe_load(f)
+    return update_config_paths(config, project_root), project_root
 
 
 def try_literal_eval(val):

@@ -21,11 +21,7 @@ class _FusedLossFn(torch.autograd.Function):
             raise ValueError("expected logits and targets of the same [B, N] shape")
         x = logits.detach().float().contiguous()
         B, N = x.shape
-        tf = ti = None
-        if target.dtype == torch.int64:
-            ti = target.contiguous()
-        else:
-            tf = target.detach().float().contiguous()
+        tgt, tkind = L.typed_targets(target)  # int64 (the reference collator's dtype), uint8 / bool (1 B per pair) or float32
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
         ws = L.workspace(L.lib().pn_loss_ws_bytes(B, N), x.device, "loss")
@@ -39,10 +35,10 @@ class _FusedLossFn(torch.autograd.Function):
             if counts.shape != (3, N) or counts.dtype != torch.float32 or not counts.is_contiguous():
                 raise ValueError("metric counts must be a contiguous float32 [3, N_labels] tensor")
             tp, fn, fp = counts[0], counts[1], counts[2]
-        L.check(L.lib().pn_loss_fwd_bwd(L.ptr(x), L.ptr(tf), L.ptr(ti), B, N, kind, float(pos_weight), float(gamma),
-                                        float(alpha), float(smoothing), float(threshold), L.ptr(loss), L.ptr(dlog),
-                                        L.ptr(tp), L.ptr(fn), L.ptr(fp), int(weight_mode), L.ptr(lw),
-                                        float(rgd_temperature), L.ptr(ws), ws.numel(), L.stream_ptr()))
+        L.check(L.lib().pn_loss_fwd_bwd_t(L.ptr(x), L.ptr(tgt), tkind, B, N, kind, float(pos_weight), float(gamma),
+                                          float(alpha), float(smoothing), float(threshold), L.ptr(loss), L.ptr(dlog),
+                                          L.ptr(tp), L.ptr(fn), L.ptr(fp), int(weight_mode), L.ptr(lw),
+                                          float(rgd_temperature), L.ptr(ws), ws.numel(), L.stream_ptr()))
         ctx.dlog = dlog
         return loss.reshape(())
 
@@ -148,11 +144,7 @@ class _SupConFn(torch.autograd.Function):
             raise ValueError("expected logits and targets of the same [B, N] shape")
         x = logits.detach().float().contiguous()
         B, N = x.shape
-        tf = ti = None
-        if target.dtype == torch.int64:
-            ti = target.contiguous()
-        else:
-            tf = target.detach().float().contiguous()
+        tgt, tkind = L.typed_targets(target)  # int64 (the reference collator's dtype), uint8 / bool (1 B per pair) or float32
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
         ws = L.workspace(L.lib().pn_supcon_ws_bytes(B), x.device, "loss")

@@ -53,7 +53,7 @@ def load_checkpoint_into(model, checkpoint_path: str, map_location="cpu", strict
     return {k: v for k, v in ckpt.items() if k != "model_state_dict"}
 
 
-def load_model(trainer, checkpoint_path: str, rank: int = 0, from_checkpoint: bool = False):
+def load_model(trainer, checkpoint_path: str, rank: int, from_checkpoint=False):
     """Twin of the reference's load_model (utils/models.py:324-374; called by bin/main.py:521-527): the checkpoint's
     model_state_dict ('module.' prefix of a DDP-wrapped writer stripped, :352-358) goes into the trainer's model; with
     `from_checkpoint` the optimiser state (by parameter id: FusedClipAdam / FusedClipSGD take torch's layout), the epoch

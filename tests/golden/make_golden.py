@@ -197,6 +197,44 @@ def _train_step(model, loss_fn, inputs, targets, clip=1.0, lr=3e-4):
     return logits.detach().numpy().copy(), float(loss.detach()), grads, float(total_norm)
 
 
+def golden_encoder_pieces():
+    """MaskedConv1D.forward and Residual.forward called STAND-ALONE (protein_encoders.py:8-17, :61-67) - the two public
+    classes under ProteInfer - on inputs whose pad positions hold garbage, which is what tells a stand-alone call from the
+    fused pipeline: MaskedConv1D masks before and after; Residual normalises the RAW input (train-mode BatchNorm statistics
+    include the pads) and adds it back unmasked, so its output carries the input's pad values.  Same toy model and seeds as
+    golden_encoder (the weights are stored again so the fixture is self-contained)."""
+    from protnote.models.protein_encoders import ProteInfer
+
+    g = torch.Generator().manual_seed(1234)
+    cfg = dict(num_labels=13, input_channels=20, output_channels=52, kernel_size=9,
+               dilation_base=3, num_resnet_blocks=5, bottleneck_factor=0.5)
+    torch.manual_seed(0)
+    model = ProteInfer(activation=torch.nn.ReLU, **cfg)
+    randomize_(model, g)
+    out = {"cfg_" + k: np.array(v) for k, v in cfg.items()}
+    out.update(sd_np(model, "sd/"))
+    lens = [120, 1, 37, 90, 119, 9]
+    lens_t = torch.tensor(lens, dtype=torch.int64)
+    g2 = torch.Generator().manual_seed(4321)
+    h = torch.randn(len(lens), 52, 120, generator=g2)  # pads hold random values too
+    out["h"], out["lens"] = h.numpy(), lens_t.numpy()
+    model.eval()
+    with torch.no_grad():
+        out["conv/block2_masked_conv1"] = model.resnet_blocks[2].masked_conv1(h, lens_t).numpy()   # 52 -> 26, k 9, dilation 9
+        out["conv/block1_masked_conv2"] = model.resnet_blocks[1].masked_conv2(h[:, :26].contiguous(), lens_t).numpy()  # 1 x 1
+        out["eval/residual1"] = model.resnet_blocks[1](h, lens_t).numpy()   # dilation 3
+        out["eval/residual4"] = model.resnet_blocks[4](h, lens_t).numpy()   # dilation 81 > most lengths
+    blk = model.resnet_blocks[1]
+    blk.train()
+    with torch.no_grad():
+        out["train/residual1"] = blk(h, lens_t).numpy()
+    for k, v in blk.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out["after_train/residual1." + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "encoder_pieces.npz"), **out)
+    print("encoder_pieces.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd")})
+
+
 def golden_protnote(variants=None):
     from protnote.models.protein_encoders import ProteInfer
     from protnote.models.ProtNote import ProtNote
@@ -1162,7 +1200,7 @@ if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(8)
     only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
-    jobs = {"encoder": golden_encoder, "protnote": golden_protnote,
+    jobs = {"encoder": golden_encoder, "encoder_pieces": golden_encoder_pieces, "protnote": golden_protnote,
             "protnote_nobn": lambda: golden_protnote([("concatenation", False)]), "losses": golden_losses_metrics, "losses_extra": golden_losses_extra,
             "collator": golden_collator, "bookkeeping": golden_bookkeeping, "tf_weights": golden_tf_weights,
             "samplers": golden_samplers, "attention": golden_attention_pooling, "grid_samplers": golden_grid_samplers,

@@ -3,6 +3,15 @@ import numpy as np
 import torch
 
 
+def replay_label_noise(monkeypatch, draw):
+    """Feed a recorded draw of the label-embedding noise (a reference run's `u`, ProtNote.py:219-240) to the twin: switch it
+    from its default in-kernel counter-hash RNG to the reference's own call, torch.rand_like, and replace that call."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    monkeypatch.setattr(ProtNote, "label_noise_rng", "torch")
+    monkeypatch.setattr(torch, "rand_like", draw)
+
+
 def make_encoder(sd, prefix, cfg, device):
     from protnote_amd.models.protein_encoders import ProteInfer
 

@@ -121,7 +121,8 @@ def test_real_base_config_builds_and_embedded_copy_agrees():
     build_models / build_training accept it unmodified."""
     import copy
 
-    real = CF.load_config(REAL_CONFIG)
+    real, root = CF.load_config(REAL_CONFIG)  # absolute path: taken as is, like the reference's pathlib join
+    assert str(real["paths"]["data_paths"]["TRAIN_DATA_PATH"]).startswith(str(root / "data"))
     for section in ("params", "embed_sequences_params"):
         for k, v in CFG[section].items():
             assert k in real[section], (section, k)

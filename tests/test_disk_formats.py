@@ -123,7 +123,7 @@ def test_reference_checkpoint_from_ddp_model_loads_bit_exactly(golden_dir):
     assert (tr.epoch, tr.starting_epoch, tr.best_val_metric) == (c["epoch"], c["starting_epoch"], c["best_val_metric"])
     assert tr.optimizer.state_dict()["param_groups"][0]["lr"] == c["optimizer_lr"]
     assert all(np.array_equal(model2.state_dict()[k].numpy(), exp["ckpt/sd/" + k]) for k in keys)
-    M.load_model(tr2 := types.SimpleNamespace(model=model2, optimizer=None, epoch=1), os.path.join(d, c["file"]))
+    M.load_model(tr2 := types.SimpleNamespace(model=model2, optimizer=None, epoch=1), os.path.join(d, c["file"]), 0)
     assert tr2.epoch == 1  # without from_checkpoint only the weights move
 
 

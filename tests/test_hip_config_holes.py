@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import protnote_oracle as O
+from tests.helpers import replay_label_noise  # noqa: F401
 from tests.helpers import make_protnote, random_encoder_sd, random_head_sd
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +80,7 @@ def test_train_step_with_save_embeddings_golden(golden_dir, case, monkeypatch):
     cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
     y = torch.from_numpy(g["multihots"]).to(DEV)
     u = torch.from_numpy(g["train/noise_u"]).to(DEV)
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.clone())
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
     logits, emb = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, label_token_counts=cnt,

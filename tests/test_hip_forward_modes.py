@@ -14,6 +14,7 @@ import pytest
 import torch
 
 from oracle import protnote_oracle as O
+from tests.helpers import replay_label_noise  # noqa: F401
 from tests.helpers import make_protnote
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +41,7 @@ def test_train_mode_forward_under_no_grad(golden_dir, fusion, monkeypatch):
     u = torch.from_numpy(g["train/noise_u"])
     model, sd = make_protnote(g, DEV)
     model.train()
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.to(t.device).clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.to(t.device).clone())
     with torch.no_grad():
         logits, _ = model(sequence_onehots=x.to(DEV), sequence_lengths=lens.to(DEV), label_embeddings=lab1.to(DEV),
                           label_token_counts=cnt1.to(DEV))

@@ -24,8 +24,50 @@ def _cases(n=28, seed=2024):
     return out
 
 
-@pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['id']}-{c['fusion']}-L{c['nl']}-bn{int(c['bn'])}-p{c['nproj']}-{c['B']}x{c['NLab']}x{c['ndesc']}")
+def _deep_cases(seed=4048):
+    """The depths the ABI advertises beyond the sweep above (PN_MAX_LAYERS 8; get_mlp / torchvision.ops.MLP take any depth,
+    ProtNote.py:63-81,337-378): OUTPUT_MLP_NUM_LAYERS and PROJECTION_HEAD_NUM_LAYERS in {5, 8}, every fusion, BN on / off."""
+    rng = np.random.RandomState(seed)
+    out = []
+    combos = [(5, 5), (8, 8), (8, 2), (2, 8), (5, 8), (8, 5), (6, 7), (7, 6)]
+    for k, (nl, nproj) in enumerate(combos):
+        fusion = ["concatenation", "concatenation_diff", "concatenation_prod", "similarity"][k % 4]
+        out.append(dict(id=100 + k, fusion=fusion, nl=nl, bn=bool(k % 3 != 2), nproj=nproj,
+                        pdim=int(4 * rng.randint(3, 12)), ldim=int(4 * rng.randint(3, 12)), d=int(4 * rng.randint(2, 10)),
+                        oscale=int(rng.randint(1, 4)), pscale=int(rng.randint(1, 4)), B=int(rng.randint(2, 40)),
+                        NLab=int(rng.randint(2, 70)), ndesc=int(rng.randint(1, 3))))
+    return out
+
+
+_IDS = lambda c: f"{c['id']}-{c['fusion']}-L{c['nl']}-bn{int(c['bn'])}-p{c['nproj']}-{c['B']}x{c['NLab']}x{c['ndesc']}"  # noqa: E731
+
+
+@pytest.mark.parametrize("c", _deep_cases(), ids=_IDS)
+def test_deep_head_configuration_vs_oracle(c):
+    """Depths 5..8 of both MLP kinds (the header's PN_MAX_LAYERS; no test ran more than 4 before round 6)."""
+    _run_head_case(c)
+
+
+def test_more_than_max_layers_is_refused():
+    """9 hidden layers / 9 projection layers: a ValueError from the twin (descriptor arrays hold PN_MAX_LAYERS = 8), not a
+    silent truncation."""
+    from protnote_amd.models.ProtNote import ProtNote
+
+    x, lab = torch.randn(4, 12, device=DEV), torch.randn(6, 12, device=DEV)
+    for kw in (dict(output_mlp_num_layers=9), dict(projection_head_num_layers=9)):
+        model = ProtNote(protein_embedding_dim=12, label_embedding_dim=12, latent_dim=8, output_mlp_hidden_dim_scale_factor=2,
+                         **{"output_mlp_num_layers": 2, "projection_head_num_layers": 2, **kw}).to(DEV).eval()
+        with pytest.raises((ValueError, RuntimeError), match="layers|nlayers"):
+            with torch.no_grad():
+                model(sequence_embeddings=x, label_embeddings=lab)
+
+
+@pytest.mark.parametrize("c", _cases(), ids=_IDS)
 def test_random_head_configuration_vs_oracle(c):
+    _run_head_case(c)
+
+
+def _run_head_case(c):
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.utils.losses import BCEWithLogitsLoss
 

@@ -95,6 +95,45 @@ def test_encoder_golden_eval_and_train(golden_dir):
         np.testing.assert_allclose(got[k].numpy(), v.numpy(), atol=1e-5, rtol=1e-4, err_msg=k)
 
 
+def test_masked_conv1d_and_residual_standalone_golden(golden_dir):
+    """The two public classes under ProteInfer, called on their own (reference protein_encoders.py:8-17, :61-67;
+    pn_masked_conv1d_fwd / pn_residual_fwd) - against activations the REFERENCE produced: conv1 and block 0 of
+    encoder_small.npz (one-hot input with garbage pads -> eval/conv1 -> eval/block0), and the stand-alone cases of
+    encoder_pieces.npz (random input whose pads hold garbage: a dilated 52 -> 26 convolution, a 1 x 1 convolution, blocks 1 and
+    4 in eval mode, block 1 in train mode with its running statistics).  What a stand-alone Residual does differently from
+    the fused pipeline - statistics over the raw pads, pads passed through - is part of the fixture."""
+    g = _g(golden_dir, "encoder_small.npz")
+    enc = make_encoder(O.as_torch_sd(g, "sd/"), "", npz_cfg(g, "cfg_"), DEV).eval()
+    x, lens = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    with torch.no_grad():
+        c1 = enc.conv1(x, lens)
+        np.testing.assert_allclose(c1.cpu().numpy(), g["eval/conv1"], atol=1e-5, rtol=1e-5)
+        b0 = enc.resnet_blocks[0](c1, lens)
+        np.testing.assert_allclose(b0.cpu().numpy(), g["eval/block0"], atol=2e-5, rtol=1e-5)
+
+    g = _g(golden_dir, "encoder_pieces.npz")
+    enc = make_encoder(O.as_torch_sd(g, "sd/"), "", npz_cfg(g, "cfg_"), DEV).eval()
+    h, lens = torch.from_numpy(g["h"]).to(DEV), torch.from_numpy(g["lens"]).to(DEV)
+    with torch.no_grad():
+        got = enc.resnet_blocks[2].masked_conv1(h, lens)
+        np.testing.assert_allclose(got.cpu().numpy(), g["conv/block2_masked_conv1"], atol=1e-5, rtol=1e-5)
+        got = enc.resnet_blocks[1].masked_conv2(h[:, :26].contiguous(), lens)
+        np.testing.assert_allclose(got.cpu().numpy(), g["conv/block1_masked_conv2"], atol=1e-5, rtol=1e-5)
+        for blk in (1, 4):
+            got = enc.resnet_blocks[blk](h, lens)
+            np.testing.assert_allclose(got.cpu().numpy(), g[f"eval/residual{blk}"], atol=2e-5, rtol=1e-5)
+        blk = enc.resnet_blocks[1].train()
+        got = blk(h, lens)
+        np.testing.assert_allclose(got.cpu().numpy(), g["train/residual1"], atol=2e-5, rtol=1e-5)
+        assert torch.equal(got[1, :, 1:], h[1, :, 1:])  # pads of the length-1 sequence: the raw input, bit for bit
+        for k in g.files:
+            if k.startswith("after_train/residual1."):
+                np.testing.assert_allclose(blk.state_dict()[k[len("after_train/residual1."):]].cpu().numpy(), g[k], atol=1e-6,
+                                           rtol=1e-5, err_msg=k)
+    with pytest.raises(ValueError, match=r"expected \[B, 52, L\]"):
+        enc.resnet_blocks[0](h[:, :40].contiguous(), lens)
+
+
 @pytest.mark.parametrize("B,Lmax,lens", [(3, 96, [96, 1, 40]), (2, 400, [400, 333]),
                                           (10, 512, [512, 1, 333, 512, 77, 500, 40, 511, 256, 129])])  # 256x192 conv tiles
 def test_encoder_full_width_vs_oracle(B, Lmax, lens):

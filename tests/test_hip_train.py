@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import protnote_oracle as O
+from tests.helpers import replay_label_noise  # noqa: F401
 from tests.helpers import make_protnote, random_encoder_sd, random_head_sd
 
 pytestmark = pytest.mark.gpu
@@ -107,7 +108,7 @@ def test_train_step_golden(golden_dir, fusion, loss, monkeypatch):
     cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
     y = torch.from_numpy(g["multihots"]).to(DEV)
     u = torch.from_numpy(g["train/noise_u"]).to(DEV)
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.clone())
     cfg = {"params": {"LOSS_FN": loss, "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1, "LABEL_SMOOTHING": 0.0}}
     loss_fn = get_loss(cfg, bce_pos_weight=torch.tensor(1.0))
     opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
@@ -261,6 +262,7 @@ def test_config0_shape_one_epoch_vs_oracle(golden_dir):
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     counts = torch.zeros(3, NL, device=DEV)
     real = torch.rand_like
+    model.label_noise_rng = "torch"  # replay the reference run's noise through torch.rand_like
     losses = []
     try:
         for k in range(NSEQ // BS):
@@ -659,7 +661,7 @@ def test_train_sequence_encoder_golden(golden_dir, monkeypatch):
     lab = torch.from_numpy(g["label_embeddings"])[0::2].contiguous().to(DEV)
     cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
     u = torch.from_numpy(g["train/noise_u"]).to(DEV)
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.clone())
     logits, _ = model(sequence_onehots=x, sequence_lengths=lens, label_embeddings=lab, label_token_counts=cnt)
     loss = BCEWithLogitsLoss()(logits, torch.from_numpy(g["multihots"]).to(DEV).float())
     loss.backward()
@@ -848,7 +850,7 @@ def test_output_mlp_without_batchnorm_golden(golden_dir, loss, monkeypatch):
     cnt = torch.from_numpy(g["label_token_counts"])[0::2].contiguous().to(DEV)
     y = torch.from_numpy(g["multihots"]).to(DEV)
     u = torch.from_numpy(g["train/noise_u"]).to(DEV)
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.clone())
     cfg = {"params": {"LOSS_FN": loss, "FOCAL_LOSS_GAMMA": 2, "FOCAL_LOSS_ALPHA": -1, "LABEL_SMOOTHING": 0.0}}
     loss_fn = get_loss(cfg, bce_pos_weight=torch.tensor(1.0))
     opt = FusedClipAdam(head_parameters(model), lr=3e-4, max_norm=1.0)
@@ -1205,7 +1207,7 @@ def test_attention_pooling_golden(golden_dir, monkeypatch):
 
     model.train()
     u = torch.from_numpy(g["train/noise_u"]).to(DEV)
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: u.clone())
+    replay_label_noise(monkeypatch, lambda t, *a, **k: u.clone())
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     params = trainable_parameters(model)
     assert any(p is model.raw_attn_scorer.weight for p in params)
@@ -1491,7 +1493,7 @@ def _run_optimizer_case(g, case, monkeypatch):
                "label_multihots": torch.from_numpy(g[f"batch{k}/multihots"]).to(DEV),
                "label_embeddings": lab, "label_token_counts": cnt} for k in range(n)]
     queue = [torch.from_numpy(g[f"batch{k}/noise_u"]).to(DEV) for k in range(n)]
-    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: queue.pop(0))
+    replay_label_noise(monkeypatch, lambda t, *a, **k: queue.pop(0))
     seen = []
     h = model.register_forward_hook(lambda m, a, out: seen.append(out[0].detach().clone()))
     metrics = trainer.train_one_epoch(loader)

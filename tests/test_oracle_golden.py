@@ -421,3 +421,27 @@ def test_config_holes_one_hidden_layer_and_save_embeddings(golden_dir, case):
         if k.startswith("train/sd_after/"):
             name = k[len("train/sd_after/"):]
             np.testing.assert_allclose(sd[name].numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=name)
+
+
+def test_encoder_pieces_standalone(golden_dir):
+    """MaskedConv1D.forward / Residual.forward called stand-alone on inputs with garbage pads (reference-generated
+    encoder_pieces.npz): the oracle's masked_conv1d / residual_block restate them - bn1 on the RAW input, the residual added
+    back unmasked - eval and train mode (running statistics included)."""
+    g = _load(golden_dir, "encoder_pieces.npz")
+    sd = O.as_torch_sd(g, "sd/")
+    h, lens = torch.from_numpy(g["h"]), torch.from_numpy(g["lens"])
+    p2, p1 = "resnet_blocks.2.", "resnet_blocks.1."
+    got = O.masked_conv1d(h, lens, sd[p2 + "masked_conv1.weight"], sd[p2 + "masked_conv1.bias"], 9)
+    np.testing.assert_allclose(got.numpy(), g["conv/block2_masked_conv1"], atol=1e-5, rtol=1e-5)
+    got = O.masked_conv1d(h[:, :26].contiguous(), lens, sd[p1 + "masked_conv2.weight"], sd[p1 + "masked_conv2.bias"], 1)
+    np.testing.assert_allclose(got.numpy(), g["conv/block1_masked_conv2"], atol=1e-5, rtol=1e-5)
+    for blk, dil in ((1, 3), (4, 81)):
+        got = O.residual_block(h, lens, {k: v.clone() for k, v in sd.items()}, f"resnet_blocks.{blk}.", dil, False)
+        np.testing.assert_allclose(got.numpy(), g[f"eval/residual{blk}"], atol=2e-5, rtol=1e-5)
+    work = {k: v.clone() for k, v in sd.items()}
+    got = O.residual_block(h, lens, work, p1, 3, True)
+    np.testing.assert_allclose(got.numpy(), g["train/residual1"], atol=2e-5, rtol=1e-5)
+    assert np.abs(got.numpy()[1, :, 1:] - g["h"][1, :, 1:]).max() == 0.0  # pads of the length-1 sequence: the raw input
+    for k in g.files:
+        if k.startswith("after_train/residual1."):
+            np.testing.assert_allclose(work[p1 + k[len("after_train/residual1."):]].numpy(), g[k], atol=1e-6, rtol=1e-5, err_msg=k)
