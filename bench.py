@@ -52,6 +52,11 @@ _F32_KINDS = dict(KIND_NAMES)
 KIND_NAMES.update({1000 + k: v + " [bf16x3]" for k, v in _F32_KINDS.items()})
 # pn_set_backward_math(1): the hidden layers' backward pair-grid GEMMs on ONE bf16 product (f32 accumulation)
 KIND_NAMES.update({1500 + k: v + " [bf16, one product]" for k, v in _F32_KINDS.items() if k < 500})
+# forward_math = bf16 with the activation operand materialised as bf16 (fwd_bf16_h.hpp): all-DMA GEMM, kind 1600 + 10 * source
+# (0 = a bf16 activation the previous layer's epilogue wrote, 1 = relu(bn(z)), 2 = pair sum) + epilogue (5 = stores bf16)
+KIND_NAMES.update({1600 + 10 * a + e: f"nt:{an}->{en} [bf16, one product, operand materialised as bf16]"
+                   for a, an in ((0, "h16"), (1, "bn_relu(z)"), (2, "pairsum_relu"))
+                   for e, en in ((0, "store"), (2, "rowdot"), (5, "store h16"))})
 # HBM-bound streaming stages (pn_prof kinds >= 2000; the library reports their ALGORITHMIC bytes, include/protnote_hip.h)
 STAGE_NAMES = {
     2001: ("K2 conv1 from one-hots (k_ncl_to_nlc + 20-channel conv)", "4 B x (20 read + 1100 written) per residue"),
@@ -64,6 +69,8 @@ STAGE_NAMES = {
     2007: ("layer-1 masked reduction (k_pair_mask_reduce_fused)", "G read once (4 B x h per row)"),
     2008: ("row-dot logits (k_rowdot_rows_reg)", "top pre-activation read (4 B x h per row), 4 B written"),
     2009: ("conv operand staging (k_conv_stage_act)", "activation read + staged image written"),
+    2010: ("forward operand materialised as bf16 (k_make_h_bf16)", "2 B x h written per row; from a stored z also 4 B x h read "
+                                                                  "(the pair-sum kind reads L2-resident tables)"),
 }
 # VALU-bound stages (pn_prof kinds >= 3000; the library reports their algorithmic vector instructions per lane-element)
 VALU_STAGE_NAMES = {
@@ -785,7 +792,7 @@ def main():
             _lib.set_math_mode("f32")
 
         def one_product(prof, pick):
-            sel = {k: v for k, v in gemm_kinds(prof).items() if 1500 <= k < 2000 and v[0] > 0 and v[2] / v[0] > 1e12 and pick(k)}
+            sel = {k: v for k, v in gemm_kinds(prof).items() if 1500 <= k < 2000 and v[0] > 0 and v[2] / v[0] > 5e11 and pick(k)}
             ms, fl, n = sum(v[1] for v in sel.values()), sum(v[2] for v in sel.values()), sum(v[0] for v in sel.values())
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -793,7 +800,7 @@ def main():
                     "flops_per_launch": fl / max(n, 1), "family_ms": ms}
 
         # forward kinds: the generated-operand NT launches (1500 + 10 * {1: bn_relu, 2: pairsum}); backward: nt:plain (dh) + tn:*
-        fwd_roof = one_product(a_prof, lambda k: (k - 1500) in (10, 20))
+        fwd_roof = one_product(a_prof, lambda k: (k - 1500) in (10, 20) or 1600 <= k < 1700)
         fwd_roof["kernel"] = "forward pair-grid GEMMs z_l = h_{l-1} W_l^T on one bf16 product (operands rounded while staging)"
         all_roof = one_product(a_prof, lambda k: True)
         all_roof["kernel"] = "all six full-grid 3072x3072 launches of the step (2 forward, 4 backward) on one bf16 product"

@@ -442,6 +442,11 @@ int pn_get_backward_math(void);
  * the mask code); shapes the single-product kernel does not cover (hidden width not a multiple of 256) fall back likewise. */
 int pn_set_forward_math(int mode);
 int pn_get_forward_math(void);
+/* Route of mode 1: 1 (default) = the activation operand h_{l-1} is written once per chunk as bf16 (k_make_h_bf16) and both
+ * operands of z_l = h_{l-1} W_l^T go by LDS-DMA (gemm_nt_bf16dma_kernel; needs a hidden width that is a multiple of 256);
+ * 0 = the single-product instantiation of the bf16x3 kernel rounds the operand while staging it through registers.  Same bf16
+ * values in the same products, another k order inside a 16-k MFMA step: the routes agree to f32 summation order.  A/B switch. */
+int pn_set_fwd_staged(int on);
 /* Kernels of mode 1, a bit mask (default 7).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
  * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel.  Bit 1: dW = dz^T h
  * on the transpose-read kernel (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16) instead of the single-product

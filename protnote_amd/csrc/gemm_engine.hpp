@@ -37,7 +37,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   A_PAIRPROD: A[r % pairB][k] * A2[r / pairB][k]  (the P (.) L block of concatenation_prod, ProtNote.py:139-150)
 enum { A_PLAIN = 0, A_AFFINE_RELU = 1, A_PAIRSUM_RELU = 2, A_CONV = 3, A_DZ_ELEM = 4, A_DZ_ROWG = 5, A_PAIRPROD = 6 };
 // E_PAIRADD: E_STORE plus the separable part of the first pair layer, out = acc + X1[r % pairB][n] + X2[r / pairB][n]
-enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3, E_PAIRADD = 4 };
+// E_STORE_H16: relu(acc * e_scale[n] + e_shift[n]) stored as bf16 (C is a uint16 matrix, ldc in bf16 elements): the eval-mode
+//              producer of the AMP-class forward writes the next layer's operand in the form its all-DMA consumer stages
+enum { E_STORE = 0, E_CONV = 1, E_ROWDOT = 2, E_SCALE_RC = 3, E_PAIRADD = 4, E_STORE_H16 = 5 };
 
 struct GemmParams {
   int M, N;          // output rows / true output columns
@@ -214,6 +216,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         ew = p.e_w[col];
       }
     }
+    if constexpr (EK == E_STORE_H16) {
+      if (cok) {
+        es = p.e_scale[col];
+        et = p.e_shift[col];
+      }
+    }
     const bool store_act = (EK == E_STORE) && (p.e_scale != nullptr);
     if constexpr (EK == E_STORE) {
       if (store_act && cok) {
@@ -271,6 +279,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           if (rok) {
             s1 += v;
             s2 += v * v;
+          }
+        } else if constexpr (EK == E_STORE_H16) {
+          if (rok && cok) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+            const bf16x2_ hv = __builtin_convertvector(f32x2_{relu(fmaf(v, es, et)), 0.f}, bf16x2_);  // v_cvt_pk_bf16_f32: RNE
+            reinterpret_cast<__bf16*>(p.C)[(long)row * p.ldc + col] = hv[0];
           }
         } else if constexpr (EK == E_SCALE_RC) {
           if (rok && cok) p.C[(long)row * p.ldc + col] = v * p.row_scale[row] * cs;

@@ -292,12 +292,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_fast_kernel(const TnParams p) 
       slab(t, I0{});
       slab(t + 1, I1{});
     }
+#ifdef PN_TN_TAIL_RT
+    // Experiment: the two compile-time copies of the last slab below make hipcc spill ~850-990 registers
+    // in the TAIL (the 256-MFMA loop body is spill-free; the spills run once per workgroup and split).  Variant: the last slab
+    // through a run-time buffer offset, as gemm_tn_bf16tr_kernel does - one copy of its code.
+    if (t < last) slab(t, I0{});  // one more full slab: the last one then sits in buffer 1
+    fa_addr += (unsigned)(last & 1) * TILEB;
+    fb_addr += (unsigned)(last & 1) * TILEB;
+    last_slab(I0{});
+#else
     if (t < last) {  // one more full slab, then the last one sits in buffer 1
       slab(t, I0{});
       last_slab(I1{});
     } else {
       last_slab(I0{});
     }
+#endif
   }
 
   float* out = p.Cpart + (long)split * p.M * p.ldc;

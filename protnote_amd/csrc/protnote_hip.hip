@@ -16,6 +16,7 @@
 #include "gemm_tn_fast.hpp"
 #include "train_kernels.hpp"
 #include "bwd_bf16_dz.hpp"
+#include "fwd_bf16_h.hpp"
 
 using namespace pn;
 
@@ -417,6 +418,10 @@ struct FwdBf16Scope {
   explicit FwdBf16Scope(bool on) : prev(tl_fwd_bf16) { tl_fwd_bf16 = on; }
   ~FwdBf16Scope() { tl_fwd_bf16 = prev; }
 };
+static bool fwd_bf16_requested(const pn_pairhead* hd) {  // (workspace sizing: the same rule as fwd_math_of, no error path)
+  const int m = hd->forward_math == 0 ? g_fwd_math.load(std::memory_order_relaxed) : hd->forward_math - 1;
+  return m == 1 && hd->dropout_p == 0.f;
+}
 static int fwd_math_of(const pn_pairhead* hd, bool* bf16) {
   if (hd->forward_math < 0 || hd->forward_math > 2)
     return fail("pairhead: forward_math %d (0 = library default, 1 = as math_mode, 2 = bf16)", hd->forward_math);
@@ -549,6 +554,77 @@ static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k_round_plane, dim3(nblk((long)p.N * p.Kseg / 4, 256)), dim3(256), 0, st, p.W, p.ldw, p.N, p.Kseg, p.wsplit);
   {
     ProfScope ps(1500 + A_PLAIN * 10 + E_STORE, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16DMA_LDS_BYTES, st, pp);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+#ifndef PN_BIG
+#define PN_BIG 1
+#endif
+// ---- AMP-class forward with the activation operand materialised as bf16 (fwd_bf16_h.hpp) ----
+// pn_set_fwd_staged(0) keeps the register-staged single-product kernels (the NP = 1 instantiations of gemm_bf16x3.hpp) for the
+// forward: same bf16 values in the same products, another k order inside a 16-k MFMA step (A/B timing, and the test that holds
+// the two routes to each other).
+static std::atomic<int> g_fwd_staged{1};
+extern "C" int pn_set_fwd_staged(int on) {
+  g_fwd_staged = on ? 1 : 0;
+  return 0;
+}
+static thread_local bool tl_fwd_nostage = false;  // pn_pairhead_fwd_eval_hidden reads f32 activations back: register-staged route
+static const long FWD_H_ROWS = 262144;            // pair rows per materialised chunk (a multiple of the 256-row tile)
+static bool fwd_staged_shape(int h) { return PN_BIG && h % 256 == 0 && h >= 256 && h <= 8192; }
+static bool fwd_staged_on(bool fwd_bf16, int h) { return fwd_bf16 && g_fwd_staged == 1 && !tl_fwd_nostage && fwd_staged_shape(h); }
+enum { ST_MAKE_H = 2010 };
+
+// h (bf16, [rows][C]) for pair rows [r0, r0 + rows): kind 0 = relu(A'[i] + B'[j]), 1 = relu(s z + t), 2 = round(z)
+static int make_h(int kind, long r0, long rows, int C, const float* A, long lda, const float* A2, long lda2, int pairB,
+                  const float* s, const float* t, uint16_t* out, hipStream_t st) {
+  if (rows <= 0) return 0;
+  MakeHParams P;
+  memset(&P, 0, sizeof(P));
+  P.r0 = r0; P.rows = rows; P.C = C; P.pairB = pairB > 0 ? pairB : 1; P.A = A; P.lda = lda; P.A2 = A2; P.lda2 = lda2;
+  P.s = s; P.t = t; P.out = out;
+  const int rpb = 16;
+  const dim3 grid(nblk(rows, rpb)), block(C / 8);
+  // algorithmic bytes: 2 B written per element; kinds 1 / 2 also read the 4 B pre-activation (kind 0 reads L2-resident tables)
+  ProfScope ps(ST_MAKE_H, (double)rows * (double)C * (kind == 0 ? 2.0 : 6.0), st);
+  if (kind == 0) hipLaunchKernelGGL((k_make_h_bf16<0>), grid, block, 0, st, P, rpb);
+  else if (kind == 1) hipLaunchKernelGGL((k_make_h_bf16<1>), grid, block, 0, st, P, rpb);
+  else hipLaunchKernelGGL((k_make_h_bf16<2>), grid, block, 0, st, P, rpb);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// C = H W^T, H = bf16 [M][K] dense (make_h / an E_STORE_H16 producer), W = the pre-rounded plane p.w_hi (k_round_plane):
+// gemm_nt_bf16dma_kernel with epilogue EK.  src_kind (0 plain, 1 bn_relu, 2 pairsum) only labels the profile kind.
+template <int EK>
+static int launch_gemm_h16(const GemmParams& p, int src_kind, hipStream_t st) {
+  auto kern = gemm_nt_bf16dma_kernel<EK>;
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  if (dev < 64 && !attr_done[dev]) {
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
+    attr_done[dev] = true;
+  }
+  if (p.M <= 0 || p.Nstore <= 0) return 0;
+  if (p.w_hi == nullptr || p.Kseg % 64 != 0 || p.N % 256 != 0 || p.Nstore != p.N || (long)256 * p.lda * 4 >= (1L << 32) ||
+      (long)256 * p.Kseg * 2 >= (1L << 32))
+    return fail("gemm (bf16 h): shape %d x %d x %d not supported", p.M, p.N, p.Kseg);
+  const long tm = (p.M + 255) / 256, tn = p.N / 256;
+  GemmParams pp = p;
+  pp.xcd_bc = (PN_XCD && tm >= 16) ? ((tn % 8 == 0) ? 8 : ((tn % 4 == 0) ? 4 : 0)) : 0;
+  pp.xcd_br = pp.xcd_bc ? 32 / pp.xcd_bc : 0;
+  long grid = tm * tn;
+  if (pp.xcd_bc) {
+    const long nblk_ = ((tm + pp.xcd_br - 1) / pp.xcd_br) * (tn / pp.xcd_bc);
+    grid = ((nblk_ + 7) / 8) * 8 * 32;
+  }
+  if (grid > 0x7fffffffL) return fail("gemm: grid too large");
+  {
+    ProfScope ps(1600 + src_kind * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16DMA_LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());
@@ -1567,6 +1643,7 @@ extern "C" int pn_mlp_rows_fwd_eval(const pn_mlp* m, const float* x, int ldx, in
 struct PairWs {
   float *A1, *B1, *weff, *z[2], *partials, *s[PN_MAX_LAYERS], *t[PN_MAX_LAYERS];
   uint16_t* wsplit;  // bf16x3 mode: hi / lo planes of the layer's weight (h x h x 4 bytes)
+  uint16_t* hbuf[2];  // forward_math = bf16: the chunk's activation operand materialised as bf16 (fwd_bf16_h.hpp), ping-pong
   int nparts;
 };
 
@@ -1588,6 +1665,12 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
     w.t[i] = bp.take<float>(h);
   }
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
+  // (carved LAST and by the descriptor alone: the fields above sit where they always sat)
+  w.hbuf[0] = w.hbuf[1] = nullptr;
+  if (fwd_bf16_requested(hd) && fwd_staged_shape(h)) {
+    w.hbuf[0] = (uint16_t*)bp.take<float>((size_t)crow * h / 2);
+    if (hd->nlayers > 2) w.hbuf[1] = (uint16_t*)bp.take<float>((size_t)crow * h / 2);
+  }
   return bp.ok;
 }
 
@@ -1681,6 +1764,39 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
       PN_OK((launch_gemm<A_PAIRPROD, E_PAIRADD>(p, 0, st)));
       in = w.z[zsel];
       zsel ^= 1;
+    }
+    if (fwd_staged_on(fwd_bf16, h) && w.hbuf[0] != nullptr) {
+      // AMP-class forward, materialised operand (fwd_bf16_h.hpp): h_{li-1} of this chunk as bf16 -> all-DMA GEMM; a hidden
+      // layer's epilogue writes the next operand directly (E_STORE_H16: relu(bn(z)) rounded once), the last one the row-dot
+      int hsel = 0;
+      bool have_h = false;
+      for (int li = 1; li < hd->nlayers; ++li) {
+        const bool last = (li + 1 == hd->nlayers);
+        if (li == 1 && !prod)
+          PN_OK(make_h(0, (long)j0 * B, rows, h, w.A1, h, w.B1, h, B, nullptr, nullptr, w.hbuf[hsel], st));
+        else if (!have_h)  // concatenation_prod: the stored raw z1 of this chunk through its fold
+          PN_OK(make_h(1, 0, rows, h, in, h, nullptr, 0, 1, w.s[li - 1], w.t[li - 1], w.hbuf[hsel], st));
+        hipLaunchKernelGGL(k_round_plane, dim3(nblk((long)h * h / 4, 256)), dim3(256), 0, st, hd->w[li], (long)h, h, h, w.wsplit);
+        GemmParams p = gp_zero();
+        p.M = (int)rows; p.N = h; p.Nstore = h; p.Kseg = h;
+        p.A = (const float*)w.hbuf[hsel]; p.lda = h / 2; p.w_hi = w.wsplit;
+        p.e_scale = w.s[li]; p.e_shift = w.t[li];
+        const int src = (li == 1 && !prod) ? 2 : (have_h ? 0 : 1);
+        if (last) {
+          p.e_w = hd->w_out; p.rowdot_out = w.partials;
+          PN_OK((launch_gemm_h16<E_ROWDOT>(p, src, st)));
+        } else {
+          if (w.hbuf[hsel ^ 1] == nullptr) return fail("pairhead: internal h buffers");
+          p.C = (float*)w.hbuf[hsel ^ 1]; p.ldc = h;
+          PN_OK((launch_gemm_h16<E_STORE_H16>(p, src, st)));
+          hsel ^= 1;
+          have_h = true;
+        }
+      }
+      hipLaunchKernelGGL(k_rowdot_reduce, dim3(nblk(rows, 256)), dim3(256), 0, st, w.partials, w.nparts, rows, hd->b_out,
+                         logits_pairs + (long)j0 * B);
+      HIP_OK(hipGetLastError());
+      continue;
     }
     FwdBf16Scope fwd_scope(fwd_bf16);  // the hidden layers' pair-grid GEMMs below (the layer-1 GEMM of _prod above is not one)
     for (int li = 1; li < hd->nlayers; ++li) {
@@ -2438,6 +2554,7 @@ struct PairTrainWs {
   StatScr statscr;
   uint16_t* wsplit;  // bf16x3 mode: hi / lo planes of the weight operand of the current pair-grid GEMM
   int* tnsync;       // pacing counters of the big weight-gradient kernel (launch_tn_fast)
+  uint16_t* hbf;     // forward_math = bf16: one chunk (FWD_H_ROWS pair rows) of the activation operand as bf16
 };
 static const long PAIR_STATS_ROWS = 4096;
 static const int SUM_BLOCKS = 1024;
@@ -2476,6 +2593,11 @@ static bool pair_train_ws_carve(const pn_pairhead* hd, int B, int NL, Bump& bp, 
   statscr_carve(bp, (long)B * NL, PAIR_STATS_ROWS, h, w.statscr);
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
   w.tnsync = bp.take<int>(TN_SYNC_INTS);
+  w.hbf = nullptr;  // (last, and by the descriptor alone: forward and backward carve the same layout)
+  if (fwd_bf16_requested(hd) && fwd_staged_shape(h) && hd->nlayers > 1) {
+    const long R = (long)B * NL;
+    w.hbf = (uint16_t*)bp.take<float>((size_t)(R < FWD_H_ROWS ? R : FWD_H_ROWS) * h / 2);
+  }
   return bp.ok;
 }
 
@@ -2614,7 +2736,28 @@ extern "C" int pn_pairhead_fwd_train(const pn_pairhead* hd, const float* P_e, co
       const DropSpec ds = drop_spec(hd->dropout_p, hd->dropout_seed, DROP_STREAM_PAIR + (l - 1));
       p.drop_seed = ds.seed; p.drop_thresh = ds.thresh; p.drop_scale = ds.scale;
     }
-    {
+    if (fwd_staged_on(fwd_bf16, h) && w.hbf != nullptr) {
+      // AMP-class forward, materialised operand (fwd_bf16_h.hpp): per chunk of FWD_H_ROWS pair rows h_{l-1} is written once
+      // as bf16 and z_l = h_{l-1} W_l^T runs all-DMA; every chunk leaves its BatchNorm column partials in its own slots of
+      // the partial buffer (row tiles numbered across the chunks) and ONE fixed-order reduction adds them
+      hipLaunchKernelGGL(k_round_plane, dim3(nblk((long)h * h / 4, 256)), dim3(256), 0, st, hd->w[l], (long)h, h, h, w.wsplit);
+      long tiles = 0;
+      for (long r0 = 0; r0 < R; r0 += FWD_H_ROWS) {
+        const long rows = R - r0 < FWD_H_ROWS ? R - r0 : FWD_H_ROWS;
+        if (l == 1 && !prod)
+          PN_OK(make_h(0, r0, rows, h, sv.Ap, h, sv.Bp, h, B, nullptr, nullptr, w.hbf, st));
+        else
+          PN_OK(make_h(1, r0, rows, h, sv.zbuf[l - 1] + (size_t)S * h, h, nullptr, 0, 1, sv.s[l - 1], sv.t[l - 1], w.hbf, st));
+        GemmParams q = gp_zero();
+        q.M = (int)rows; q.N = h; q.Nstore = h; q.Kseg = h;
+        q.A = (const float*)w.hbf; q.lda = h / 2; q.w_hi = w.wsplit;
+        q.C = z + (size_t)r0 * h; q.ldc = h;
+        q.col_part = w.colscr.part + (size_t)tiles * 2 * h;
+        PN_OK((launch_gemm_h16<E_STORE>(q, (l == 1 && !prod) ? 2 : 1, st)));
+        tiles += (rows + 255) / 256;
+      }
+      PN_OK(reduce_parts<float>(w.colscr.part, tiles, 2 * h, h, w.S1, w.S2, nullptr, w.colscr.red, st));
+    } else {
       FwdBf16Scope fwd_scope(fwd_bf16);
       if (l == 1 && !prod) {
         p.A = sv.Ap; p.lda = h; p.A2 = sv.Bp; p.lda2 = h; p.pairB = B;
@@ -3268,6 +3411,11 @@ extern "C" int pn_pairhead_fwd_eval_hidden(const pn_pairhead* hd, const float* P
   MathScope math_scope(hd->math_mode);
   bool fwd_bf16 = false;
   PN_OK(fwd_math_of(hd, &fwd_bf16));
+  struct NoStage {  // this entry point reads the f32 activations of the chunk back: the register-staged single-product route
+    bool prev;
+    NoStage() : prev(tl_fwd_nostage) { tl_fwd_nostage = true; }
+    ~NoStage() { tl_fwd_nostage = prev; }
+  } no_stage;
   hipStream_t st = (hipStream_t)stream;
   const int h = hd->h;
   const long R = (long)B * NL;

@@ -144,7 +144,11 @@ class _SupConFn(torch.autograd.Function):
             raise ValueError("expected logits and targets of the same [B, N] shape")
         x = logits.detach().float().contiguous()
         B, N = x.shape
-        tgt, tkind = L.typed_targets(target)  # int64 (the reference collator's dtype), uint8 / bool (1 B per pair) or float32
+        tf = ti = None  # (pn_supcon_fwd_bwd keeps the two-pointer form: int64 or float32 targets)
+        if target.dtype == torch.int64:
+            ti = target.contiguous()
+        else:
+            tf = target.detach().float().contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         dlog = torch.empty_like(x)
         ws = L.workspace(L.lib().pn_supcon_ws_bytes(B), x.device, "loss")

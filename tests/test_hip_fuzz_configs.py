@@ -119,6 +119,14 @@ def _run_head_case(c):
     rl_ = O.protnote_forward(work, None, None, lab.double(), fusion=c["fusion"], training=True, sequence_embeddings=P_f.double())
     rloss = O.bce_loss(rl_, y.double())
     rg = dict(zip(names, torch.autograd.grad(rloss, [leaves[k] for k in names], allow_unused=True)))
+    # the yardstick of the deep cases: the oracle's own f32 run against its f64 run (a BatchNorm over 2 rows, five layers deep,
+    # is ill-conditioned for any f32 implementation)
+    sd32 = {k: (v.float() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    leaves32 = {k: sd32[k].clone().requires_grad_(True) for k in names}
+    work32 = dict(sd32)
+    work32.update(leaves32)
+    rl32 = O.protnote_forward(work32, None, None, lab, fusion=c["fusion"], training=True, sequence_embeddings=P_f)
+    rg32 = dict(zip(names, torch.autograd.grad(O.bce_loss(rl32, y), [leaves32[k] for k in names], allow_unused=True)))
     scale = max(1.0, rl_.abs().max().item())
     assert (logits.detach().cpu().double() - rl_.detach()).abs().max().item() < 5e-4 * scale, c
     assert abs(loss.item() - rloss.item()) < 1e-4 * max(1.0, abs(rloss.item()))
@@ -128,7 +136,8 @@ def _run_head_case(c):
             continue
         assert named[k].grad is not None, k
         rel = (named[k].grad.cpu().double() - r).norm().item() / max(r.norm().item(), 1e-30)
-        assert rel < 3e-3 or (named[k].grad.cpu().double() - r).abs().max().item() < 1e-7, (c, k, rel)
+        rel32 = (rg32[k].double() - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert rel < max(3e-3, 4.0 * rel32) or (named[k].grad.cpu().double() - r).abs().max().item() < 1e-7, (c, k, rel, rel32)
     # BatchNorm buffers after the train-mode forward (the oracle's functional batch_norm advanced sd64's buffers in place)
     after = model.state_dict()
     for k, v in work.items():

@@ -243,7 +243,7 @@ def test_forward_bf16_other_shapes_vs_oracle(B, NL, latent, scale, nl, fusion):
         rel, amp = _rel(p.grad.double().cpu(), g64[name]), _rel(g_amp[name], g64[name])
         if rel > worst[1]:
             worst = (name, rel, amp)
-        assert rel <= 2.0 * amp + 1e-6 and rel < 0.1, (name, rel, amp)
+        assert rel <= 2.0 * amp + 1e-6 and rel < 0.25, (name, rel, amp)   # (five bf16 layers: 0.10 on W_l.0, autocast 0.16)
     model.load_state_dict(sd)  # (the train-mode forward advanced the BatchNorm buffers)
     model.eval()
     with torch.no_grad():
@@ -353,3 +353,61 @@ def test_forward_math_switches():
         model.forward_math = None
     assert torch.equal(per_model, by_default) and not torch.equal(per_model, base)
     assert torch.equal(explicit_same, base)
+
+
+@pytest.mark.parametrize("fusion,nl,B,NL", [("concatenation", 3, 96, 730), ("concatenation_prod", 3, 64, 500),
+                                             ("concatenation", 2, 40, 300), ("concatenation_diff", 5, 33, 410)])
+def test_forward_bf16_routes_agree(fusion, nl, B, NL):
+    """pn_set_fwd_staged: 1 (default) = the activation operand is written once per chunk as bf16 and both operands go by
+    LDS-DMA (fwd_bf16_h.hpp: k_make_h_bf16 + gemm_nt_bf16dma_kernel, E_STORE_H16 producers in eval); 0 = the register-staged
+    single-product kernels round it while staging.  The same bf16 values meet in the same products - only the k order inside a
+    16-k MFMA step differs - so eval logits, train logits, the BatchNorm buffers and every gradient agree to f32 summation
+    order; each route is bit-reproducible; and both differ from forward_math = "same" (ragged row tiles, several eval chunks)."""
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(51)
+    in_mult = 2 if fusion == "concatenation" else 3
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, nl, in_mult=in_mult)
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.1).float().to(DEV)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=nl, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, feature_fusion=fusion)
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.pair_label_chunk = 300  # several chunks in the eval head
+
+    def run(staged, fwd="bf16"):
+        L.check(L.lib().pn_set_fwd_staged(staged))
+        try:
+            model.forward_math = fwd
+            model.load_state_dict(sd)
+            model.eval()
+            with torch.no_grad():
+                ev, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            model.train()
+            for p in model.parameters():
+                p.grad = None
+            lg, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            BCEWithLogitsLoss()(lg, y).backward()
+            bufs = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+            return ev.clone(), lg.detach().clone(), bufs, {n: p.grad.clone() for n, p in model.named_parameters()}
+        finally:
+            L.lib().pn_set_fwd_staged(1)
+
+    a, a2, b, c = run(1), run(1), run(0), run(1, "same")
+    for x, y_ in zip(a[:2], a2[:2]):
+        assert torch.equal(x, y_)                                     # the staged route is bit-reproducible
+    assert all(torch.equal(a[3][n], a2[3][n]) for n in a[3])
+    scale = max(1.0, float(a[0].abs().max()))
+    d_ev, d_tr = float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max())
+    assert 0.0 < d_ev < 2e-4 * scale and d_tr < 2e-4 * scale, (d_ev, d_tr, scale)   # f32 summation order, not bf16 class
+    assert float((a[0] - c[0]).abs().max()) > 20 * d_ev              # ... which is what separates both from the f32 forward
+    for k in a[2]:
+        np.testing.assert_allclose(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    worst = max(_rel(a[3][n].double(), b[3][n].double()) for n in a[3])
+    assert worst < 2e-3, worst   # ReLU-mask flips of pre-activations that differ in the last bits; the bf16 class is ~1e-2
+    print(f"[{fusion}, {nl} layers, {B} x {NL}] staged vs register-staged bf16 forward: eval {d_ev:.2e}, train {d_tr:.2e}, "
+          f"worst gradient {worst:.2e}")

@@ -168,7 +168,10 @@ def test_kernel_label_noise_hook_and_distribution():
     u = torch.empty_like(x)
     L.check(L.lib().pn_label_noise_seeded(L.ptr(x), seed, scale, L.ptr(out), rows, cols, L.stream_ptr()))
     L.check(L.lib().pn_uniform(seed, rows, cols, L.ptr(u), L.stream_ptr()))
-    assert torch.equal(out, x + (2.0 * u - 1.0) * scale)
+    ref = torch.empty_like(x)   # the explicit-u kernel on the hook's draw: the same expression, bit for bit
+    L.check(L.lib().pn_label_noise(L.ptr(x), L.ptr(u), scale, L.ptr(ref), x.numel(), L.stream_ptr()))
+    assert torch.equal(out, ref)
+    assert float((out.double() - (x.double() + (2.0 * u.double() - 1.0) * scale)).abs().max()) < 5e-7   # (fma vs mul + add)
     ud = u.double()
     assert float(ud.min()) >= 0.0 and float(ud.max()) < 1.0
     assert torch.equal(u * 16777216.0, torch.floor(u * 16777216.0))   # the 24-bit grid of torch's own float uniform

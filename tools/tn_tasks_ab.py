@@ -27,7 +27,8 @@ def main():
     dev = torch.device("cuda:0")
     steps = int(os.environ.get("PN_STEPS", "6"))
     model = bench.build_model(dev).train()
-    model.math_mode, model.backward_math = os.environ.get("PN_AB_FORWARD", "bf16x3"), "bf16"
+    model.math_mode, model.backward_math = os.environ.get("PN_AB_FORWARD", "bf16x3"), os.environ.get("PN_AB_BACKWARD", "bf16")
+    model.forward_math = os.environ.get("PN_AB_FORWARD_MATH", "same")
     opt = FusedClipAdam(list(head_parameters(model)), lr=3e-4, max_norm=1.0)
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     batch = bench.synthetic_batch(256, 512, 32102, dev, seed=1000)
@@ -41,7 +42,10 @@ def main():
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
     prof = _lib.prof_end()
-    out = {"build_hash": _lib.build_hash(), "csrc_hash_now": build.csrc_hash(), "extra_flags": build._extra(),
+    # a checksum of every gradient-updated weight after the timed steps: A/B variants that claim bit-identity must agree on it
+    checksum = float(opt.flat_w.double().sum().item())
+    out = {"build_hash": _lib.build_hash(), "flat_w_checksum": repr(checksum),
+           "modes": {"math": model.math_mode, "forward_math": model.forward_math, "backward_math": model.backward_math}, "csrc_hash_now": build.csrc_hash(), "extra_flags": build._extra(),
            "steps": steps, "ms_per_step": dt * 1e3, "final_loss": float(loss),
            "per_launch_ms": {bench.KIND_NAMES.get(k, str(k)): round(v[1] / v[0], 3) for k, v in sorted(bench.gemm_kinds(prof).items())
                              if v[0] > 0 and v[2] / v[0] > 1e12},
