@@ -488,7 +488,9 @@ int pn_dropout_mask(unsigned seed, int stream, float p, long rows, int cols, flo
  * ALGORITHMIC BYTES of the launches (what the pass must read + write once): 2001 conv1 from one-hots (K2),
  * 2002 masked mean-pool (K6), 2003 loss + dlogits + TP/FN/FP (K13/K14), 2004 clip + Adam/SGD (K16),
  * 2005 dz in place, 2006 BatchNorm-backward statistics, 2007 layer-1 masked reduction, 2008 row-dot logits,
- * 2009 convolution operand staging.  Kinds >= 3000 are VALU-bound stages; `total_flops` carries their algorithmic vector
+ * 2009 convolution operand staging, 2010 the AMP-class forward's activation operand written as bf16.  GEMM kinds carry the
+ * arithmetic as an offset: + 1000 bf16x3, + 1500 one bf16 product (NT) / + 1600 (TN), 1700 + 10 * source + epilogue = one bf16
+ * product on a materialised bf16 operand (source 0 = a bf16 activation, 1 = relu(bn(z)), 2 = pair sum).  Kinds >= 3000 are VALU-bound stages; `total_flops` carries their algorithmic vector
  * instructions per lane-element: 3001 the one-hidden-layer head's forward (3 per pair and hidden column), 3002 its backward
  * masked reductions (8).  Returns the number of kinds written. */
 int pn_prof_begin(void);

@@ -105,8 +105,11 @@ enum {
   ST_PAIR_MASK_REDUCE = 2007,  // layer-1 backward: M0 / M1 tables from one pass over the gradient
   ST_ROWDOT = 2008,       // logits from the stored top pre-activation
   ST_CONV_STAGE = 2009,   // relu(bn(x)) staged once per convolution for the all-DMA conv kernel
-  // VALU-bound stages (kinds >= 3000): the `flops` field carries the pass's ALGORITHMIC VECTOR INSTRUCTIONS per lane-element
-  // (bench.py puts them next to 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s)
+  ST_MAKE_H = 2010,       // forward_math = bf16: the activation operand of a pair-grid GEMM written once as bf16 (fwd_bf16_h.hpp)
+  // VALU-bound stages (kinds >= 3000): the `flops` field carries the pass's ALGORITHMIC VECTOR OPERATIONS per lane-element.
+  // bench.py prices them against the vector unit's issue rate, 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T issue slots/s:
+  // an add or fma has a packed f32 form (two operations per slot -> 78.6 T/s), fmaxf has none on gfx9 (one per slot), so the
+  // forward's add + max + fma mix peaks at 3 operations per 2 slots = 59 T/s; the backward is priced at the packed rate
   ST_PAIR1_FWD = 3001,    // OUTPUT_MLP_NUM_LAYERS: 1 forward: add, max, fma per pair and hidden column
   ST_PAIR1_BWD = 3002     // ... backward masked reductions on the rank-1 gradient: 8 per pair and hidden column
 };
@@ -576,7 +579,6 @@ static thread_local bool tl_fwd_nostage = false;  // pn_pairhead_fwd_eval_hidden
 static const long FWD_H_ROWS = 262144;            // pair rows per materialised chunk (a multiple of the 256-row tile)
 static bool fwd_staged_shape(int h) { return PN_BIG && h % 256 == 0 && h >= 256 && h <= 8192; }
 static bool fwd_staged_on(bool fwd_bf16, int h) { return fwd_bf16 && g_fwd_staged == 1 && !tl_fwd_nostage && fwd_staged_shape(h); }
-enum { ST_MAKE_H = 2010 };
 
 // h (bf16, [rows][C]) for pair rows [r0, r0 + rows): kind 0 = relu(A'[i] + B'[j]), 1 = relu(s z + t), 2 = round(z)
 static int make_h(int kind, long r0, long rows, int C, const float* A, long lda, const float* A2, long lda2, int pairB,
@@ -624,7 +626,8 @@ static int launch_gemm_h16(const GemmParams& p, int src_kind, hipStream_t st) {
   }
   if (grid > 0x7fffffffL) return fail("gemm: grid too large");
   {
-    ProfScope ps(1600 + src_kind * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
+    // (1700 + ...: 1500 + kind covers the single-product NT kinds 0..59 AND the TN kinds 100..122 = 1600..1622)
+    ProfScope ps(1700 + src_kind * 10 + EK, 2.0 * (double)p.M * (double)p.N * (double)p.Kseg, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NT_BF16DMA_LDS_BYTES, st, pp);
   }
   HIP_OK(hipGetLastError());

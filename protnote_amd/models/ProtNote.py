@@ -474,14 +474,10 @@ class ProtNote(nn.Module):
             if stored:
                 from .train_path import ensemble_logits, forward_train
 
-                if want_embeddings:
-                    self.__dict__["_pn_want_embeddings"] = True  # read (and cleared) by _HeadsTrainFn.forward
-                try:
-                    logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
-                                           label_token_counts, attn_mask)
-                finally:
-                    self.__dict__.pop("_pn_want_embeddings", None)
-                    saved = self.__dict__.pop("_pn_saved_embeddings", None)
+                opts = {"want_embeddings": want_embeddings}  # owned by this call: flag in, embeddings out
+                logits = forward_train(self, sequence_onehots, sequence_embeddings, sequence_lengths, L_f,
+                                       label_token_counts, attn_mask, opts)
+                saved = opts.get("embeddings")
                 ndesc = 1 if self.training else int(self.inference_descriptions_per_label)
                 if ndesc != 1:  # ProtNote.py:308-322, differentiable
                     logits = ensemble_logits(logits, ndesc)

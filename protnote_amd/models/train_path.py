@@ -116,14 +116,16 @@ class _PrivateStore(dict):
 
 class _HeadsTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, P_f, L_f, *params):
+    def forward(ctx, model, P_f, L_f, opts, *params):
+        """`opts` (a plain dict owned by the caller of this ONE forward - nothing is parked on the model, so concurrent forwards
+        on one model cannot steal each other's flags): "want_graph" = autograd is recording (this function itself
+        runs under no_grad), "want_embeddings" = save_embeddings=True, "embeddings" = where they are returned."""
         lib = L.lib()
         dev = P_f.device
         st = L.stream_ptr()
         ctx.model = model
         ctx.param_list = params
-        # autograd runs this under no_grad; whether a graph is being built was noted by forward_train
-        want_graph = bool(model.__dict__.pop("_pn_want_graph", True))
+        want_graph = bool(opts.get("want_graph", True))
         # model.eval() + autograd (reference ProtNote.forward has no mode restriction): BatchNorm normalises with its
         # running statistics and updates nothing (pn_mlp.bn_use_running)
         bn_running = ctx.bn_running = 0 if model.training else 1
@@ -192,12 +194,12 @@ class _HeadsTrainFn(torch.autograd.Function):
         pairs = torch.empty(NL * B, dtype=torch.float32, device=dev)
         L.check(lib.pn_pairhead_fwd_train(C.byref(hd), L.ptr(P_e), L.ptr(L_e), B, NL, L.ptr(pairs), chunk,
                                           L.ptr(save), save.numel(), L.ptr(ws), ws.numel(), st))
-        if model.__dict__.pop("_pn_want_embeddings", False):
+        if opts.get("want_embeddings", False):
             # save_embeddings=True (reference ProtNote.py:292-302,324-332): the penultimate output-MLP activations are read
             # back from the store this forward just filled; rows in the reference's protein-major order i * N_L + j
             hidden = torch.empty(NL, B, hd.h, dtype=torch.float32, device=dev)
             L.check(lib.pn_pairhead_train_hidden(C.byref(hd), B, NL, chunk, L.ptr(save), save.numel(), L.ptr(hidden), st))
-            model.__dict__["_pn_saved_embeddings"] = {
+            opts["embeddings"] = {
                 "output_layer_embeddings": hidden.permute(1, 0, 2).reshape(B * NL, hd.h).cpu(),
                 "joint_embeddings": model._joint_embeddings_cpu(P_e, L_e)}
             del hidden
@@ -232,7 +234,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         grads = {}
         # parameters with requires_grad False (TRAIN_PROJECTION_HEAD: False -> output_layer.*, ProtNoteTrainer.py:221-222,
         # or frozen by hand) get a NULL destination: the C side then skips their gradient GEMMs / reductions entirely
-        wanted = {id(p) for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]) if need}
+        wanted = {id(p) for p, need in zip(ctx.param_list, ctx.needs_input_grad[4:]) if need}
 
         def gbuf(p):
             if id(p) not in wanted:
@@ -303,11 +305,11 @@ class _HeadsTrainFn(torch.autograd.Function):
         mlp_bwd(model.W_l, L_f, dL_e, "W_l", dL_f)
 
         outs = []
-        for p, need in zip(ctx.param_list, ctx.needs_input_grad[3:]):
+        for p, need in zip(ctx.param_list, ctx.needs_input_grad[4:]):
             outs.append(grads.get(id(p)) if need else None)
         ctx.model = None
         ctx.own_save = None  # a private store goes back to the allocator with its backward
-        return (None, dP_f, dL_f, *outs)
+        return (None, dP_f, dL_f, None, *outs)
 
 
 def head_parameters(model):
@@ -393,7 +395,7 @@ def ensemble_logits(logits, ndesc):
 
 
 def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths, L_f, label_token_counts,
-                  attention_mask=None):
+                  attention_mask=None, opts=None):
     """Reference ProtNote.forward (ProtNote.py:219-309) on the activation-storing kernels: training mode (with or without
     autograd: under torch.no_grad() BatchNorm still takes batch statistics and advances its buffers) and eval mode with
     autograd on (BatchNorm on its running statistics, no noise, no dropout; the result is differentiable)."""
@@ -452,5 +454,6 @@ def forward_train(model, sequence_onehots, sequence_embeddings, sequence_lengths
         P_f = torch.nn.functional.dropout(P_f, p_seq, training=True)
     if p_lab > 0 and model.training:
         L_f = torch.nn.functional.dropout(L_f, p_lab, training=True)
-    model.__dict__["_pn_want_graph"] = torch.is_grad_enabled()
-    return _HeadsTrainFn.apply(model, P_f, L_f, *head_parameters(model))
+    opts = {} if opts is None else opts  # "want_embeddings" in, "embeddings" out (see _HeadsTrainFn.forward)
+    opts["want_graph"] = torch.is_grad_enabled()
+    return _HeadsTrainFn.apply(model, P_f, L_f, opts, *head_parameters(model))

@@ -28,19 +28,43 @@ def strip_ddp_prefix(state_dict):
     return state_dict
 
 
+# Full unpickling of a checkpoint executes whatever the file contains.  It is what the reference does (torch.load without
+# weights_only, utils/models.py:347), but here it is OPT-IN: set this flag (or PN_TRUST_CHECKPOINT=1) for files you trust.
+TRUST_PICKLED_CHECKPOINTS = False
+
+
+def _numpy_scalar_globals():
+    """The few numpy types a metric scalar drags into an otherwise tensor-only checkpoint (`best_val_metric` as np.float64)."""
+    out = [np.dtype, np.float64, np.float32, np.int64]
+    for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+        try:
+            out.append(__import__(mod, fromlist=["scalar"]).scalar)
+        except (ImportError, AttributeError):
+            pass
+    out += [type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64))]
+    return out
+
+
 def _load_checkpoint_file(path: str, map_location):
     """A checkpoint written by the reference's save_checkpoint (utils/models.py:304-321) holds tensors, ints and floats only, so
-    it loads under torch's restricted unpickler (weights_only=True: no code execution).  Anything that does not (a checkpoint with
-    pickled custom objects) falls back to the reference's own full unpickling (torch.load, :347) with a warning - only load such
-    files from sources you trust."""
+    it loads under torch's restricted unpickler (weights_only=True: no code execution; numpy scalar types are allow-listed for
+    a `best_val_metric` that arrives as np.float64).  A file that needs more than that is REFUSED unless the caller opted into
+    full unpickling (TRUST_PICKLED_CHECKPOINTS / PN_TRUST_CHECKPOINT=1) - a pickle that fails the restricted unpickler is
+    exactly what a malicious one looks like."""
+    import os
     import pickle
-    import warnings
 
     try:
-        return torch.load(path, map_location=map_location, weights_only=True)
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return torch.load(path, map_location=map_location, weights_only=True)
     except (pickle.UnpicklingError, RuntimeError, AttributeError) as exc:
-        warnings.warn(f"{path}: not loadable with weights_only=True ({str(exc)[:120]}); falling back to full unpickling - "
-                      "this executes whatever the file contains", stacklevel=3)
+        if not (TRUST_PICKLED_CHECKPOINTS or os.environ.get("PN_TRUST_CHECKPOINT") == "1"):
+            raise RuntimeError(f"{path}: not loadable with torch's restricted unpickler ({str(exc)[:160]}).  Full unpickling "
+                               "executes code from the file; if you trust it, set protnote_amd.utils.models."
+                               "TRUST_PICKLED_CHECKPOINTS = True (or PN_TRUST_CHECKPOINT=1) and load again") from exc
+        import warnings
+
+        warnings.warn(f"{path}: full unpickling (trusted by the caller) - this executes whatever the file contains", stacklevel=3)
         return torch.load(path, map_location=map_location, weights_only=False)
 
 

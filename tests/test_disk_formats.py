@@ -3,6 +3,7 @@ import os
 
 import numpy as np
 import pandas as pd
+import pytest
 import torch
 
 from protnote_amd.models.ProtNote import ProtNote
@@ -141,3 +142,36 @@ def test_label_embedding_pair_in_producer_layout_reads_like_the_reference_datase
     emb, counts, per = M.load_label_embedding_cache(os.path.join(d, rel), vocab, tuple(pr["descriptions"]))
     assert np.array_equal(emb.numpy(), exp["pair/sorted_label_embeddings"])
     assert np.array_equal(counts.numpy(), exp["pair/sorted_label_token_counts"]) and per == 2
+
+
+def test_checkpoints_that_need_full_unpickling_are_refused_unless_trusted(tmp_path, monkeypatch):
+    """a file that fails torch's restricted unpickler is not silently re-read with full unpickling (which executes
+    code from the file) - that is opt-in.  A numpy-scalar metric, the one non-tensor a real run puts into a checkpoint, loads
+    without it."""
+    import types
+
+    import numpy as np
+    import torch
+
+    from protnote_amd.utils import models as M
+
+    lin = torch.nn.Linear(3, 2)
+    ok = tmp_path / "ok.pt"
+    torch.save({"epoch": 3, "model_state_dict": lin.state_dict(), "optimizer_state_dict": {}, "best_val_metric": np.float64(0.5)}, ok)
+    rest = M.load_checkpoint_into(torch.nn.Linear(3, 2), str(ok))
+    assert rest["epoch"] == 3 and float(rest["best_val_metric"]) == 0.5
+
+    import sys
+    mod = types.ModuleType("pn_evil_mod")  # any custom class: the restricted unpickler refuses it
+    exec("class Evil:\n    def __init__(self):\n        self.x = 1\n", mod.__dict__)
+    monkeypatch.setitem(sys.modules, "pn_evil_mod", mod)
+    Evil = mod.Evil
+    bad = tmp_path / "bad.pt"
+    torch.save({"epoch": 1, "model_state_dict": lin.state_dict(), "extra": Evil()}, bad)
+    monkeypatch.delenv("PN_TRUST_CHECKPOINT", raising=False)
+    with pytest.raises(RuntimeError, match="restricted unpickler"):
+        M.load_checkpoint_into(torch.nn.Linear(3, 2), str(bad))
+    monkeypatch.setattr(M, "TRUST_PICKLED_CHECKPOINTS", True)
+    with pytest.warns(UserWarning, match="full unpickling"):
+        rest = M.load_checkpoint_into(torch.nn.Linear(3, 2), str(bad))
+    assert rest["extra"].x == 1

@@ -360,9 +360,13 @@ def test_forward_math_switches():
 def test_forward_bf16_routes_agree(fusion, nl, B, NL):
     """pn_set_fwd_staged: 1 (default) = the activation operand is written once per chunk as bf16 and both operands go by
     LDS-DMA (fwd_bf16_h.hpp: k_make_h_bf16 + gemm_nt_bf16dma_kernel, E_STORE_H16 producers in eval); 0 = the register-staged
-    single-product kernels round it while staging.  The same bf16 values meet in the same products - only the k order inside a
-    16-k MFMA step differs - so eval logits, train logits, the BatchNorm buffers and every gradient agree to f32 summation
-    order; each route is bit-reproducible; and both differ from forward_math = "same" (ragged row tiles, several eval chunks)."""
+    single-product kernels round it while staging.  The same bf16 values meet in the same products; what differs is the k order
+    inside a 16-k MFMA step, i.e. the f32 rounding of every pre-activation - and a pre-activation that moves by one f32 ulp can
+    land on the other side of a bf16 rounding boundary of the NEXT layer's operand (a few elements per row and layer, each
+    worth one bf16 ulp).  So the routes are two equally good draws of the same arithmetic class, not bit-twins: held here are
+    (i) each route is bit-reproducible, (ii) both are the same distance from the float64 oracle (eval and train logits within
+    1.25 x of each other), (iii) they are closer to each other than to the oracle, (iv) BatchNorm buffers and gradients
+    agree at the bf16 class."""
     from protnote_amd import _lib as L
     from protnote_amd.models.ProtNote import ProtNote
     from protnote_amd.utils.losses import BCEWithLogitsLoss
@@ -370,19 +374,23 @@ def test_forward_bf16_routes_agree(fusion, nl, B, NL):
     gen = torch.Generator().manual_seed(51)
     in_mult = 2 if fusion == "concatenation" else 3
     sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, nl, in_mult=in_mult)
-    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
-    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
-    y = (torch.rand(B, NL, generator=gen) < 0.1).float().to(DEV)
+    P_c = torch.randn(B, 1100, generator=gen)
+    lab_c = torch.randn(NL, 1024, generator=gen)
+    y_c = (torch.rand(B, NL, generator=gen) < 0.1).float()
+    lg64, _, g64 = _oracle_grads(sd, P_c, lab_c, y_c, torch.float64, fusion=fusion)
+    ev64 = _oracle_eval(sd, P_c, lab_c, torch.float64, fusion=fusion)
+    torch.cuda.empty_cache()
+    P_f, lab, y = P_c.to(DEV), lab_c.to(DEV), y_c.to(DEV)
     model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=nl, projection_head_num_layers=4,
                      projection_head_hidden_dim_scale_factor=3, feature_fusion=fusion)
     model.load_state_dict(sd)
     model = model.to(DEV)
     model.pair_label_chunk = 300  # several chunks in the eval head
 
-    def run(staged, fwd="bf16"):
+    def run(staged):
         L.check(L.lib().pn_set_fwd_staged(staged))
         try:
-            model.forward_math = fwd
+            model.forward_math = "bf16"
             model.load_state_dict(sd)
             model.eval()
             with torch.no_grad():
@@ -393,21 +401,27 @@ def test_forward_bf16_routes_agree(fusion, nl, B, NL):
             lg, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
             BCEWithLogitsLoss()(lg, y).backward()
             bufs = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
-            return ev.clone(), lg.detach().clone(), bufs, {n: p.grad.clone() for n, p in model.named_parameters()}
+            return ev.double().cpu(), lg.detach().double().cpu(), bufs, {n: p.grad.double().cpu() for n, p in model.named_parameters()}
         finally:
             L.lib().pn_set_fwd_staged(1)
 
-    a, a2, b, c = run(1), run(1), run(0), run(1, "same")
-    for x, y_ in zip(a[:2], a2[:2]):
-        assert torch.equal(x, y_)                                     # the staged route is bit-reproducible
-    assert all(torch.equal(a[3][n], a2[3][n]) for n in a[3])
-    scale = max(1.0, float(a[0].abs().max()))
-    d_ev, d_tr = float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max())
-    assert 0.0 < d_ev < 2e-4 * scale and d_tr < 2e-4 * scale, (d_ev, d_tr, scale)   # f32 summation order, not bf16 class
-    assert float((a[0] - c[0]).abs().max()) > 20 * d_ev              # ... which is what separates both from the f32 forward
+    a, a2, b = run(1), run(1), run(0)
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and all(torch.equal(a[3][n], a2[3][n]) for n in a[3])   # (i)
+    out = []
+    for what, x, y_, ref in (("eval", a[0], b[0], ev64), ("train", a[1], b[1], lg64)):
+        e_st, e_rg, d = float((x - ref).abs().max()), float((y_ - ref).abs().max()), float((x - y_).abs().max())
+        r_st, r_rg = float((x - ref).pow(2).mean().sqrt()), float((y_ - ref).pow(2).mean().sqrt())
+        out.append(f"{what}: staged {e_st:.2e} (rms {r_st:.2e}) register-staged {e_rg:.2e} (rms {r_rg:.2e}) between the routes {d:.2e}")
+        assert d > 0.0                                                                  # the other kernels really ran
+        assert r_st <= 1.25 * r_rg and r_rg <= 1.25 * r_st, (what, r_st, r_rg)           # (ii)
+        assert float((x - y_).pow(2).mean().sqrt()) < 0.5 * max(r_st, r_rg), (what, d)   # (iii)
     for k in a[2]:
-        np.testing.assert_allclose(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
-    worst = max(_rel(a[3][n].double(), b[3][n].double()) for n in a[3])
-    assert worst < 2e-3, worst   # ReLU-mask flips of pre-activations that differ in the last bits; the bf16 class is ~1e-2
-    print(f"[{fusion}, {nl} layers, {B} x {NL}] staged vs register-staged bf16 forward: eval {d_ev:.2e}, train {d_tr:.2e}, "
-          f"worst gradient {worst:.2e}")
+        np.testing.assert_allclose(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+    worst = ("", 0.0, 0.0)
+    for n in a[3]:
+        e_st, e_rg = _rel(a[3][n], g64[n]), _rel(b[3][n], g64[n])
+        if e_st > worst[1]:
+            worst = (n, e_st, e_rg)
+        assert e_st <= 1.5 * e_rg + 1e-4 and e_rg <= 1.5 * e_st + 1e-4, (n, e_st, e_rg)   # (iv)
+    print(f"[{fusion}, {nl} layers, {B} x {NL}] bf16 forward, logits vs f64 - " + "; ".join(out) +
+          f"; worst gradient {worst[0]}: staged {worst[1]:.2e} register-staged {worst[2]:.2e}")
