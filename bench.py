@@ -741,12 +741,15 @@ def main():
     elapsed, prof, loss_val, comm = timed_train(args.steps, args.warmup)
     fast = None
     if args.math == "f32" and not args.no_fast_mode:  # same workload once more on the opt-in bf16x3 arithmetic
+        # (sub-benchmarks run a bounded number of steps: the default driver invocation is 20 + 5 of the 6.6 s headline step, and
+        #  the whole run has to stay inside a few minutes)
+        n_fast, w_fast = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
         _lib.set_math_mode("bf16x3")
-        f_elapsed, f_prof, f_loss, _ = timed_train(args.steps, args.warmup)
+        f_elapsed, f_prof, f_loss, _ = timed_train(n_fast, w_fast)
         _lib.set_math_mode("f32")
         fast = {"math": "bf16x3 (f32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, f32 accumulate)",
-                "value": world * B * NL * args.steps / f_elapsed, "unit": "pairs/s",
-                "ms_per_step": f_elapsed / args.steps * 1e3, "final_loss": f_loss,
+                "value": world * B * NL * n_fast / f_elapsed, "unit": "pairs/s", "steps": n_fast,
+                "ms_per_step": f_elapsed / n_fast * 1e3, "final_loss": f_loss,
                 "roofline": roofline_block(f_prof, "bf16x3", "pair-grid 3072x3072 bf16x3 GEMM family"),
                 "kernels": kernel_table(f_prof)}
 
@@ -755,7 +758,7 @@ def main():
     # (pn_set_backward_math(1); the reference trains under fp16 autocast, ProtNoteTrainer.py:728-738)
     amp = None
     if args.math == "f32" and not args.no_fast_mode:
-        n_amp, w_amp = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        n_amp, w_amp = max(1, min(args.steps, 6)), 1
         amp = {}
         for fwd_mode in ("bf16x3", "f32"):
             _lib.set_math_mode(fwd_mode)
@@ -789,7 +792,7 @@ def main():
     # oracle, not to the 1e-3 bound (tests/test_hip_fwd_bf16.py)
     amp_full = None
     if args.math == "f32" and not args.no_fast_mode:
-        n_run, w_amp = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        n_run, w_amp = max(1, min(args.steps, 8)), 1
         _lib.set_math_mode("bf16x3")
         _lib.set_backward_math("bf16")
         _lib.set_forward_math("bf16")
@@ -957,7 +960,7 @@ def main():
     if rank == 0:
         pairs = world * B * NL * args.steps
         traffic, traffic_src, traffic_stale = None, None, None
-        for cand in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        for cand in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if args.math == "f32" and os.path.exists(tpath):
                 try:
