@@ -165,7 +165,9 @@ typedef struct pn_pairhead {
   int backward_math;
   /* pn_pairhead_fwd_*: arithmetic of the hidden layers' FORWARD pair-grid GEMMs (z_l = h_{l-1} W_l^T, l >= 1): 0 = the library
    * default (pn_set_forward_math), 1 = as math_mode, 2 = one bf16 product with f32 accumulation (AMP class, see
-   * pn_set_forward_math).  pn_pairhead_bwd ignores it (the backward regenerates h from the stored f32 z). */
+   * pn_set_forward_math).  pn_pairhead_bwd ignores it (the backward regenerates h from the stored f32 z).  The workspace
+   * queries (pn_pairhead_eval_ws_bytes / _train_ws_bytes) read it too - mode 2 carves one chunk of bf16 operand - so query and
+   * call must see the same value (with 0: the same process default). */
   int forward_math;
 } pn_pairhead;
 
