@@ -1670,7 +1670,7 @@ static bool pair_carve(const pn_pairhead* hd, int B, int NL, int chunk, Bump& bp
   w.wsplit = (uint16_t*)bp.take<float>((size_t)h * h);
   // (carved LAST and by the descriptor alone: the fields above sit where they always sat)
   w.hbuf[0] = w.hbuf[1] = nullptr;
-  if (fwd_bf16_requested(hd) && fwd_staged_shape(h)) {
+  if (fwd_bf16_requested(hd) && fwd_staged_shape(h) && hd->nlayers > 1) {
     w.hbuf[0] = (uint16_t*)bp.take<float>((size_t)crow * h / 2);
     if (hd->nlayers > 2) w.hbuf[1] = (uint16_t*)bp.take<float>((size_t)crow * h / 2);
   }
@@ -1768,7 +1768,7 @@ extern "C" int pn_pairhead_fwd_eval(const pn_pairhead* hd, const float* P_e, con
       in = w.z[zsel];
       zsel ^= 1;
     }
-    if (fwd_staged_on(fwd_bf16, h) && w.hbuf[0] != nullptr) {
+    if (fwd_staged_on(fwd_bf16, h) && w.hbuf[0] != nullptr && hd->nlayers > 1) {  // (one hidden layer: no hidden pair-grid GEMM)
       // AMP-class forward, materialised operand (fwd_bf16_h.hpp): h_{li-1} of this chunk as bf16 -> all-DMA GEMM; a hidden
       // layer's epilogue writes the next operand directly (E_STORE_H16: relu(bn(z)) rounded once), the last one the row-dot
       int hsel = 0;

@@ -425,3 +425,99 @@ def test_forward_bf16_routes_agree(fusion, nl, B, NL):
         assert e_st <= 1.5 * e_rg + 1e-4 and e_rg <= 1.5 * e_st + 1e-4, (n, e_st, e_rg)   # (iv)
     print(f"[{fusion}, {nl} layers, {B} x {NL}] bf16 forward, logits vs f64 - " + "; ".join(out) +
           f"; worst gradient {worst[0]}: staged {worst[1]:.2e} register-staged {worst[2]:.2e}")
+
+
+@pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "concatenation_prod"])
+def test_forward_bf16_one_hidden_layer_is_unchanged(fusion):
+    """OUTPUT_MLP_NUM_LAYERS: 1 has no hidden pair-grid GEMM (the separable layer is the only hidden layer; concatenation_prod's
+    extra layer-1 GEMM follows math_mode by definition), so forward_math = "bf16" changes nothing: eval logits, train logits and
+    every gradient bit-identical to forward_math = "same" - at a width the staged route would otherwise take."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(77)
+    in_mult = 2 if fusion == "concatenation" else 3
+    sd = random_head_sd(gen, 1100, 1024, 256, 768, 2, 768, 1, in_mult=in_mult)
+    B, NL = 24, 130
+    P_f = torch.randn(B, 1100, generator=gen).to(DEV)
+    lab = torch.randn(NL, 1024, generator=gen).to(DEV)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float().to(DEV)
+    model = ProtNote(latent_dim=256, output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=1, projection_head_num_layers=2,
+                     projection_head_hidden_dim_scale_factor=3, feature_fusion=fusion)
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.pair_label_chunk = 50
+    out = {}
+    for fwd in ("same", "bf16"):
+        model.forward_math = fwd
+        model.load_state_dict(sd)
+        model.eval()
+        with torch.no_grad():
+            ev, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        lg, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+        BCEWithLogitsLoss()(lg, y).backward()
+        out[fwd] = (ev.clone(), lg.detach().clone(), [p.grad.clone() for p in model.parameters()])
+    assert torch.isfinite(out["bf16"][0]).all() and float(out["bf16"][0].abs().max()) > 0.1
+    assert torch.equal(out["same"][0], out["bf16"][0]) and torch.equal(out["same"][1], out["bf16"][1])
+    assert all(torch.equal(a, b) for a, b in zip(out["same"][2], out["bf16"][2]))
+
+
+def test_forward_bf16_without_batchnorm_and_in_a_differentiated_eval_forward():
+    """Two corners of the mode: (i) OUTPUT_MLP_BATCHNORM: False (Linear bias + ReLU; the bias rides in the fold's shift) - train
+    step with forward + backward bf16 against the f64 oracle at the bf16 class; (ii) model.eval() with autograd on (the
+    activation-storing path with BatchNorm on its running statistics) gives the logits of the fused inference kernels under
+    no_grad - the stored f32 pre-activation goes through the same fold and the same rounding as the fused producer's epilogue."""
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(91)
+    torch.manual_seed(91)
+    model = ProtNote(protein_embedding_dim=64, label_embedding_dim=48, latent_dim=128, output_mlp_hidden_dim_scale_factor=2,
+                     output_mlp_num_layers=3, outout_mlp_add_batchnorm=False, projection_head_num_layers=2,
+                     projection_head_hidden_dim_scale_factor=2)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (1.6 / m.weight.shape[1] ** 0.5))
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
+            elif isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.3)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B, NL = 12, 50
+    P_f = torch.randn(B, 64, generator=gen)
+    lab = torch.randn(NL, 48, generator=gen)
+    y = (torch.rand(B, NL, generator=gen) < 0.2).float()
+    lg64, ls64, g64 = _oracle_grads(sd, P_f, lab, y, torch.float64)
+    model = model.to(DEV).train()
+    model.forward_math, model.backward_math = "bf16", "bf16"
+    lg, _ = model(sequence_embeddings=P_f.to(DEV), label_embeddings=lab.to(DEV))
+    loss = BCEWithLogitsLoss()(lg, y.to(DEV))
+    loss.backward()
+    scale = max(1.0, float(lg64.abs().max()))
+    err = float((lg.detach().double().cpu() - lg64).abs().max())
+    assert 1e-5 < err < 3e-2 * scale, (err, scale)
+    np.testing.assert_allclose(loss.item(), ls64, rtol=5e-3)
+    for n, p in model.named_parameters():
+        assert _rel(p.grad.double().cpu(), g64[n]) < 8e-2, n
+
+    # (ii) full width, BatchNorm on: eval + autograd == eval under no_grad
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, 3)
+    m2 = _full_width_model(sd).eval()
+    m2.forward_math = "bf16"
+    P2, l2 = torch.randn(40, 1100, generator=gen).to(DEV), torch.randn(90, 1024, generator=gen).to(DEV)
+    with torch.no_grad():
+        fused, _ = m2(sequence_embeddings=P2, label_embeddings=l2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        stored, _ = m2(sequence_embeddings=P2, label_embeddings=l2)
+    assert stored.requires_grad
+    d = float((stored.detach() - fused).abs().max())
+    assert d < 1e-4 * max(1.0, float(fused.abs().max())), d
+    stored.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m2.output_layer.parameters())
