@@ -16,7 +16,10 @@ import bench
 from protnote_amd import _lib
 from protnote_amd.utils.losses import BCEWithLogitsLoss
 
-PEAK = bench.F32_MFMA_PEAK_TFLOPS
+# PN_SWEEP_MODE=amp: the same sweep (a subset of the shapes) in the full AMP class - bf16x3 base arithmetic, forward_math and
+# backward_math = bf16 - priced against the dense bf16 peak
+AMP = os.environ.get("PN_SWEEP_MODE", "") == "amp"
+PEAK = bench.BF16_MFMA_PEAK_TFLOPS if AMP else bench.F32_MFMA_PEAK_TFLOPS
 
 
 def table(prof, steps):
@@ -38,13 +41,18 @@ def main():
     dev = torch.device("cuda:0")
     model = bench.build_model(dev, seed=1)
     model.label_embedding_noising_alpha = 0.0
+    if AMP:
+        model.math_mode, model.forward_math, model.backward_math = "bf16x3", "bf16", "bf16"
     gen = torch.Generator().manual_seed(3)
     P_all = torch.randn(300, 1100, generator=gen).to(dev)
     lab_all = torch.randn(64204, 1024, generator=gen).to(dev)
     shapes = [(B, NL, "") for B in (8, 32, 100, 256) for NL in (5134, 10268, 32102, 64204)]
     shapes += [(20, 32102, "B % 32 != 0 (ragged last batch of an epoch)"), (250, 32102, "B % 32 != 0"),
                (32, 1789, "ragged N_L (in-batch label sampling)"), (8, 333, "tiny grid"), (300, 5134, "B > 256")]
-    out = {"peak_tflops": PEAK, "note": "whole GEMM engine (pair grid + row MLPs; the encoder is not run: sequence_embeddings "
+    if AMP:
+        shapes = [(B, NL, "") for B in (8, 32, 256) for NL in (5134, 32102)] + [(8, 64204, "GO x 2 descriptions at the reference's batch"),
+                                                                                   (20, 32102, "B % 32 != 0"), (8, 333, "tiny grid")]
+    out = {"peak_tflops": PEAK, "mode": "amp (bf16x3 base, forward_math = backward_math = bf16)" if AMP else "f32", "note": "whole GEMM engine (pair grid + row MLPs; the encoder is not run: sequence_embeddings "
                                         "are given), hipEvent-timed per launch", "configs": []}
     for B, NL, note in shapes:
         P_f, lab = P_all[:B].contiguous(), lab_all[:NL].contiguous()
