@@ -94,36 +94,46 @@ def test_headline_survives_broken_optional_blocks():
 
 
 def test_cpu_baseline_legs_and_budget(monkeypatch):
-    """cpu_baseline starts its legs together (32 / 64 / half the host's threads, deduplicated on small hosts) under ONE budget;
-    a leg reports its largest finished sample; the best finished leg is the value.  The oracle step is stubbed: the real one
-    takes ~20 s per leg."""
+    """cpu_baseline: legs at half / all / twice the CPUs the process can really use (affinity AND cgroup quota - the GPU boxes
+    show 256 hardware threads under a 16-CPU quota), B = 2 at each thread count in ONE child under ONE budget, then B = 4 at the
+    fastest; no leg is null when the child finishes; a child cut off by the budget still reports what it finished.  The oracle
+    step is stubbed: the real one takes ~10-20 s per sample."""
     import bench
 
-    assert bench.cpu_leg_threads(256) == [32, 64, 128] and bench.cpu_leg_threads(8) == [4, 8]
+    assert bench.cpu_leg_threads(16) == [8, 16, 32] and bench.cpu_leg_threads(1) == [1, 2]
+    eff, quota = bench.effective_cpus()
+    assert 1 <= eff <= (bench.os.cpu_count() or 1)
 
     class FakeProc:
+        cut = False
+
         def __init__(self, cmd, **kw):
-            self.t = int(cmd[-1].rsplit("(", 1)[1].rstrip(")"))
+            self.threads = eval(cmd[-1].rsplit("_cpu_legs_main(", 1)[1].rstrip(")"))
+
+        def lines(self, upto):
+            secs = {8: 14.0, 16: 9.0, 32: 11.0}
+            out = [json.dumps({"threads": t, "B": 2, "pairs": 64204, "seconds": secs[t]}) for t in self.threads]
+            out.append(json.dumps({"threads": 16, "B": 4, "pairs": 128408, "seconds": 17.0}))
+            return "\n".join(out[:upto]) + "\n"
 
         def communicate(self, timeout=None):
             import subprocess
 
-            if self.t == 128:  # never finishes B = 4: only the B = 2 line is on record
-                if timeout is not None and not getattr(self, "killed", False):
-                    self.partial = json.dumps({"B": 2, "pairs": 64204, "seconds": 9.0}) + "\n"
-                    raise subprocess.TimeoutExpired("x", timeout)
-                return self.partial, None
-            secs = {32: 21.0, 64: 16.0}[self.t]
-            return (json.dumps({"B": 2, "pairs": 64204, "seconds": secs / 1.8}) + "\n" +
-                    json.dumps({"B": 4, "pairs": 128408, "seconds": secs}) + "\n"), None
+            if FakeProc.cut and not getattr(self, "killed", False):
+                raise subprocess.TimeoutExpired("x", timeout)
+            return self.lines(2 if FakeProc.cut else 4), None
 
         def kill(self):
             self.killed = True
 
+    monkeypatch.setattr(bench, "effective_cpus", lambda: (16, 16.0))
     monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
     monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
     out = bench.cpu_baseline(budget=1.0)
-    assert set(out["legs"]) == {"32", "64", "128"} and all(v["value"] for v in out["legs"].values())
-    assert out["cores"] == 64 and out["value"] == pytest.approx(128408 / 16.0) and out["kind"] == "port"
-    assert out["legs"]["128"]["B"] == 2 and "not finished" in out["legs"]["128"]["note"]
-    assert "B=4" in out["sample"] and "64 threads" in out["sample"]
+    assert set(out["legs"]) == {"8", "16", "32", "16 (B=4)"} and all(v["value"] for v in out["legs"].values())
+    assert out["cores"] == 16 and out["value"] == pytest.approx(128408 / 17.0) and out["kind"] == "port"
+    assert out["usable_cpus"] == 16 and out["host_cores"] == 256 and "B=4" in out["sample"] and "16 threads" in out["sample"]
+    FakeProc.cut = True   # the budget ends during the third leg: the two finished legs stand, the best of them is the value
+    out = bench.cpu_baseline(budget=1.0)
+    assert out["legs"]["32"]["value"] is None and "budget" in out["legs"]["32"]["note"]
+    assert out["cores"] == 16 and out["value"] == pytest.approx(64204 / 9.0) and "B=2" in out["sample"]
