@@ -195,39 +195,53 @@ def effective_cpus():
 
 
 def cpu_leg_threads(eff):
-    """Thread counts of the cpu_baseline legs: half, all and twice the CPUs the process can really use (PN_CPU_THREADS: one
-    explicit count)."""
+    """Thread counts of the cpu_baseline legs: all and twice the CPUs the process can really use, then - budget permitting - four
+    times (PN_CPU_THREADS: one explicit count)."""
     if os.environ.get("PN_CPU_THREADS"):
         return [max(1, int(os.environ["PN_CPU_THREADS"]))]
-    return sorted({max(1, eff // 2), max(1, eff), max(1, 2 * eff)})
+    return sorted({max(1, eff), max(1, 2 * eff), max(1, 4 * eff)})
 
 
-def _cpu_legs_main(threads_list):
-    """Child process of cpu_baseline: the B = 2 half-sample at every thread count (one after the other: the CPU quota is one
-    pool), then the B = 4 sample at the fastest count; one JSON line per finished sample."""
-    best = None
-    for t in threads_list:
+def _cpu_legs_main(threads_list, budget):
+    """Child process of cpu_baseline: the B = 2 half-sample at the first two thread counts (one after the other: the CPU quota
+    is one pool), the B = 4 sample at the faster of them, then the remaining thread counts at B = 2 while the budget lasts;
+    one JSON line per finished sample."""
+    t_start = time.time()
+    best, slowest = None, 0.0
+
+    def leg(t):
+        nonlocal best, slowest
         pairs, dt = _cpu_sample(t, 2)
         print(json.dumps({"threads": t, "B": 2, "pairs": pairs, "seconds": dt}), flush=True)
+        slowest = max(slowest, dt)
         if best is None or pairs / dt > best[1]:
             best = (t, pairs / dt)
+
+    for t in threads_list[:2]:
+        leg(t)
     pairs, dt = _cpu_sample(best[0], CPU_SAMPLE[0])
     print(json.dumps({"threads": best[0], "B": CPU_SAMPLE[0], "pairs": pairs, "seconds": dt}), flush=True)
+    for t in threads_list[2:]:
+        if budget - (time.time() - t_start) < 1.3 * slowest:
+            print(json.dumps({"threads": t, "skipped": "budget"}), flush=True)
+            continue
+        leg(t)
 
 
 def cpu_baseline(budget=CPU_BUDGET_S):
     """Oracle train step (reference algorithm restated, f32, torch-CPU; pinned to reference golden vectors) on a bounded
     sample of the same workload at the QUOTED label set: L = 512, N_L = 32102, full-width model (the whole W_l recompute over
-    the real label table is in it).  One child process, one wall-clock budget: legs at half / all / twice the CPUs the process
-    can really use (affinity and cgroup quota, effective_cpus) run the B = 2 half-sample one after the other, then the fastest
-    thread count runs the B = 4 sample (128 k pairs).  `value` = that B = 4 figure (the best B = 2 leg if B = 4 did not finish:
-    fewer pairs over the same W_l cost, i.e. lower, never flattering); `cores` = its threads."""
+    the real label table is in it).  One child process, one wall-clock budget: legs at one and two times the CPUs the process
+    can really use (affinity and cgroup quota, effective_cpus) run the B = 2 half-sample one after the other, the faster thread
+    count then runs the B = 4 sample (128 k pairs), and a four-times leg follows if the budget still holds it.  `value` = the
+    B = 4 figure (the best B = 2 leg if B = 4 did not finish: fewer pairs over the same W_l cost, i.e. lower, never
+    flattering); `cores` = its threads."""
     total = os.cpu_count() or 1
     eff, quota = effective_cpus()
     B4, L, NL = CPU_SAMPLE
     threads = cpu_leg_threads(eff)
     env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
-    code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_legs_main(%r)" % (ROOT, threads)
+    code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_legs_main(%r, %r)" % (ROOT, threads, float(budget) - 6.0)
     t0 = time.time()
     out, note = "", None
     try:
@@ -249,14 +263,18 @@ def cpu_baseline(budget=CPU_BUDGET_S):
             done.append(json.loads(ln))
         except ValueError:
             pass
-    legs = {}
+    legs, skipped = {}, []
     for t in threads:
-        r = [d for d in done if d["threads"] == t and d["B"] == 2]
-        legs[str(t)] = ({"threads": t, "B": 2, "value": r[0]["pairs"] / r[0]["seconds"], "seconds": r[0]["seconds"]} if r else
-                        {"threads": t, "B": 2, "value": None, "seconds": None, "note": note or "not reached"})
-    full = [d for d in done if d["B"] == B4]
+        r = [d for d in done if d["threads"] == t and d.get("B") == 2]
+        if r:
+            legs[str(t)] = {"threads": t, "B": 2, "value": r[0]["pairs"] / r[0]["seconds"], "seconds": r[0]["seconds"]}
+        elif any(d["threads"] == t and d.get("skipped") for d in done) or (t in threads[2:] and note is None):
+            skipped.append(t)  # the optional leg: not started because the budget would not hold it
+        else:
+            legs[str(t)] = {"threads": t, "B": 2, "value": None, "seconds": None, "note": note or "not reached"}
+    full = [d for d in done if d.get("B") == B4]
     base = {"unit": "protein-label pairs/s", "kind": "port", "host_cores": total, "usable_cpus": eff,
-            "cpu_quota": quota, "legs": legs, "wall_seconds": time.time() - t0}
+            "cpu_quota": quota, "legs": legs, "legs_not_started": skipped, "wall_seconds": time.time() - t0}
     if full:
         f = full[-1]
         legs[f"{f['threads']} (B={B4})"] = {"threads": f["threads"], "B": B4, "value": f["pairs"] / f["seconds"], "seconds": f["seconds"]}
@@ -268,7 +286,7 @@ def cpu_baseline(budget=CPU_BUDGET_S):
         best = max(ok, key=lambda v: v["value"])
     return {"value": best["value"], "cores": best["threads"], **base,
             "sample": f"1 oracle train step (fwd+bwd+clip+Adam), B={best['B']}, L={L}, N_L={NL} (the quoted label set), full-width "
-                      f"model, {best['seconds']:.1f} s on {best['threads']} threads = the fastest of the {'/'.join(map(str, threads))}-thread "
+                      f"model, {best['seconds']:.1f} s on {best['threads']} threads = the faster of the {'/'.join(map(str, threads[:2]))}-thread "
                       f"legs; the host shows {total} hardware threads, the cgroup grants {eff} CPUs"}
 
 

@@ -94,34 +94,35 @@ def test_headline_survives_broken_optional_blocks():
 
 
 def test_cpu_baseline_legs_and_budget(monkeypatch):
-    """cpu_baseline: legs at half / all / twice the CPUs the process can really use (affinity AND cgroup quota - the GPU boxes
-    show 256 hardware threads under a 16-CPU quota), B = 2 at each thread count in ONE child under ONE budget, then B = 4 at the
-    fastest; no leg is null when the child finishes; a child cut off by the budget still reports what it finished.  The oracle
-    step is stubbed: the real one takes ~10-20 s per sample."""
+    """cpu_baseline: legs at one / two (/ four, budget permitting) times the CPUs the process can really use (affinity AND cgroup
+    quota - the GPU boxes show 256 hardware threads under a 16-CPU quota), B = 2 at the first two thread counts, then B = 4 at
+    the faster, in ONE child under ONE budget; no leg that ran is null; a child cut off by the budget still reports what it
+    finished.  The oracle step is stubbed: the real one takes ~10-20 s per sample."""
     import bench
 
-    assert bench.cpu_leg_threads(16) == [8, 16, 32] and bench.cpu_leg_threads(1) == [1, 2]
+    assert bench.cpu_leg_threads(16) == [16, 32, 64] and bench.cpu_leg_threads(1) == [1, 2, 4]
     eff, quota = bench.effective_cpus()
     assert 1 <= eff <= (bench.os.cpu_count() or 1)
 
     class FakeProc:
-        cut = False
+        mode = "all"
 
         def __init__(self, cmd, **kw):
-            self.threads = eval(cmd[-1].rsplit("_cpu_legs_main(", 1)[1].rstrip(")"))
+            pass
 
-        def lines(self, upto):
-            secs = {8: 14.0, 16: 9.0, 32: 11.0}
-            out = [json.dumps({"threads": t, "B": 2, "pairs": 64204, "seconds": secs[t]}) for t in self.threads]
-            out.append(json.dumps({"threads": 16, "B": 4, "pairs": 128408, "seconds": 17.0}))
-            return "\n".join(out[:upto]) + "\n"
+        def lines(self):
+            out = [{"threads": 16, "B": 2, "pairs": 64204, "seconds": 12.9}, {"threads": 32, "B": 2, "pairs": 64204, "seconds": 12.6},
+                   {"threads": 32, "B": 4, "pairs": 128408, "seconds": 21.0}, {"threads": 64, "skipped": "budget"}]
+            if FakeProc.mode == "cut":
+                out = out[:1]
+            return "\n".join(json.dumps(o) for o in out) + "\n"
 
         def communicate(self, timeout=None):
             import subprocess
 
-            if FakeProc.cut and not getattr(self, "killed", False):
+            if FakeProc.mode == "cut" and not getattr(self, "killed", False):
                 raise subprocess.TimeoutExpired("x", timeout)
-            return self.lines(2 if FakeProc.cut else 4), None
+            return self.lines(), None
 
         def kill(self):
             self.killed = True
@@ -129,11 +130,32 @@ def test_cpu_baseline_legs_and_budget(monkeypatch):
     monkeypatch.setattr(bench, "effective_cpus", lambda: (16, 16.0))
     monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
     monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
-    out = bench.cpu_baseline(budget=1.0)
-    assert set(out["legs"]) == {"8", "16", "32", "16 (B=4)"} and all(v["value"] for v in out["legs"].values())
-    assert out["cores"] == 16 and out["value"] == pytest.approx(128408 / 17.0) and out["kind"] == "port"
-    assert out["usable_cpus"] == 16 and out["host_cores"] == 256 and "B=4" in out["sample"] and "16 threads" in out["sample"]
-    FakeProc.cut = True   # the budget ends during the third leg: the two finished legs stand, the best of them is the value
-    out = bench.cpu_baseline(budget=1.0)
+    out = bench.cpu_baseline(budget=10.0)
+    assert set(out["legs"]) == {"16", "32", "32 (B=4)"} and all(v["value"] for v in out["legs"].values())
+    assert out["legs_not_started"] == [64]
+    assert out["cores"] == 32 and out["value"] == pytest.approx(128408 / 21.0) and out["kind"] == "port"
+    assert out["usable_cpus"] == 16 and out["host_cores"] == 256 and "B=4" in out["sample"] and "32 threads" in out["sample"]
+    FakeProc.mode = "cut"   # the budget ends during the second leg: the finished leg stands and is the value
+    out = bench.cpu_baseline(budget=10.0)
     assert out["legs"]["32"]["value"] is None and "budget" in out["legs"]["32"]["note"]
-    assert out["cores"] == 16 and out["value"] == pytest.approx(64204 / 9.0) and "B=2" in out["sample"]
+    assert out["cores"] == 16 and out["value"] == pytest.approx(64204 / 12.9) and "B=2" in out["sample"]
+
+
+def test_cpu_legs_child_orders_its_samples(monkeypatch, capsys):
+    """The child: B = 2 at the first two thread counts, B = 4 at the faster, the optional count only if the budget holds it."""
+    import bench
+
+    calls = []
+
+    def fake(threads, B=None):
+        calls.append((threads, B))
+        return (B or 4) * 32102, {16: 0.02, 32: 0.01, 64: 0.01}[threads]
+
+    monkeypatch.setattr(bench, "_cpu_sample", fake)
+    bench._cpu_legs_main([16, 32, 64], 100.0)
+    assert calls == [(16, 2), (32, 2), (32, 4), (64, 2)]
+    calls.clear()
+    bench._cpu_legs_main([16, 32, 64], 0.0)
+    assert calls == [(16, 2), (32, 2), (32, 4)]
+    lines = [json.loads(ln) for ln in capsys.readouterr().out.strip().splitlines()]
+    assert lines[-1] == {"threads": 64, "skipped": "budget"}
