@@ -449,6 +449,11 @@ int pn_get_forward_math(void);
  * 0 = the single-product instantiation of the bf16x3 kernel rounds the operand while staging it through registers.  Same bf16
  * values in the same products, another k order inside a 16-k MFMA step: the routes agree to f32 summation order.  A/B switch. */
 int pn_set_fwd_staged(int on);
+/* MFMA shape of the all-LDS-DMA one-product bf16 NT GEMMs (the staged route above and dh = dz W with dz stored as bf16):
+ * 1 (default) = v_mfma_f32_16x16x32_bf16 (gemm_bf16_m16.hpp - the shape this package can feed: +12 % in the main loop),
+ * 0 = v_mfma_f32_32x32x16_bf16 (bwd_bf16_dz.hpp).  Every accumulator is bit-identical between the two; row dots and BatchNorm
+ * column partials reduce in another order (last-ulp differences).  A/B switch. */
+int pn_set_bf16_mfma16(int on);
 /* Kernels of mode 1, a bit mask (default 7).  Bit 0: dh = dz W on the deep-pipelined single-product kernel (gemm_bf16.hpp:
  * every operand fetched two slabs ahead) instead of the single-product instantiation of the bf16x3 kernel.  Bit 1: dW = dz^T h
  * on the transpose-read kernel (16-byte row loads, K-major LDS image, ds_read_b64_tr_b16) instead of the single-product

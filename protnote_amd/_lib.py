@@ -182,6 +182,7 @@ _SIGS = {
     "pn_set_forward_math": (C.c_int, [C.c_int]),
     "pn_get_forward_math": (C.c_int, []),
     "pn_set_fwd_staged": (C.c_int, [C.c_int]),
+    "pn_set_bf16_mfma16": (C.c_int, [C.c_int]),
     "pn_set_bwd_deep": (C.c_int, [C.c_int]),
     "pn_set_f32_dma": (C.c_int, [C.c_int]),
     "pn_set_encoder_f64": (C.c_int, [C.c_int]),

@@ -17,6 +17,7 @@
 #include "train_kernels.hpp"
 #include "bwd_bf16_dz.hpp"
 #include "fwd_bf16_h.hpp"
+#include "gemm_bf16_m16.hpp"
 
 using namespace pn;
 
@@ -529,16 +530,32 @@ static int launch_gemm_bf16_single(const GemmParams& p, hipStream_t st) {
   return 0;
 }
 
-// dh = dz W with dz stored as bf16 (bwd_bf16_dz.hpp): both operands by LDS-DMA
-static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
-  auto kern = gemm_nt_bf16dma_kernel<E_STORE>;
-  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
+// The all-DMA one-product bf16 NT GEMMs run on v_mfma_f32_16x16x32_bf16 (gemm_bf16_m16.hpp: the power-efficient shape on this
+// package); pn_set_bf16_mfma16(0) selects the 32 x 32 x 16 kernel of bwd_bf16_dz.hpp (same accumulators bit for bit; A/B, tests)
+static std::atomic<int> g_bf16_m16{1};
+extern "C" int pn_set_bf16_mfma16(int on) {
+  g_bf16_m16 = on ? 1 : 0;
+  return 0;
+}
+// both kernels of an epilogue get their dynamic-LDS attribute once per device; returns the one to launch
+template <int EK>
+static int bf16dma_kernel(void (**out)(GemmParams)) {
+  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the calls
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_nt_bf16dma_kernel<EK>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute((const void*)gemm_nt_bf16m16_kernel<EK>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
     attr_done[dev] = true;
   }
+  *out = g_bf16_m16.load() ? gemm_nt_bf16m16_kernel<EK> : gemm_nt_bf16dma_kernel<EK>;
+  return 0;
+}
+
+// dh = dz W with dz stored as bf16 (bwd_bf16_dz.hpp): both operands by LDS-DMA
+static int launch_gemm_bf16dma(const GemmParams& p, hipStream_t st) {
+  void (*kern)(GemmParams) = nullptr;
+  if (int rc = bf16dma_kernel<E_STORE>(&kern)) return rc;
   if (p.M <= 0 || p.Nstore <= 0) return 0;
   if (p.wsplit == nullptr || p.Kseg % 64 != 0 || p.N % 256 != 0 || p.Nstore != p.N || (long)256 * p.lda * 4 >= (1L << 32) ||
       (long)256 * p.Kseg * 2 >= (1L << 32))
@@ -600,17 +617,11 @@ static int make_h(int kind, long r0, long rows, int C, const float* A, long lda,
 }
 
 // C = H W^T, H = bf16 [M][K] dense (make_h / an E_STORE_H16 producer), W = the pre-rounded plane p.w_hi (k_round_plane):
-// gemm_nt_bf16dma_kernel with epilogue EK.  src_kind (0 plain, 1 bn_relu, 2 pairsum) only labels the profile kind.
+// gemm_nt_bf16m16_kernel (pn_set_bf16_mfma16(0): gemm_nt_bf16dma_kernel) with epilogue EK.  src_kind (0 plain, 1 bn_relu, 2 pairsum) only labels the profile kind.
 template <int EK>
 static int launch_gemm_h16(const GemmParams& p, int src_kind, hipStream_t st) {
-  auto kern = gemm_nt_bf16dma_kernel<EK>;
-  static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
-  if (dev < 64 && !attr_done[dev]) {
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NT_BF16DMA_LDS_BYTES));
-    attr_done[dev] = true;
-  }
+  void (*kern)(GemmParams) = nullptr;
+  if (int rc = bf16dma_kernel<EK>(&kern)) return rc;
   if (p.M <= 0 || p.Nstore <= 0) return 0;
   if (p.w_hi == nullptr || p.Kseg % 64 != 0 || p.N % 256 != 0 || p.Nstore != p.N || (long)256 * p.lda * 4 >= (1L << 32) ||
       (long)256 * p.Kseg * 2 >= (1L << 32))

@@ -427,6 +427,75 @@ def test_forward_bf16_routes_agree(fusion, nl, B, NL):
           f"; worst gradient {worst[0]}: staged {worst[1]:.2e} register-staged {worst[2]:.2e}")
 
 
+def test_mfma16_matches_mfma32():
+    """pn_set_bf16_mfma16: the all-LDS-DMA one-product bf16 NT GEMMs run on v_mfma_f32_16x16x32_bf16 (gemm_bf16_m16.hpp, default) or on
+    v_mfma_f32_32x32x16_bf16 (bwd_bf16_dz.hpp).  Every accumulator is bit-identical between the two (tools/lab_bf16_nt.hip compares z
+    and the bf16 h on the device at 262 144 x 3072 x 3072); what differs is the reduction order of the fused epilogues.  Held here:
+    (i) backward_math = bf16 over an f32 forward - dh = dz W is a plain store, so EVERY gradient is bit-identical;
+    (ii) forward_math = bf16, eval - h is bit-identical, the logits are row dots summed in another order: f32 rounding only;
+    (iii) forward_math = bf16, train - the BatchNorm column partials sum in another order, batch statistics move in the last ulp, a few
+    elements of the next bf16 operand round the other way: same arithmetic class (same distance from the float64 oracle, rms of the
+    difference far below it)."""
+    from protnote_amd import _lib as L
+    from protnote_amd.models.ProtNote import ProtNote
+    from protnote_amd.utils.losses import BCEWithLogitsLoss
+
+    gen = torch.Generator().manual_seed(77)
+    B, NL, nl = 72, 520, 3
+    sd = random_head_sd(gen, 1100, 1024, 1024, 3072, 4, 3072, nl)
+    P_c = torch.randn(B, 1100, generator=gen)
+    lab_c = torch.randn(NL, 1024, generator=gen)
+    y_c = (torch.rand(B, NL, generator=gen) < 0.1).float()
+    lg64, _, _ = _oracle_grads(sd, P_c, lab_c, y_c, torch.float64)
+    torch.cuda.empty_cache()
+    P_f, lab, y = P_c.to(DEV), lab_c.to(DEV), y_c.to(DEV)
+    model = ProtNote(output_mlp_hidden_dim_scale_factor=3, output_mlp_num_layers=nl, projection_head_num_layers=4,
+                     projection_head_hidden_dim_scale_factor=3, feature_fusion="concatenation")
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.pair_label_chunk = 200
+
+    def run(m16, fwd, bwd):
+        L.check(L.lib().pn_set_bf16_mfma16(m16))
+        try:
+            model.forward_math, model.backward_math = fwd, bwd
+            model.load_state_dict(sd)
+            model.eval()
+            with torch.no_grad():
+                ev, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            model.train()
+            for p in model.parameters():
+                p.grad = None
+            lg, _ = model(sequence_embeddings=P_f, label_embeddings=lab)
+            BCEWithLogitsLoss()(lg, y).backward()
+            return ev.clone(), lg.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}
+        finally:
+            L.lib().pn_set_bf16_mfma16(1)
+            model.forward_math, model.backward_math = "same", "same"
+
+    # (i)
+    a, b = run(1, "same", "bf16"), run(0, "same", "bf16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    # (ii), (iii)
+    a, b = run(1, "bf16", "bf16"), run(0, "bf16", "bf16")
+    scale = float(a[0].abs().max())
+    d_ev = float((a[0] - b[0]).abs().max())
+    assert d_ev <= 4e-6 * scale, (d_ev, scale)
+    ref = lg64.to(DEV)
+    r16 = float((a[1].double() - ref).pow(2).mean().sqrt())
+    r32 = float((b[1].double() - ref).pow(2).mean().sqrt())
+    d_tr = float((a[1] - b[1]).double().pow(2).mean().sqrt())
+    assert r16 <= 1.05 * r32 and r32 <= 1.05 * r16, (r16, r32)
+    assert d_tr <= 0.1 * max(r16, r32), (d_tr, r16, r32)
+    for n in a[2]:
+        g16, g32 = a[2][n].double(), b[2][n].double()
+        assert float((g16 - g32).norm()) <= 2e-2 * float(g32.norm()) + 1e-12, n
+    print(f"16x16x32 vs 32x32x16: gradients of an f32 forward bit-identical; bf16 forward - eval logits differ by {d_ev:.1e} at scale "
+          f"{scale:.1f}; train logits rms vs f64 {r16:.2e} / {r32:.2e}, rms between the two {d_tr:.1e}")
+
+
 @pytest.mark.parametrize("fusion", ["concatenation", "concatenation_diff", "concatenation_prod"])
 def test_forward_bf16_one_hidden_layer_is_unchanged(fusion):
     """OUTPUT_MLP_NUM_LAYERS: 1 has no hidden pair-grid GEMM (the separable layer is the only hidden layer; concatenation_prod's

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o /tmp/mfma_probe
 //   python tools/power_trace.py --out gpurun_out/r03_power_probe_bf16.json -- /tmp/mfma_probe bf16 8
 //   python tools/power_trace.py --out gpurun_out/r03_power_probe_f32.json  -- /tmp/mfma_probe f32 8
+//   /tmp/mfma_probe bf16_16 8     (round 6: the same loop on v_mfma_f32_16x16x32_bf16)
 //
 // This is an UPPER bound for any real kernel (operands never change, so the datapath toggles less than with streamed data,
 // and nothing else on the chip draws power): DESIGN.md 4.6 uses it to place the bf16x3 GEMMs (3 bf16 MFMAs per product)
@@ -81,8 +82,50 @@ __global__ __launch_bounds__(512, 2) void k_probe(const uint32_t* __restrict__ s
   if (s == 123.456f) out[blockIdx.x * 64 + lane] = s;  // never true: keeps the accumulators alive
 }
 
+// the same register-only loop on v_mfma_f32_16x16x32_bf16: 4 x 8 accumulator tiles of 16 x 16 (the same 64 x 128 wave tile and the
+// same 128 accumulator registers), 32 independent chains; one pass = 32 MFMAs over k = 32 = the flops of 16 MFMAs of 32 x 32 x 16
+__global__ __launch_bounds__(512, 2) void k_probe16(const uint32_t* __restrict__ seed, float* __restrict__ out, int iters) {
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  uint32_t r[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) r[k] = seed[(threadIdx.x * 48 + k) & 4095];
+  f32x4_ acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    bf16x8 a[4], b[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, (u32x4){r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]});
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = __builtin_bit_cast(bf16x8, (u32x4){r[16 + 4 * j], r[17 + 4 * j], r[18 + 4 * j], r[19 + 4 * j]});
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 48; ++k) asm volatile("" : "+v"(r[k]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+  if (s == 123.456f) out[blockIdx.x * 64 + lane] = s;
+}
+
 int main(int argc, char** argv) {
   const bool bf16 = argc < 2 || strcmp(argv[1], "f32") != 0;
+  const bool m16 = argc > 1 && strcmp(argv[1], "bf16_16") == 0;  // v_mfma_f32_16x16x32_bf16 (64 MFMAs of 16 Kflop per pass = the same flops)
   const double seconds = argc > 2 ? atof(argv[2]) : 8.0;
   // operands: bf16 / f32 values with exponents around 1.0 and random mantissas (finite, no denormals)
   std::vector<uint32_t> h(4096);
@@ -107,7 +150,8 @@ int main(int argc, char** argv) {
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (bf16) hipLaunchKernelGGL(k_probe<true>, dim3(grid), dim3(512), 0, 0, d_seed, d_out, iters);
+    if (m16) hipLaunchKernelGGL(k_probe16, dim3(grid), dim3(512), 0, 0, d_seed, d_out, iters);
+    else if (bf16) hipLaunchKernelGGL(k_probe<true>, dim3(grid), dim3(512), 0, 0, d_seed, d_out, iters);
     else hipLaunchKernelGGL(k_probe<false>, dim3(grid), dim3(512), 0, 0, d_seed, d_out, iters);
   };
   launch();
@@ -129,6 +173,6 @@ int main(int argc, char** argv) {
   const double mean = flop_per_launch * n / (total_ms * 1e-3) / 1e12;
   printf("{\"probe\": \"%s\", \"cus\": %d, \"launches\": %d, \"seconds\": %.2f, \"tflops_mean\": %.1f, \"tflops_first_best\": %.1f, "
          "\"tflops_last\": %.1f}\n",
-         bf16 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_32x32x2_f32", cus, n, total_ms * 1e-3, mean, best, last);
+         m16 ? "v_mfma_f32_16x16x32_bf16" : (bf16 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_32x32x2_f32"), cus, n, total_ms * 1e-3, mean, best, last);
   return 0;
 }

@@ -29,6 +29,8 @@ def main():
     model = bench.build_model(dev).train()
     model.math_mode, model.backward_math = os.environ.get("PN_AB_FORWARD", "bf16x3"), os.environ.get("PN_AB_BACKWARD", "bf16")
     model.forward_math = os.environ.get("PN_AB_FORWARD_MATH", "same")
+    if "PN_AB_MFMA16" in os.environ:  # run-time A/B of the one-product NT kernels' MFMA shape (round 6)
+        _lib.check(_lib.lib().pn_set_bf16_mfma16(int(os.environ["PN_AB_MFMA16"])))
     opt = FusedClipAdam(list(head_parameters(model)), lr=3e-4, max_norm=1.0)
     loss_fn = get_loss({"params": {"LOSS_FN": "BCE"}}, bce_pos_weight=torch.tensor(1.0))
     batch = bench.synthetic_batch(256, 512, 32102, dev, seed=1000)
@@ -45,7 +47,7 @@ def main():
     # a checksum of every gradient-updated weight after the timed steps: A/B variants that claim bit-identity must agree on it
     checksum = float(opt.flat_w.double().sum().item())
     out = {"build_hash": _lib.build_hash(), "flat_w_checksum": repr(checksum),
-           "modes": {"math": model.math_mode, "forward_math": model.forward_math, "backward_math": model.backward_math}, "csrc_hash_now": build.csrc_hash(), "extra_flags": build._extra(),
+           "modes": {"math": model.math_mode, "forward_math": model.forward_math, "backward_math": model.backward_math}, "csrc_hash_now": build.csrc_hash(), "extra_flags": build._extra(), "bf16_mfma16": os.environ.get("PN_AB_MFMA16", "default (1)"),
            "steps": steps, "ms_per_step": dt * 1e3, "final_loss": float(loss),
            "per_launch_ms": {bench.KIND_NAMES.get(k, str(k)): round(v[1] / v[0], 3) for k, v in sorted(bench.gemm_kinds(prof).items())
                              if v[0] > 0 and v[2] / v[0] > 1e12},
