@@ -562,16 +562,23 @@ template <int TB, int NP = 3, bool TR = false, bool ABF16 = false>
 static int launch_tn_bf16x3(TnParams p, float* dst, long ldd, float* part, size_t part_cap_floats, hipStream_t st) {
   void (*kern)(TnParams) = nullptr;
   constexpr bool SYNC = TR && TB == TB_AFFINE_RELU;  // pacing for the kind whose two operands both stream from HBM
-  if constexpr (TR) kern = gemm_tn_bf16tr_kernel<TB, ABF16, SYNC>;
-  else kern = gemm_tn_bf16x3_kernel<TB, NP>;
+  void (*kern_alt)(TnParams) = nullptr;  // TR: the 32 x 32 x 16 form (pn_set_bf16_mfma16(0))
+  if constexpr (TR) {
+    kern = gemm_tn_bf16tr_kernel<TB, ABF16, SYNC, true>;
+    kern_alt = gemm_tn_bf16tr_kernel<TB, ABF16, SYNC, false>;
+  } else {
+    kern = gemm_tn_bf16x3_kernel<TB, NP>;
+  }
   constexpr int LDS = TR ? TN_BF16TR_LDS_BYTES : 2 * 512 * 36 * (int)sizeof(float);
   static std::atomic<bool> attr_done[64];  // zero-initialised; hipFuncSetAttribute is idempotent, the flag only saves the call
   int dev = 0;
   HIP_OK(hipGetDevice(&dev));
   if (dev < 64 && !attr_done[dev]) {
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (kern_alt != nullptr) HIP_OK(hipFuncSetAttribute((const void*)kern_alt, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done[dev] = true;
   }
+  if (kern_alt != nullptr && !g_bf16_m16.load()) kern = kern_alt;
   int ns = tn_pick_split(p.R, p.M, p.N, part_cap_floats, 256, 1);
   if (ns == 1) {
     p.Cpart = dst;

@@ -4,6 +4,8 @@
 //   * dh = dz W        gemm_nt_bf16dma_kernel: BOTH operands by LDS-DMA (no vector instruction touches an operand), BK = 64;
 //   * dW = dz^T h      gemm_tn_bf16tr_kernel<TB, true>: the dz tile goes global -> registers -> LDS as it is (no conversion).
 // The bytes of the dz operand halve on every path (HBM, fabric, L2 -> L1), and k_dz_apply writes half of what it wrote.
+// (Round 6: both GEMMs issue their products as v_mfma_f32_16x16x32_bf16 by default - gemm_bf16_m16.hpp's gemm_nt_bf16m16_kernel and
+// the M16 form of gemm_tn_bf16tr_kernel, bit-identical accumulators; pn_set_bf16_mfma16(0) selects the 32 x 32 x 16 forms below.)
 // Same bf16 values as the staging-time rounding of gemm_bf16.hpp (round to nearest even, applied to the same f32 dz).
 #pragma once
 #include "gemm_bf16.hpp"

@@ -6,7 +6,8 @@
 //   h_{l-1}[r][:] = relu(A'[r % B] + B'[r / B])     (layer 2: from the two folded layer-1 tables, L2-resident)
 //                 = relu(s * z_{l-1}[r] + t)         (deeper layers: one read of the stored f32 pre-activation)
 // is written ONCE as bf16 (k_make_h_bf16: 2 B per element, a chunk at a time into a workspace buffer - nothing of pair-grid
-// size is allocated), then z_l = h_{l-1} W_l^T runs on gemm_nt_bf16dma_kernel<EK> with the usual epilogues (E_STORE + BatchNorm
+// size is allocated), then z_l = h_{l-1} W_l^T runs on gemm_nt_bf16m16_kernel<EK> (gemm_bf16_m16.hpp; pn_set_bf16_mfma16(0): gemm_nt_bf16dma_kernel<EK>,
+// the same accumulators) with the usual epilogues (E_STORE + BatchNorm
 // column partials in training; E_STORE_H16 = the NEXT layer's relu(bn(.)) written straight as bf16, and E_ROWDOT, in eval).
 // Same bf16 values in the same products as the staging-time rounding; k is paired in natural order inside a 16-k MFMA step
 // (the register-staged kernels pair {4g..4g+3, 16+4g..}), so the two routes agree to f32 summation order.

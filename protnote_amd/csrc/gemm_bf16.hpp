@@ -16,6 +16,8 @@
 //   gemm_tn_bf16tr_kernel  dW = dz^T h.  Operands staged the way they lie in memory (16-byte loads along a row) and
 //     transposed by the LDS read path (ds_read_b64_tr_b16) instead of in registers: a quarter of the load instructions.
 #pragma once
+#include <type_traits>
+
 #include "gemm_bf16x3.hpp"
 #include "gemm_tn_fast.hpp"
 
@@ -249,11 +251,20 @@ __device__ __forceinline__ void lds_write_bf16x4(unsigned addr, float a, float b
 // SYNC: the 32 workgroups of a region task pace each other every PN_TN_SYNC_SLABS slabs (gemm_tn_fast.hpp: arrival counters
 // in the caller's workspace, bounded wait, an optimisation and never a dependency) - for the kind whose two operands both
 // stream from HBM, so that the task's panels stay in the XCD's L2 while all 32 need them.
-template <int TB, bool ABF16 = false, bool SYNC = false>
+// M16 (round 6): the products are issued as v_mfma_f32_16x16x32_bf16 - the shape this package can feed (gemm_bf16_m16.hpp: the
+// register-only loop sustains 2.12 PFLOP/s on it, 1.86 on 32 x 32 x 16).  A slab of 32 k-rows is then ONE k-step: a fragment is
+// 16 columns x 32 k, lane l takes column l % 16 and k = 8 (l / 16) .. + 7 as two transpose reads of the k-rows 8 (l / 16) .. + 3
+// and + 4 .. + 7 - so the two 16-lane groups a ds_read_b64_tr_b16 services together point at k-rows r and r + 8 of the SAME
+// columns, which a uniform row stride puts on the same banks (8 x 576 = 18 x 256): the k-rows with bit 3 set are therefore
+// stored 32 bytes to the right, into the row's padding (writers and readers add the same constant; rows 0-3 then cover the
+// 32-byte slots 0, 2, 4, 6 of the bank window and rows 8-11 the slots 1, 3, 5, 7).  Same staging, pacing, task order and k
+// order per accumulator; 24 transpose reads and 32 MFMAs of 16 Kflop per slab where the 32 x 32 x 16 form has 24 and 16 of 32.
+template <int TB, bool ABF16 = false, bool SYNC = false, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p) {
   static_assert(TB == TB_AFFINE_RELU || TB == TB_PAIRSUM_RELU, "operand kind not built for the transpose-read TN kernel");
   constexpr int BM = 256, BN = 256, BK = 32, NQ = 4;
   constexpr unsigned ROWB = 576u;         // LDS bytes of one k-row: 256 bf16 + 64 bytes of padding
+  constexpr unsigned SH8 = M16 ? 32u : 0u;  // byte shift of the k-rows with bit 3 set (8-15, 24-31)
   constexpr unsigned TILEB = BK * ROWB;   // one operand buffer; LDS: A0 | A1 | B0 | B1
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
   auto pin_b = [&]() { asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb2)); };
   unsigned wr_addr = lds0 + (unsigned)wave * ROWB + 8u * lane;  // this thread's 4 columns in tile row `wave` of A buffer 0
   asm volatile("" : "+v"(wr_addr));
-  unsigned wr16_addr = lds0 + (unsigned)(2 * wave + (lane >> 5)) * ROWB + 16u * (lane & 31);  // ABF16: 8 columns of that row
+  // ABF16: 8 columns of row 2 wave + lane / 32 (and of that + 16: the same bit 3)
+  unsigned wr16_addr = lds0 + (unsigned)(2 * wave + (lane >> 5)) * ROWB + 16u * (lane & 31) + ((wave & 4) ? SH8 : 0u);
   asm volatile("" : "+v"(wr16_addr));
   auto commit_a = [&](auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
     } else {
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        lds_write_bf16x4(wr_addr + (BUF * TILEB + (unsigned)(8 * q) * ROWB), ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+        lds_write_bf16x4(wr_addr + (BUF * TILEB + (unsigned)(8 * q) * ROWB + (q & 1) * SH8), ra[q].x, ra[q].y, ra[q].z, ra[q].w);
     }
   };
   auto commit_b = [&](auto buf_c) {
@@ -382,26 +394,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
         lo = pk_add(rb[q].xy, rb2.xy);
         hi = pk_add(rb[q].zw, rb2.zw);
       }
-      lds_write_bf16x4(wr_addr + ((2 + BUF) * TILEB + (unsigned)(8 * q) * ROWB), relu_raw(lo.x), relu_raw(lo.y), relu_raw(hi.x),
-                       relu_raw(hi.y));
+      lds_write_bf16x4(wr_addr + ((2 + BUF) * TILEB + (unsigned)(8 * q) * ROWB + (q & 1) * SH8), relu_raw(lo.x), relu_raw(lo.y),
+                       relu_raw(hi.x), relu_raw(hi.y));
     }
   };
 
-  f32x16 acc[2][4];
+  // accumulators: 2 x 4 tiles of 32 x 32 (f32x16), or - M16 - 4 x 8 tiles of 16 x 16 (f32x4): 128 registers either way
+  typedef typename std::conditional<M16, f32x4, f32x16>::type acc_t;
+  constexpr int FI = M16 ? 4 : 2, FJ = M16 ? 8 : 4, AE = M16 ? 4 : 16;
+  acc_t acc[FI][FJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < FJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
   // fragment = 32 columns x 16 k of a k-step: lane l takes column l % 32 and k = 8 (l / 32) .. + 7 as two transpose reads of
   // 4 k each.  Inside its 16-lane group lane i points at k-row (i / 4) of the quad and at columns 16 ((l / 16) % 2) + 4 (i % 4)
   // of the 32; the hardware returns column i of that 4 x 16 block.
+  // M16: fragment = 16 columns x 32 k: lane group l / 16 takes the k-rows 8 (l / 16) .. + 7, lane i of it points at k-row
+  // 8 (l / 16) + i / 4 (+ 4 for the second read) and at columns 4 (i % 4) of the 16.
   const int li = lane & 15, lg = lane >> 4;
-  unsigned fa_addr = lds0 + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB + (unsigned)(wm * 64 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
-  unsigned fb_addr = lds0 + 2u * TILEB + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB +
-                     (unsigned)(wn * 128 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
+  unsigned fa_addr = M16 ? lds0 + (unsigned)(8 * lg + (li >> 2)) * ROWB + (unsigned)(lg & 1) * SH8 + (unsigned)(wm * 64 + 4 * (li & 3)) * 2u
+                         : lds0 + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB + (unsigned)(wm * 64 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
+  unsigned fb_addr = M16 ? lds0 + 2u * TILEB + (unsigned)(8 * lg + (li >> 2)) * ROWB + (unsigned)(lg & 1) * SH8 +
+                               (unsigned)(wn * 128 + 4 * (li & 3)) * 2u
+                         : lds0 + 2u * TILEB + (unsigned)(8 * (lg >> 1) + (li >> 2)) * ROWB +
+                               (unsigned)(wn * 128 + 16 * (lg & 1) + 4 * (li & 3)) * 2u;
   asm volatile("" : "+v"(fa_addr), "+v"(fb_addr));
   auto compute = [&](auto buf_c, auto ks_c) {
     constexpr int BUF = decltype(buf_c)::value, KS = decltype(ks_c)::value;
@@ -418,10 +438,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
       const s16x4 hi = lds_read_tr4(fb_addr + (BUF * TILEB + (unsigned)(16 * KS + 4) * ROWB + j * 64u));
       b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
+    if constexpr (!M16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // M16: the slab's 24 transpose reads, then its 32 MFMAs in two halves (accumulator rows 0-1, 2-3)
+  bf16x8 a16[4], b16[8];
+  auto read16 = [&](auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s16x4 lo = lds_read_tr4(fa_addr + (BUF * TILEB + i * 32u));
+      const s16x4 hi = lds_read_tr4(fa_addr + (BUF * TILEB + 4u * ROWB + i * 32u));
+      a16[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const s16x4 lo = lds_read_tr4(fb_addr + (BUF * TILEB + j * 32u));
+      const s16x4 hi = lds_read_tr4(fb_addr + (BUF * TILEB + 4u * ROWB + j * 32u));
+      b16[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  auto mma16 = [&](auto h_c) {
+    constexpr int H = decltype(h_c)::value;
+    if constexpr (M16) {
+#pragma unroll
+      for (int i = 2 * H; i < 2 * H + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[i], b16[j], acc[i][j], 0, 0, 0);
+    }
   };
   // eight MFMAs of a k-step with half a slab's conversion + LDS writes woven between them
   auto weave = [&](auto nvalu_c) {
@@ -432,6 +480,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
       if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+  };
+  // M16: sixteen MFMAs (half a slab) with the same work woven between them; NR transpose reads first
+  auto weave16 = [&](auto nread_c, auto nvalu_c) {
+    constexpr int NR = decltype(nread_c)::value, NV = decltype(nvalu_c)::value;
+    if constexpr (NR > 0) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
   };
 
@@ -475,16 +534,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
       __builtin_amdgcn_sched_barrier(0);
       pin_a();
       if constexpr (SYNC && CUR == 0) checkpoint(t);
-      compute(C{}, I0{});
-      commit_a(N{});
-      weave(integral_constant<int, 1>{});
+      if constexpr (M16) {
+        read16(C{});
+        mma16(I0{});
+        commit_a(N{});
+        weave16(integral_constant<int, 24>{}, integral_constant<int, 1>{});
+      } else {
+        compute(C{}, I0{});
+        commit_a(N{});
+        weave(integral_constant<int, 1>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
       fetch_a(t2);
       __builtin_amdgcn_sched_barrier(0);
       pin_b();
-      compute(C{}, I1{});
-      commit_b(N{});
-      weave(integral_constant<int, 3>{});
+      if constexpr (M16) {
+        mma16(I1{});
+        commit_b(N{});
+        weave16(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+      } else {
+        compute(C{}, I1{});
+        commit_b(N{});
+        weave(integral_constant<int, 3>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
       fetch_b(t2);
       __builtin_amdgcn_sched_barrier(0);
@@ -501,24 +573,44 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_bf16tr_kernel(const TnParams p
     // hipcc keep two copies of the 128 accumulators across the merge and spill ~250 registers)
     fa_addr += (unsigned)(last & 1) * TILEB;
     fb_addr += (unsigned)(last & 1) * TILEB;
-    compute(I0{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    compute(I0{}, I1{});
+    if constexpr (M16) {
+      read16(I0{});
+      mma16(I0{});
+      mma16(I1{});
+    } else {
+      compute(I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      compute(I0{}, I1{});
+    }
   }
 
   float* out = p.Cpart + (long)split * p.M * p.ldc;
-  const int hl = lane >> 5, cl = lane & 31;
+  if constexpr (M16) {  // accumulator (i, j), lane l: column l % 16, rows 4 (l / 16) + e
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + (wn * 4 + j) * 32 + cl;
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + (wn * 8 + j) * 16 + li;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-        out[(long)m * p.ldc + n] = acc[i][j][e];
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + (wm * 4 + i) * 16 + 4 * lg + e;
+          out[(long)m * p.ldc + n] = acc[i][j][e];
+        }
       }
-    }
+  } else {
+    const int hl = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (wn * 4 + j) * 32 + cl;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+          out[(long)m * p.ldc + n] = acc[i][j][e];
+        }
+      }
+  }
 }
 constexpr int TN_BF16TR_LDS_BYTES = 4 * 32 * 576;
 

@@ -428,10 +428,11 @@ def test_forward_bf16_routes_agree(fusion, nl, B, NL):
 
 
 def test_mfma16_matches_mfma32():
-    """pn_set_bf16_mfma16: the all-LDS-DMA one-product bf16 NT GEMMs run on v_mfma_f32_16x16x32_bf16 (gemm_bf16_m16.hpp, default) or on
-    v_mfma_f32_32x32x16_bf16 (bwd_bf16_dz.hpp).  Every accumulator is bit-identical between the two (tools/lab_bf16_nt.hip compares z
-    and the bf16 h on the device at 262 144 x 3072 x 3072); what differs is the reduction order of the fused epilogues.  Held here:
-    (i) backward_math = bf16 over an f32 forward - dh = dz W is a plain store, so EVERY gradient is bit-identical;
+    """pn_set_bf16_mfma16: the one-product bf16 GEMMs - the all-LDS-DMA NT kernel (gemm_bf16_m16.hpp) and the transpose-read
+    weight-gradient kernel (gemm_bf16.hpp, M16) - issue v_mfma_f32_16x16x32_bf16 (default) or v_mfma_f32_32x32x16_bf16.  Every
+    accumulator is bit-identical between the two (tools/lab_bf16_nt.hip compares z and the bf16 h on the device at
+    262 144 x 3072 x 3072); what differs is the reduction order of the fused epilogues.  Held here:
+    (i) backward_math = bf16 over an f32 forward - dh = dz W and dW = dz^T h are plain stores, so EVERY gradient is bit-identical;
     (ii) forward_math = bf16, eval - h is bit-identical, the logits are row dots summed in another order: f32 rounding only;
     (iii) forward_math = bf16, train - the BatchNorm column partials sum in another order, batch statistics move in the last ulp, a few
     elements of the next bf16 operand round the other way: same arithmetic class (same distance from the float64 oracle, rms of the
