@@ -21,7 +21,7 @@ for sub in ("sq", "mem", "fetch", "write"):
         seen = set()
         for r in csv.DictReader(open(f, newline="")):
             k = r["Kernel_Name"]
-            if not ("bf16dma" in k or "make_h" in k): continue
+            if not ("bf16dma" in k or "bf16m16" in k or "make_h" in k): continue
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
             if d < 1.0: continue   # pair-grid chunk launches only (8 ms GEMMs, ~1.5 ms operand passes)
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
