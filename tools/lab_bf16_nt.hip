@@ -274,6 +274,24 @@ int main(int argc, char** argv) {
       CK(hipMemset(C32, 0xff, (size_t)M * h * 4));
       run("m16s     <E_STORE> f32 plain, swapped, non-temporal", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE, 7>, 512, pn::NT_BF16DMA_LDS_BYTES, pq, reps, &ms);
       maxdiff("z vs shipped", C32ref, C32, M * h, false, b.dg, &bad, 2e-5);
+      for (int P : {2, 4, 8}) {
+        for (int tile_cyc : {120000, 170000}) {
+          pn::GemmParams pg = pq;
+          pg.L = P;
+          pg.dil = tile_cyc / P;
+          char lab[96];
+          snprintf(lab, sizeof lab, "m16 <E_STORE> plain, staggered %d x %d cyc", P, tile_cyc / P);
+          CK(hipMemset(C32, 0xff, (size_t)M * h * 4));
+          run(lab, pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE, 33>, 512, pn::NT_BF16DMA_LDS_BYTES, pg, reps, &ms);
+          maxdiff("z vs shipped", C32ref, C32, M * h, false, b.dg, &bad, 0.0);
+        }
+      }
+      {
+        pn::GemmParams pg = p;  // row dots: no stores - what does the stagger itself cost?
+        pg.L = 4;
+        pg.dil = 170000 / 4;
+        run("m16 <E_ROWDOT>, staggered 4 x 42500 cyc", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_ROWDOT, 33>, 512, pn::NT_BF16DMA_LDS_BYTES, pg, reps, &ms);
+      }
       pn::GemmParams ph = p;
       CK(hipMemset(b.C16, 0xff, (size_t)c_words * 4));
       run("m16s     <E_STORE_H16> swapped, non-temporal", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE_H16, 7>, 512, pn::NT_BF16DMA_LDS_BYTES, ph, reps, &ms);

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16dma_v_kernel(const GemmPar
 // Accumulator of fragment (i, j): lane l holds column l % 16, rows 4 (l / 16) + e, e = 0..3.
 // Loop, rotated at the barrier:   barrier(s) | read (s, 0) -> F | DMA of slab s + 1 | MFMAs (s - 1, 1) from G |
 //                                 read (s, 1) -> G | MFMAs (s, 0) from F | wait, barrier(s + 1)
-// VAR bit 0: the weight pieces go behind the first MFMA phase instead of ahead of it;  bit 1: swapped operand roles (epilogue16s);  bit 2: non-temporal stores.
+// VAR bit 0: the weight pieces go behind the first MFMA phase instead of ahead of it;  bit 1: swapped operand roles (epilogue16s);  bit 2: non-temporal stores;  bit 5: staggered start (below).
 // ---------------------------------------------------------------------------------------------------------------------
 // 16-byte / 8-byte global stores, optionally non-temporal (the output is not read again by this kernel)
 template <bool NTS>
@@ -717,6 +717,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16dma_m16_kernel(const GemmP
   const int col0 = tile_n * BN;
   const int nslab = p.Kseg / 64;
   const unsigned lds0 = lds_addr(smem);
+  // VAR bit 5 (lab): stagger the first wave of workgroups (one per CU) over p.L phases of p.dil shader cycles each, so that the
+  // CUs - which otherwise run their equal tiles in lockstep and all store at the same moment - spread their epilogues over a tile time
+  if constexpr ((VAR & 32) != 0) {
+    const int bid = blockIdx.x;
+    if (bid < 256 && p.L > 1) {
+      const long target = (long)((bid >> 3) % p.L) * p.dil;
+      const long t0 = (long)__builtin_amdgcn_s_memtime();
+      while ((long)__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(32);
+    }
+  }
 
   const char* w_tile = reinterpret_cast<const char*>(p.w_hi) + (long)col0 * p.Kseg * 2;
   const char* a_tile = reinterpret_cast<const char*>(p.A) + (long)row0 * p.lda * 4;
