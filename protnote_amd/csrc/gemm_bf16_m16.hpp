@@ -8,24 +8,21 @@
 // MFMA loop sustains 1.86 PFLOP/s on 32 x 32 x 16 and 2.12 on 16 x 16 x 32 (the deeper dot product moves half the accumulator
 // bytes per flop), and the vendor library's kernel for this shape (256 x 256 x 64 tile, 16 x 16 x 32, 1.46 PFLOP/s:
 // profiles/r06_bf16_gemm_yardstick.json) uses the latter.  Same tile, LDS image, DMA pieces and XCD order as
-// gemm_nt_bf16dma_kernel; the main loop alone gains 12 % (E_ROWDOT 1.25 -> 1.41 PFLOP/s), the storing epilogues 4 % (their
-// ~10 us of stores per tile - ~14 B per clock and CU - stay exposed: one workgroup per CU).
+// gemm_nt_bf16dma_kernel; the main loop alone gains 12 % (E_ROWDOT 1.25 -> 1.41 PFLOP/s), the f32-storing epilogues 4 % (their
+// ~10 us of stores per tile stay exposed: one workgroup per CU), the bf16-storing one 12 % (16-byte stores of fragment pairs).
 //
-// Results: every accumulator is bit-identical to the 32 x 32 x 16 kernel's (z and the bf16 h compare equal on the device; measured,
-// not assumed: tools/lab_bf16_nt.hip on 262 144 x 3072 x 3072 and tests/test_hip_fwd_bf16.py::test_mfma16_matches_mfma32); the row dots and the BatchNorm column partials reduce in another order
-// (last-ulp differences).  pn_set_bf16_mfma16(0) selects the 32 x 32 x 16 kernel (A/B, the tests).
+// Results: every accumulator is bit-identical to the 32 x 32 x 16 kernel's (z and the bf16 h compare equal on the device;
+// measured, not assumed: tools/lab_bf16_nt.hip on 262 144 x 3072 x 3072, tests/test_hip_fwd_bf16.py::test_mfma16_matches_mfma32);
+// the row dots and the BatchNorm column partials reduce in another order (last-ulp differences).  pn_set_bf16_mfma16(0) selects
+// the 32 x 32 x 16 kernel (A/B, the tests).
 #pragma once
 #include "bwd_bf16_dz.hpp"
 
 namespace pn {
 
-// 16-byte / 8-byte global stores
+// 16-byte global store
 __device__ __forceinline__ void st16(float* ptr, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(ptr) = make_float4(a, b, c, d);
-}
-__device__ __forceinline__ void st8(uint16_t* ptr, uint32_t lo, uint32_t hi) {
-  typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<u32x2_*>(ptr) = u32x2_{lo, hi};
 }
 
 // 4 x 4 transpose across the four lanes of a quad (lane & 3 = a): in, lane a holds x[b] = V[b][a]; out, x[b] = V[a][b].
@@ -46,11 +43,11 @@ __device__ __forceinline__ void quad_transpose(float (&x)[4], int a) {
 
 // Epilogue of the 16 x 16 x 32 kernels: accumulator of fragment (i, j), lane l: column l % 16, rows 4 (l / 16) + e.  Stores go
 // through quad_transpose over four adjacent fragments, after which lane (c = (l % 16) / 4, a = l % 4) holds columns
-// 16 (4 J + a) + 4 c .. + 3 of its row: one 16-byte (f32) / 8-byte (bf16) store per lane, 256 / 128 contiguous bytes per row and
-// instruction.  N % 256 == 0 (launcher), so there is no column bound to check.
+// 16 (4 J + a) + 4 c .. + 3 of its row: one 16-byte store per lane, 256 contiguous bytes per row and instruction.  (E_STORE_H16 goes
+// through the swapped roles and gemm_epilogue_m16s_h16 below.)  N % 256 == 0 (launcher), so there is no column bound to check.
 template <int EK, int WAVES_M, int WAVES_N, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_m16(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int tile_n, float* smem) {
-  static_assert(EK == E_STORE || EK == E_ROWDOT || EK == E_STORE_H16, "epilogues of the bf16 h-operand GEMMs");
+  static_assert(EK == E_STORE || EK == E_ROWDOT, "E_STORE_H16 takes the swapped roles");
   static_assert(FN % 4 == 0, "stores transpose four fragments at a time");
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BN = WAVES_N * FN * 16;
@@ -102,7 +99,7 @@ __device__ __forceinline__ void gemm_epilogue_m16(const GemmParams& p, f32x4 (&a
       const int col = col0 + (wn * FN + j) * 16 + cl;
       float bj = 0.f, es = 1.f, et = 0.f;
       if constexpr (EK == E_STORE) bj = p.bias ? p.bias[col] : 0.f;
-      const bool act = (EK == E_STORE_H16) || store_act;
+      const bool act = store_act;
       if (act) {
         es = p.e_scale[col];
         et = p.e_shift[col];
@@ -145,12 +142,7 @@ __device__ __forceinline__ void gemm_epilogue_m16(const GemmParams& p, f32x4 (&a
           quad_transpose(x, qa);
           const int col = col0 + (wn * FN + 4 * J + qa) * 16 + 4 * qc;
           if (row < p.M) {
-            if constexpr (EK == E_STORE) {
-              st16(p.C + (long)row * p.ldc + col, x[0], x[1], x[2], x[3]);
-            } else {
-              typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-              st8(reinterpret_cast<uint16_t*>(p.C) + (long)row * p.ldc + col, round2(x[0], x[1]), round2(x[2], x[3]));
-            }
+            st16(p.C + (long)row * p.ldc + col, x[0], x[1], x[2], x[3]);
           }
         }
       }
@@ -170,15 +162,17 @@ __device__ __forceinline__ void gemm_epilogue_m16(const GemmParams& p, f32x4 (&a
   }
 }
 
-// Epilogue for the SWAPPED operand roles (the MFMA is given the weight fragment as its row operand): accumulator of fragment
-// (i, j), lane l: ROW l % 16 of the 16-row fragment i, COLUMNS 4 (l / 16) + e of fragment j - four consecutive columns per lane, so
-// a fragment is one 16-byte store per lane (16 rows x 64 contiguous bytes per instruction) and needs no cross-lane move; a row's
-// dot product is an in-lane sum and two shuffles; a column's BatchNorm partial is a sum over the 16 lanes of a row group.
-template <int EK, int WAVES_M, int WAVES_N, int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue_m16s(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int tile_n, float* smem) {
-  static_assert(EK == E_STORE || EK == E_ROWDOT || EK == E_STORE_H16, "epilogues of the bf16 h-operand GEMMs");
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BN = WAVES_N * FN * 16;
+// Epilogue of E_STORE_H16 for the SWAPPED operand roles (the MFMA is given the weight fragment as its row operand): accumulator of
+// fragment (i, j), lane l: ROW l % 16 of the 16-row fragment i, COLUMNS 4 (l / 16) + e of fragment j - four consecutive columns per
+// lane without a cross-lane move.  As bf16 that is 8 bytes per lane and 32 contiguous bytes per row, which the store path handles
+// badly (~5 B per clock and CU: 15 us per tile).  So two fragments go together: v_permlane16_swap exchanges the odd 16-lane rows of
+// fragment j's packed columns with the even rows of fragment j + 1's, after which a lane of an even row holds columns
+// 4 cq .. + 7 of fragment j and a lane of an odd row columns 4 (cq - 1) .. + 7 of fragment j + 1: ONE 16-byte store, 64 contiguous
+// bytes per row and instruction - 4.33 -> 3.97 ms per 262 144-row launch, 0.23 ms above the storeless row-dot kernel (four
+// fragments per store group, 128 contiguous bytes: the same).  Same values in the same places: bit-identical output.
+template <int WAVES_M, int WAVES_N, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_m16s_h16(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0) {
+  static_assert(FN % 2 == 0, "fragments are stored in pairs");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -186,97 +180,24 @@ __device__ __forceinline__ void gemm_epilogue_m16s(const GemmParams& p, f32x4 (&
   const int wn = wave % WAVES_N;
   const int cq = lane >> 4;  // which 4-column group of a 16-column fragment
   const int rl = lane & 15;
-  const bool want_stats = (EK == E_STORE) && (p.col_part != nullptr);
-  const bool store_act = (EK == E_STORE) && (p.e_scale != nullptr);
-  float* red = smem;
-  const int colw = col0 + wn * FN * 16 + 4 * cq;  // + 16 j + e
-  if constexpr (EK == E_ROWDOT) {
-    float rowacc[FM];
+  const int colw = col0 + wn * FN * 16 + 4 * cq;  // + 16 j + e: this lane's columns before the exchange
 #pragma unroll
-    for (int i = 0; i < FM; ++i) rowacc[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const float4 es = ld4(p.e_scale + colw + 16 * j), et = ld4(p.e_shift + colw + 16 * j), ew = ld4(p.e_w + colw + 16 * j);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        rowacc[i] += relu(fmaf(acc[i][j][0], es.x, et.x)) * ew.x;
-        rowacc[i] += relu(fmaf(acc[i][j][1], es.y, et.y)) * ew.y;
-        rowacc[i] += relu(fmaf(acc[i][j][2], es.z, et.z)) * ew.z;
-        rowacc[i] += relu(fmaf(acc[i][j][3], es.w, et.w)) * ew.w;
-      }
-    }
+  for (int j = 0; j < FN; j += 2) {
+    const float4 es0 = ld4(p.e_scale + colw + 16 * j), et0 = ld4(p.e_shift + colw + 16 * j);
+    const float4 es1 = ld4(p.e_scale + colw + 16 * j + 16), et1 = ld4(p.e_shift + colw + 16 * j + 16);
+    const int col = col0 + wn * FN * 16 + 16 * (j + (cq & 1)) + 4 * (cq & ~1);  // after the exchange
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      float v = rowacc[i];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
       const int row = row0 + (wm * FM + i) * 16 + rl;
-      if (cq == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
-    }
-    return;
-  } else {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      float4 bj = make_float4(0.f, 0.f, 0.f, 0.f), es = make_float4(1.f, 1.f, 1.f, 1.f), et = bj;
-      if constexpr (EK == E_STORE)
-        if (p.bias) bj = ld4(p.bias + colw + 16 * j);
-      const bool act = (EK == E_STORE_H16) || store_act;
-      if (act) {
-        es = ld4(p.e_scale + colw + 16 * j);
-        et = ld4(p.e_shift + colw + 16 * j);
-      }
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = row0 + (wm * FM + i) * 16 + rl;
-        float v[4] = {acc[i][j][0] + bj.x, acc[i][j][1] + bj.y, acc[i][j][2] + bj.z, acc[i][j][3] + bj.w};
-        if (act) {
-          v[0] = relu(fmaf(v[0], es.x, et.x));
-          v[1] = relu(fmaf(v[1], es.y, et.y));
-          v[2] = relu(fmaf(v[2], es.z, et.z));
-          v[3] = relu(fmaf(v[3], es.w, et.w));
-        }
-        if (row < p.M) {
-          if constexpr (EK == E_STORE) {
-            st16(p.C + (long)row * p.ldc + colw + 16 * j, v[0], v[1], v[2], v[3]);
-          } else {
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            st8(reinterpret_cast<uint16_t*>(p.C) + (long)row * p.ldc + colw + 16 * j, round2(v[0], v[1]), round2(v[2], v[3]));
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * v[e];
-          }
-        }
-      }
-      if (want_stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s1[e] += __shfl_xor(s1[e], m);
-            s2[e] += __shfl_xor(s2[e], m);
-          }
-        }
-        if (rl == 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            red[(wm * 2 + 0) * BN + (wn * FN + j) * 16 + 4 * cq + e] = s1[e];
-            red[(wm * 2 + 1) * BN + (wn * FN + j) * 16 + 4 * cq + e] = s2[e];
-          }
-        }
-      }
-    }
-    if (want_stats) {
-      __syncthreads();
-      const long tile_m = row0 / (WAVES_M * FM * 16);
-      for (int i = tid; i < 2 * BN; i += NT) {
-        const int which = i / BN, c = i - which * BN;
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_M; ++w) a += red[(w * 2 + which) * BN + c];
-        p.col_part[(tile_m * 2 + which) * p.N + col0 + c] = a;
+      const uint32_t x0 = round2(relu(fmaf(acc[i][j][0], es0.x, et0.x)), relu(fmaf(acc[i][j][1], es0.y, et0.y)));
+      const uint32_t x1 = round2(relu(fmaf(acc[i][j][2], es0.z, et0.z)), relu(fmaf(acc[i][j][3], es0.w, et0.w)));
+      const uint32_t y0 = round2(relu(fmaf(acc[i][j + 1][0], es1.x, et1.x)), relu(fmaf(acc[i][j + 1][1], es1.y, et1.y)));
+      const uint32_t y1 = round2(relu(fmaf(acc[i][j + 1][2], es1.z, et1.z)), relu(fmaf(acc[i][j + 1][3], es1.w, et1.w)));
+      const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);  // (every lane takes part: no divergence above)
+      const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+      if (row < p.M) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4_*>(reinterpret_cast<uint16_t*>(p.C) + (long)row * p.ldc + col) = u32x4_{s0[0], s1[0], s0[1], s1[1]};
       }
     }
   }
@@ -287,8 +208,8 @@ __device__ __forceinline__ void gemm_epilogue_m16s(const GemmParams& p, f32x4 (&
 // Loop, rotated at the barrier:   barrier(s) | read (s, 0) -> F | A pieces of slab s + 1 | 32 MFMAs of (s - 1, 1) from G |
 //                                 W pieces of slab s + 1 | read (s, 1) -> G | 32 MFMAs of (s, 0) from F | wait, barrier(s + 1)
 // (of six placements of the eight DMA pieces this one was the fastest: the streamed operand first, a whole slab to land).
-// SWAP: the weight fragment is the MFMA's row operand - the accumulator is then transposed (gemm_epilogue_m16s: four consecutive
-// columns per lane, stores without cross-lane moves): faster for the 2-byte store of E_STORE_H16, slower for the others.
+// SWAP (E_STORE_H16): the weight fragment is the MFMA's row operand - the accumulator is then transposed (gemm_epilogue_m16s_h16:
+// four consecutive columns per lane); measured slower for the f32 store (64-byte row segments against the quad transpose's 256).
 template <int EK>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16m16_kernel(const GemmParams p) {
   constexpr int WAVES_M = 4, WAVES_N = 2, FM = 4, FN = 8;
@@ -419,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16m16_kernel(const GemmParam
   }
   if (s < nslab) slab(s, I1{}, I1{});
   mma(ga, gb);
-  if constexpr (SWAP) gemm_epilogue_m16s<EK, WAVES_M, WAVES_N, FM, FN>(p, acc, row0, col0, tile_n, smem);
+  if constexpr (SWAP) gemm_epilogue_m16s_h16<WAVES_M, WAVES_N, FM, FN>(p, acc, row0, col0);
   else gemm_epilogue_m16<EK, WAVES_M, WAVES_N, FM, FN>(p, acc, row0, col0, tile_n, smem);
 }
 

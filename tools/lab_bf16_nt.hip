@@ -297,6 +297,12 @@ int main(int argc, char** argv) {
       run("m16s     <E_STORE_H16> swapped, non-temporal", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE_H16, 7>, 512, pn::NT_BF16DMA_LDS_BYTES, ph, reps, &ms);
       maxdiff("bf16 h vs shipped", C16ref, b.C16, M * h, true, b.dg, &bad, 8e-3);
       CK(hipMemset(b.C16, 0xff, (size_t)c_words * 4));
+      run("m16s     <E_STORE_H16> swapped, fragment pairs (permlane16_swap)", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE_H16, 67>, 512, pn::NT_BF16DMA_LDS_BYTES, ph, reps, &ms);
+      maxdiff("bf16 h vs shipped: must be 0", C16ref, b.C16, M * h, true, b.dg, &bad, 0.0);
+      CK(hipMemset(b.C16, 0xff, (size_t)c_words * 4));
+      run("m16s     <E_STORE_H16> swapped, fragment quads (permlane16 + 32 swaps)", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE_H16, 131>, 512, pn::NT_BF16DMA_LDS_BYTES, ph, reps, &ms);
+      maxdiff("bf16 h vs shipped: must be 0", C16ref, b.C16, M * h, true, b.dg, &bad, 0.0);
+      CK(hipMemset(b.C16, 0xff, (size_t)c_words * 4));
       run("m16      <E_STORE_H16> non-temporal", pn::lab::gemm_nt_bf16dma_m16_kernel<pn::E_STORE_H16, 5>, 512, pn::NT_BF16DMA_LDS_BYTES, ph, reps, &ms);
       maxdiff("bf16 h vs shipped", C16ref, b.C16, M * h, true, b.dg, &bad, 8e-3);
     }

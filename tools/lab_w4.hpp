@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16dma_v_kernel(const GemmPar
 // Accumulator of fragment (i, j): lane l holds column l % 16, rows 4 (l / 16) + e, e = 0..3.
 // Loop, rotated at the barrier:   barrier(s) | read (s, 0) -> F | DMA of slab s + 1 | MFMAs (s - 1, 1) from G |
 //                                 read (s, 1) -> G | MFMAs (s, 0) from F | wait, barrier(s + 1)
-// VAR bit 0: the weight pieces go behind the first MFMA phase instead of ahead of it;  bit 1: swapped operand roles (epilogue16s);  bit 2: non-temporal stores;  bit 5: staggered start (below).
+// VAR bit 0: the weight pieces go behind the first MFMA phase instead of ahead of it;  bit 1: swapped operand roles (epilogue16s);  bit 2: non-temporal stores;  bit 5: staggered start (below);  bit 6: E_STORE_H16 of the swapped layout stores fragment pairs (v_permlane16_swap).
 // ---------------------------------------------------------------------------------------------------------------------
 // 16-byte / 8-byte global stores, optionally non-temporal (the output is not read again by this kernel)
 template <bool NTS>
@@ -588,7 +588,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
 // (i, j), lane l: ROW l % 16 of the 16-row fragment i, COLUMNS 4 (l / 16) + e of fragment j - four consecutive columns per lane, so
 // a fragment is one 16-byte store per lane (16 rows x 64 contiguous bytes per instruction) and needs no cross-lane move; a row's
 // dot product is an in-lane sum and two shuffles; a column's BatchNorm partial is a sum over the 16 lanes of a row group.
-template <int EK, int WAVES_M, int WAVES_N, int FM, int FN, bool NTS = false>
+template <int EK, int WAVES_M, int WAVES_N, int FM, int FN, bool NTS = false, bool PAIR16 = false, bool QUAD16 = false>
 __device__ __forceinline__ void gemm_epilogue16s(const GemmParams& p, f32x4 (&acc)[FM][FN], int row0, int col0, int tile_n, float* smem) {
   static_assert(EK == E_STORE || EK == E_ROWDOT || EK == E_STORE_H16, "epilogues of the bf16 h-operand GEMMs");
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -628,6 +628,71 @@ __device__ __forceinline__ void gemm_epilogue16s(const GemmParams& p, f32x4 (&ac
       if (cq == 0 && row < p.M) p.rowdot_out[(long)(tile_n * WAVES_N + wn) * p.M + row] = v;
     }
     return;
+  } else if constexpr (EK == E_STORE_H16 && QUAD16) {
+    // bf16 store, FOUR fragments at a time: the permlane16 exchange of the pair variant below, then v_permlane32_swap between the two
+    // pairs - lane row cq then holds all 16 columns of fragment j + cq: 32 contiguous bytes per lane (two 16-byte stores), 128 per row
+#pragma unroll
+    for (int j = 0; j < FN; j += 4) {
+      float4 es[4], et[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        es[f] = ld4(p.e_scale + colw + 16 * (j + f));
+        et[f] = ld4(p.e_shift + colw + 16 * (j + f));
+      }
+      const int col = col0 + wn * FN * 16 + 16 * (j + ((cq & 1) | ((cq & 2)))) ;  // fragment j + cq
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = row0 + (wm * FM + i) * 16 + rl;
+        uint32_t x[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          x[f][0] = round2(relu(fmaf(acc[i][j + f][0], es[f].x, et[f].x)), relu(fmaf(acc[i][j + f][1], es[f].y, et[f].y)));
+          x[f][1] = round2(relu(fmaf(acc[i][j + f][2], es[f].z, et[f].z)), relu(fmaf(acc[i][j + f][3], es[f].w, et[f].w)));
+        }
+        // step 1 (rows of 16 lanes): pair (0, 1) -> P = {p0, p1, p2, p3}, pair (2, 3) -> Q
+        const auto a0 = __builtin_amdgcn_permlane16_swap(x[0][0], x[1][0], false, false);
+        const auto a1 = __builtin_amdgcn_permlane16_swap(x[0][1], x[1][1], false, false);
+        const auto b0 = __builtin_amdgcn_permlane16_swap(x[2][0], x[3][0], false, false);
+        const auto b1 = __builtin_amdgcn_permlane16_swap(x[2][1], x[3][1], false, false);
+        // P = (a0[0], a1[0], a0[1], a1[1]): rows 0 / 2 hold columns 0-7 / 8-15 of fragment j, rows 1 / 3 those of fragment j + 1; Q likewise
+        const auto c0 = __builtin_amdgcn_permlane32_swap(a0[0], b0[0], false, false);
+        const auto c1 = __builtin_amdgcn_permlane32_swap(a1[0], b1[0], false, false);
+        const auto c2 = __builtin_amdgcn_permlane32_swap(a0[1], b0[1], false, false);
+        const auto c3 = __builtin_amdgcn_permlane32_swap(a1[1], b1[1], false, false);
+        // lanes 0-31 (rows 0, 1): P' = P (columns 0-7 of fragment j / j + 1), Q' = P of rows 2, 3 (their columns 8-15);
+        // lanes 32-63 (rows 2, 3): P' = Q of rows 0, 1 (columns 0-7 of fragment j + 2 / j + 3), Q' = Q (their columns 8-15)
+        if (row < p.M) {
+          typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+          uint16_t* dst = reinterpret_cast<uint16_t*>(p.C) + (long)row * p.ldc + col;
+          *reinterpret_cast<u32x4_*>(dst) = u32x4_{c0[0], c1[0], c2[0], c3[0]};
+          *reinterpret_cast<u32x4_*>(dst + 8) = u32x4_{c0[1], c1[1], c2[1], c3[1]};
+        }
+      }
+    }
+  } else if constexpr (EK == E_STORE_H16 && PAIR16) {
+    // bf16 store, two fragments at a time: v_permlane16_swap exchanges the odd 16-lane rows of fragment j's packed columns with the
+    // even rows of fragment j + 1's, after which a lane of an even row holds columns 4 cq .. + 7 of fragment j and a lane of an odd
+    // row columns 4 (cq - 1) .. + 7 of fragment j + 1: one 16-byte store, 64 contiguous bytes per row and instruction
+#pragma unroll
+    for (int j = 0; j < FN; j += 2) {
+      const float4 es0 = ld4(p.e_scale + colw + 16 * j), et0 = ld4(p.e_shift + colw + 16 * j);
+      const float4 es1 = ld4(p.e_scale + colw + 16 * j + 16), et1 = ld4(p.e_shift + colw + 16 * j + 16);
+      const int col = col0 + wn * FN * 16 + 16 * (j + (cq & 1)) + 4 * (cq & ~1);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = row0 + (wm * FM + i) * 16 + rl;
+        const uint32_t x0 = round2(relu(fmaf(acc[i][j][0], es0.x, et0.x)), relu(fmaf(acc[i][j][1], es0.y, et0.y)));
+        const uint32_t x1 = round2(relu(fmaf(acc[i][j][2], es0.z, et0.z)), relu(fmaf(acc[i][j][3], es0.w, et0.w)));
+        const uint32_t y0 = round2(relu(fmaf(acc[i][j + 1][0], es1.x, et1.x)), relu(fmaf(acc[i][j + 1][1], es1.y, et1.y)));
+        const uint32_t y1 = round2(relu(fmaf(acc[i][j + 1][2], es1.z, et1.z)), relu(fmaf(acc[i][j + 1][3], es1.w, et1.w)));
+        const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        if (row < p.M) {
+          typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<u32x4_*>(reinterpret_cast<uint16_t*>(p.C) + (long)row * p.ldc + col) = u32x4_{s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -883,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16dma_m16_kernel(const GemmP
   }
   if (s < nslab) slab(s, I1{}, I1{});
   mma(ga, gb);
-  if constexpr ((VAR & 2) != 0) gemm_epilogue16s<EK, WAVES_M, WAVES_N, FM, FN, (VAR & 4) != 0>(p, acc, row0, col0, tile_n, smem);
+  if constexpr ((VAR & 2) != 0) gemm_epilogue16s<EK, WAVES_M, WAVES_N, FM, FN, (VAR & 4) != 0, (VAR & 64) != 0, (VAR & 128) != 0>(p, acc, row0, col0, tile_n, smem);
   else gemm_epilogue16<EK, WAVES_M, WAVES_N, FM, FN, (VAR & 4) != 0>(p, acc, row0, col0, tile_n, smem);
 }
 
